@@ -1,0 +1,179 @@
+/*
+ * satools_hip.h — C ABI of libsatools_hip.so: the MI355X (gfx950) kernels under the
+ * SA-toolkit `anonymize` / `model.convert()` hot path.
+ *
+ * The reference (deep-privacy/SA-toolkit) has no FFI on this path: the boundary is a Python
+ * object (`Net.convert/get_bn/get_f0`, egs/vc/libritts/local/tuning/hifigan.py:58-128).  This
+ * library sits UNDER that object: the Python host in `sa-toolkit_amd/` mirrors the reference
+ * interface and calls these entry points through ctypes.  Each entry point below cites the
+ * reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative sat_status on failure and never throws;
+ *     `sat_last_error()` returns a thread-local message for the last failing call;
+ *   - all pointers are caller-owned DEVICE pointers unless a parameter is documented as host;
+ *     nothing is allocated behind the caller's back (workspaces are sized by a query call and
+ *     passed in);
+ *   - `stream` is a hipStream_t passed as void* (the caller's current stream); all work is
+ *     enqueued asynchronously on it, no entry point synchronises;
+ *   - activations are f32, channel-major `[B][C][T]` with T contiguous ("frames of a
+ *     channel are contiguous"), the layout the generator consumes
+ *     (hifigan.py:94-97 concatenates along dim 1 of [B,C,T]).
+ *   - calls are re-entrant and thread-safe for distinct streams/workspaces.
+ */
+#ifndef SATOOLS_HIP_H
+#define SATOOLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAT_ABI_VERSION 1
+
+typedef enum {
+  SAT_OK = 0,
+  SAT_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+  SAT_ERR_HIP = -2,         /* a HIP runtime call failed */
+  SAT_ERR_WORKSPACE = -3,   /* workspace too small */
+  SAT_ERR_NO_DEVICE = -4    /* no gfx950 device visible */
+} sat_status;
+
+int sat_abi_version(void);
+const char* sat_last_error(void);
+/* name of device 0 and its CU count; SAT_ERR_NO_DEVICE without a GPU. `name` is a host buffer. */
+int sat_device_info(char* name, int name_len, int* cu_count);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused 1-D convolution as an implicit GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32;
+ * exact f32, k-ordered fma chain).  One kernel family serves
+ *   - Conv1d / dilated Conv1d of the HiFi-GAN generator  (hifigan/archi.py:40-42, nn.py:96-175)
+ *   - ConvTranspose1d, as a polyphase conv with `up` output phases (archi.py:47-59)
+ *   - TDNNF linearB (unfold + matmul == valid conv over frames, chain/nn.py:267-278) and linearA
+ *   - wav2vec2 conv feature extractor / linear layers / grouped positional conv.
+ *
+ *   y[b, co, q*up + r] = epilogue( sum_{ci,j} W[(co*up + r), ci, j] *
+ *                                   pre(x[b, ci, q*stride + j*dilation - pad_left]) )
+ *   pre(v)      = in_lrelu ? (v > 0 ? v : v*in_slope) : v ;   out-of-range x reads as 0
+ *   epilogue(v) : v += bias[co]; if(res) v += res_scale*res[b,co,(q*up+r)*res_tstride+res_toff];
+ *                 if(ch_scale) v = v*ch_scale[co] + ch_shift[co];  if(relu) v = max(v,0);
+ *                 if(accum) v = y_old + v;  if(accum_div != 0) v = v / accum_div
+ *
+ * Weights are pre-packed by the host (sa-toolkit_amd/packing.py) as
+ *   w_packed[g][cin_pad][ksize][co_pad],  co fastest, cin_pad = roundup(C_in/groups, 16),
+ *   co_pad = roundup(rows_per_group, 64), rows = C_out*up, zero filled.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t B, C_in, T_in;       /* input  [B][C_in][T_in]  */
+  int32_t C_out, T_q;          /* output [B][C_out][T_q*up]; T_q = positions per phase */
+  int32_t ksize, dilation, stride, pad_left;
+  int32_t groups;              /* C_in and C_out divisible by groups */
+  int32_t up;                  /* 1 for a plain conv */
+  int32_t in_lrelu;  float in_slope;
+  int32_t relu;
+  int32_t accum;     float accum_div;
+  float   res_scale; int32_t res_toff, res_tstride;
+  int64_t x_bstride, x_cstride;      /* element strides of x  */
+  int64_t y_bstride, y_cstride;      /* element strides of y  */
+  int64_t res_bstride, res_cstride;  /* element strides of res */
+  const float* bias;       /* [C_out] or NULL */
+  const float* res;        /* residual source or NULL */
+  const float* ch_scale;   /* [C_out] or NULL (BatchNorm1d eval folded: 1/sqrt(var+eps)) */
+  const float* ch_shift;   /* [C_out] or NULL (-mean/sqrt(var+eps)) */
+} sat_conv1d_desc;
+
+int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const float* w_packed, float* y,
+                   void* stream);
+/* cin_pad / co_pad the packed layout must use for this shape (host-side helper, no GPU needed) */
+int sat_conv1d_packed_dims(int C_in, int C_out, int up, int groups, int* cin_pad, int* co_pad);
+/* Polyphase view of ConvTranspose1d(k, stride u, padding pad): output t = q*u + r reads input
+ * s = q + delta with tap j = r + pad - u*delta.  Returns the width of the delta window over all
+ * phases (the `ksize` of the equivalent conv with `up = u`) and its left padding (-delta_min). */
+int sat_convtranspose_phase_dims(int k, int u, int pad, int* ksize, int* pad_left);
+
+/* ------------------------------------------------------------------------------------------
+ * HiFi-GAN generator (CoreHifiGan.forward_resnet, hifigan/archi.py:77-91; ResBlock1,
+ * hifigan/nn.py:93-187).  The handle only stores the architecture and the device pointers of
+ * the packed weights (owned by the caller, which must keep them alive).
+ * Conv ids: 0 = conv_pre; 1..n_ups = ups[i]; then resblock convs in the order
+ * resblocks[rb].convs1[0], convs2[0], convs1[1], convs2[1], convs1[2], convs2[2];
+ * last = conv_post (plain [C][7] weights, not packed).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sat_hifigan sat_hifigan;
+int sat_hifigan_create(sat_hifigan** out, int in_channels, int initial_channels, int n_ups,
+                       const int* up_rates, const int* up_kernels, int n_rb_kernels,
+                       const int* rb_kernels, const int* rb_dilations /* [n_rb_kernels][3] */);
+int sat_hifigan_num_convs(const sat_hifigan* h);
+int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const float* w_packed, const float* bias);
+size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T);
+/* x [B][in_channels][T] -> y [B][1][T*prod(up_rates)+1]  (tanh output, archi.py:87-90) */
+int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, float* y, void* workspace,
+                            size_t workspace_bytes, int B, int T, void* stream);
+void sat_hifigan_destroy(sat_hifigan* h);
+
+/* final stage alone: leaky_relu(0.01) -> ReflectionPad1d((1,0)) -> Conv1d(C,1,7,pad 3) -> tanh
+ * (archi.py:87-90).  x [B][C][T] -> y [B][1][T+1];  w [C][7], bias [1]. */
+int sat_hifigan_convpost_f32(const float* x, const float* w, const float* bias, float* y, int B,
+                             int C, int T, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Kaldi-compatible fbank (satools/satools/kaldifeature.py:461-593, called as
+ * fbank(x*32768, num_mel_bins=80, snip_edges=False) at tdnnf_vq.py:243-244) fused with the
+ * per-utterance mean normalisation UttCMVN() (cmvn.py:157-165) and the replicate padding of
+ * pad_input (tdnnf_vq.py:228-234).
+ *   wav [B][n]  ->  feats [B][n_mel][pad + m + pad],  m = (n + shift/2) / shift
+ * `window` [400] and `mel` [n_mel][257] are device tables built by the host with the
+ * reference's own formulas (povey window; get_mel_banks); `mel_lo/mel_hi` [n_mel] bound the
+ * non-zero bins of each triangular filter; `scale` is the 32768 factor.
+ * workspace: sat_fbank_workspace_bytes(B, n).
+ * ------------------------------------------------------------------------------------------ */
+size_t sat_fbank_workspace_bytes(int B, int n);
+int sat_fbank_cmvn_pad_f32(const float* wav, float* feats, const float* window, const float* mel,
+                           const int32_t* mel_lo, const int32_t* mel_hi, void* workspace,
+                           size_t workspace_bytes, int B, int n, float scale, int n_mel, int pad,
+                           int do_cmvn, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Vector quantiser of the bottleneck layer (VectorQuantizerEMA.forward eval branch,
+ * chain/nn.py:402-476): d = (sum x^2 + sum e^2) - 2 x.e^T in f32, first-minimum argmin,
+ * output x + (e[idx] - x).   z [B][D][T] (channel-major) , codebook [n_codes][D]
+ *   -> q [B][D][T], idx [B][T] (int32), optional dist [B][T][n_codes], optional margin [B][T]
+ * ------------------------------------------------------------------------------------------ */
+int sat_vq_argmin_gather_f32(const float* z, const float* codebook, float* q, int32_t* idx,
+                             float* dist, int B, int D, int T, int n_codes, void* stream);
+
+/* pad frames at both ends: x [B][C][T] -> y [B][C][left+T+right].  Left = first frame replicated.
+ * Right: interleave_right = 0 -> last frame replicated (F.pad(...,"replicate"),
+ * tdnnf_wav2vec2_vq.py:299); interleave_right = 1 -> the reference's pad_input
+ * (tdnnf_vq.py:228-234), whose right side tiles the last frames of ALL utterances of the batch
+ * as one sequence: frame p of utterance b is the last frame of utterance (b*right + p) mod B.
+ * sat_fbank_cmvn_pad_f32 applies the same pad_input rule. */
+int sat_pad_replicate_f32(const float* x, float* y, int B, int C, int T, int left, int right,
+                          int interleave_right, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generator input assembly (Net._forward, hifigan.py:83-97): F0 normalisation statistics are
+ * batch-coupled (UttCMVN(var_norm=True, keep_zeros=True), cmvn.py:143-155), so the mean/std
+ * reduction and the per-element transform are separate calls.
+ *   sat_f0_stats_f32:  f0 [n] -> stats[2] = {mean, std} over the non-zero entries
+ *                      (std = sqrt(unbiased var + 1e-6))
+ *   sat_f0_apply_f32:  in place: voiced -> (v - mean)/std, zeros stay 0; optional quantisation
+ *                      round(v*q)/q (half-to-even) keeping zeros (hifigan/nn.py:28-40);
+ *                      optional additive noise (host-drawn, nn.py:42-62) re-zeroing positions
+ *                      that are 0 after quantisation.
+ *   sat_assemble_input_f32: x[b] = [ bn[b] (C_bn x T) ; nearest-interp f0[b] (1 x T_f0 -> T) ;
+ *                      spk[b] (n_spk values, the one-hot row as f32) broadcast over T ]
+ *                      (F.interpolate nearest + torch.cat, hifigan.py:91-97)
+ * ------------------------------------------------------------------------------------------ */
+int sat_f0_stats_f32(const float* f0, int n, float* stats, void* stream);
+int sat_f0_apply_f32(float* f0, int n, const float* stats, int quant_bins, const float* noise,
+                     void* stream);
+int sat_assemble_input_f32(const float* bn, const float* f0, const float* spk, float* x,
+                           int B, int C_bn, int T, int T_f0, int n_spk, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SATOOLS_HIP_H */

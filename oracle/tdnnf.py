@@ -1,0 +1,94 @@
+"""TDNNF-VQ bottleneck extractor, CPU restatement.
+Reference: egs/asr/librispeech/local/chain/tuning/tdnnf_vq.py:228-257 (extract_bn, pad_input),
+satools/satools/chain/nn.py:267-292 (TDNNF), :338-347 (TDNNFBatchNorm), :402-476 (VQ eval),
+satools/satools/chain/objf.py:137-144 (affine), satools/satools/cmvn.py:157-165 (UttCMVN())."""
+import torch
+import torch.nn.functional as F
+
+from . import fbank as fb
+
+
+def pad_input(x, pad):
+    """tdnnf_vq.py:228-234; x [N, T, C].  Left: the first frame of each utterance `pad` times.
+    Right: the reference builds it as `x[:, -1, :].repeat(1, pad, 1).reshape(N, -1, C)`; the
+    2-D slice is tiled as ONE sequence [last_0, last_1, ..., last_{N-1}, last_0, ...] of N*pad
+    frames and then cut into N pieces, so for N > 1 right-pad frame p of utterance b is the last
+    frame of utterance (b*pad + p) mod N.  Restated as is (it is what the reference computes)."""
+    if pad <= 0:
+        return x
+    N = x.shape[0]
+    left = x[:, :1].expand(-1, pad, -1)
+    src = (torch.arange(N * pad) % N).view(N, pad)
+    right = x[:, -1, :][src]
+    return torch.cat([left, x, right], 1)
+
+
+def vq(z, codebook):
+    """chain/nn.py:424-459 eval branch.  z [N, T, D] -> (quantized, indices [N*T], distances)"""
+    flat = z.reshape(-1, z.shape[-1])
+    dist = (torch.sum(flat ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1)
+            - 2 * torch.matmul(flat, codebook.t()))
+    idx = torch.argmin(dist, dim=1)
+    enc = torch.zeros(idx.shape[0], codebook.shape[0], dtype=torch.float32)
+    enc.scatter_(1, idx.unsqueeze(1), 1)
+    quant = torch.matmul(enc, codebook).view(z.shape)
+    quant = z + (quant - z)
+    return quant, idx, dist
+
+
+def tdnnf_layer(sd, prefix, x, ctx, sub, bypass, return_bottleneck=False, aux=None):
+    """one TDNNFBatchNorm; x [N, T, D].  prefix e.g. 'tdnnfs.0.'"""
+    N, T, D = x.shape
+    win = x.reshape(N, -1).unfold(1, D * ctx, D * sub).contiguous()
+    wB, bB = sd[prefix + "tdnn.linearB.inner_nat.weight"], sd[prefix + "tdnn.linearB.inner_nat.bias"]
+    z = win.matmul(wB.t())
+    z = z + bB
+    cb_key = prefix + "bottleneck_func.quant._embedding.weight"
+    if cb_key in sd:
+        zq, idx, dist = vq(z, sd[cb_key])
+        if aux is not None:
+            aux.update(z=z, idx=idx.view(N, -1), dist=dist.view(N, z.shape[1], -1))
+        z = zq
+    if return_bottleneck:
+        return z
+    y = F.linear(z, sd[prefix + "tdnn.linearA.weight"], sd[prefix + "tdnn.linearA.bias"])
+    if bypass:
+        l = ctx // 2 if ctx > 1 else 0
+        r = -l if (ctx > 1 and ctx % 2 == 1) else None
+        y = y + x[:, l:r:sub, :] * 0.66
+    y = F.batch_norm(y.permute(0, 2, 1), sd[prefix + "bn.running_mean"], sd[prefix + "bn.running_var"],
+                     None, None, False, 0.1, 1e-5).permute(0, 2, 1)
+    return F.relu(y)
+
+
+FBANK_KS = [3, 3, 3, 1, 3, 3, 3, 3, 3, 3, 3, 3]
+FBANK_SUB = [1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1]
+W2V2_KS = [3, 3, 3]
+W2V2_SUB = [1, 1, 1]
+
+
+def run_stack(sd, x, ks, subs, aux=None, hook=None):
+    """tdnn1, tdnnfs[0,2,...] and the bottleneck of the last one (tdnnf_vq.py:250-256)"""
+    feat = x.shape[-1]
+    x = tdnnf_layer(sd, "tdnn1.", x, ks[0], subs[0], bypass=(feat == 1024))
+    if hook:
+        hook("tdnn1", x)
+    for i in range(1, len(ks) - 1):
+        name = f"tdnnfs.{2 * (i - 1)}."
+        x = tdnnf_layer(sd, name, x, ks[i], subs[i], bypass=True)
+        if hook:
+            hook(name[:-1], x)
+    last = f"tdnnfs.{2 * (len(ks) - 2)}."
+    return tdnnf_layer(sd, last, x, ks[-1], subs[-1], bypass=False, return_bottleneck=True, aux=aux)
+
+
+def extract_bn_fbank(sd, wav, aux=None, hook=None):
+    """sd: state dict of the ASR-BN net (keys without the 'bn_extractor.' prefix).
+    wav [N, n] in [-1, 1]  ->  [N, T, 256]"""
+    x = wav.detach().clone() * 32768
+    x = fb.fbank(x, 80)
+    if hook:
+        hook("fbank", x)
+    x = x - x.mean(dim=1).unsqueeze(1)          # UttCMVN(): mean over frames
+    x = pad_input(x, 19)
+    return run_stack(sd, x, FBANK_KS, FBANK_SUB, aux=aux, hook=hook)

@@ -1,0 +1,118 @@
+"""ctypes binding of libsatools_hip.so (include/satools_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, an exception
+is raised.  Nothing here imports from `oracle/`."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsatools_hip.so")
+
+c_float_p = C.c_void_p  # raw device pointers travel as integers
+
+
+class SatError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mirror of sat_conv1d_desc"""
+    _fields_ = [
+        ("B", C.c_int32), ("C_in", C.c_int32), ("T_in", C.c_int32),
+        ("C_out", C.c_int32), ("T_q", C.c_int32),
+        ("ksize", C.c_int32), ("dilation", C.c_int32), ("stride", C.c_int32), ("pad_left", C.c_int32),
+        ("groups", C.c_int32), ("up", C.c_int32),
+        ("in_lrelu", C.c_int32), ("in_slope", C.c_float),
+        ("relu", C.c_int32),
+        ("accum", C.c_int32), ("accum_div", C.c_float),
+        ("res_scale", C.c_float), ("res_toff", C.c_int32), ("res_tstride", C.c_int32),
+        ("x_bstride", C.c_int64), ("x_cstride", C.c_int64),
+        ("y_bstride", C.c_int64), ("y_cstride", C.c_int64),
+        ("res_bstride", C.c_int64), ("res_cstride", C.c_int64),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("ch_scale", C.c_void_p), ("ch_shift", C.c_void_p),
+    ]
+
+
+_PROTOS = {
+    "sat_abi_version": (C.c_int, []),
+    "sat_last_error": (C.c_char_p, []),
+    "sat_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    "sat_conv1d_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sat_conv1d_packed_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sat_convtranspose_phase_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sat_hifigan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sat_hifigan_num_convs": (C.c_int, [C.c_void_p]),
+    "sat_hifigan_set_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "sat_hifigan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "sat_hifigan_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                          C.c_int, C.c_void_p]),
+    "sat_hifigan_destroy": (None, [C.c_void_p]),
+    "sat_hifigan_convpost_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p]),
+    "sat_fbank_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sat_fbank_cmvn_pad_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                         C.c_int, C.c_void_p]),
+    "sat_vq_argmin_gather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sat_pad_replicate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]),
+    "sat_f0_stats_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "sat_f0_apply_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "sat_assemble_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """names declared in include/satools_hip.h that the library must export"""
+    return sorted(_PROTOS)
+
+
+def lib():
+    """load (once) and return the ctypes library; raises if it has not been built"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SatError(
+                f"{LIB_PATH} is missing: build it with `python sa-toolkit_amd/build.py` "
+                "(there is no CPU fallback for the HIP path)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.sat_abi_version() != 1:
+            raise SatError("libsatools_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().sat_last_error().decode("utf-8", "replace")
+        raise SatError(f"{what} failed ({status}): {msg}")
+
+
+def ptr(t):
+    """device pointer of a contiguous f32/i32 CUDA(HIP) tensor, None -> NULL"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SatError("HIP entry points need device tensors; got a CPU tensor (no CPU fallback)")
+    if not t.is_contiguous():
+        raise SatError("HIP entry points need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])

@@ -1,0 +1,162 @@
+"""The anonymizer `Net` behind the reference's model-config interface
+(egs/vc/libritts/local/tuning/hifigan.py:19-131): convert / extract_features / _forward /
+get_bn / get_f0 / set_f0 / get_spk_id / f0_transformation, attributes spk, utt2spk,
+bn_extractor, hifigan, f0_yaapt_opts.  Every tensor op of the path runs in libsatools_hip.so."""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, f0_transforms, ops
+from .hifigan import CoreHifiGan
+
+
+class SimpleNamespace:
+    """attribute bag whose missing attributes read as None
+    (satools/satools/utils/general.py:9-32: `args.f0_transformation` may be absent)"""
+
+    def __init__(self, /, **kwargs):
+        self.__dict__.update(kwargs)
+
+    def __getattr__(self, key):
+        return self.__dict__.get(key)
+
+    def __getitem__(self, key):
+        return self.__dict__.get(key)
+
+    def __repr__(self):
+        return "SimpleNamespace({})".format(", ".join(f"{k}={v!r}" for k, v in self.__dict__.items()))
+
+
+def build(args):
+    """factory with the reference's signature: build(args) -> Net class (hifigan.py:18-131)"""
+    from . import infer_helper
+
+    class Net(nn.Module):
+        def __init__(self, utt2spk):
+            super().__init__()
+            self.bn_extractor_model = args.asrbn_model
+            self.bn_extractor = infer_helper.load_model(self.bn_extractor_model, from_file=__file__, load_weight=False)
+            self.bn_extractor.eval()
+            self.f0_yaapt_opts = {
+                "frame_length": 35.0,
+                "frame_space": 20.0,
+                "nccf_thresh1": 0.25,
+                "tda_frame_length": 25.0,
+            }
+            self.utt2spk = utt2spk
+            self.spk = sorted(set([v for v in utt2spk.values()]))
+            self.f0: Optional[torch.Tensor] = None
+            self.hifigan = CoreHifiGan(
+                imput_dim=256 + 1 + len(self.spk),
+                upsample_rates=[5, 4, 4, 2, 2],
+                upsample_kernel_sizes=[11, 8, 8, 4, 4],
+            )
+
+        # ---- nn.Module surface quirks kept from the reference --------------------------------
+        def remove_weight_norm(self):
+            self.hifigan.remove_weight_norm()
+
+        def train(self, mode=True):
+            # hifigan.py:54-56: keeps the extractor in eval and returns None (so .eval() too)
+            super().train(mode)
+            self.bn_extractor.eval()
+
+        def _device(self):
+            return next(self.hifigan.parameters()).device
+
+        def _to_device(self, t):
+            dev = self._device()
+            if dev.type != "cuda":
+                raise _lib.SatError("the model is on the CPU: call .to('cuda') first "
+                                    "(the MI355X path has no CPU fallback)")
+            return t.to(dev)
+
+        # ---- feature extractors (decorators are pass-through under SA_JIT_TWEAK=true,
+        #      utils/feature_extractor_decorator.py:60-71; parse_wavinfo_wav clones) -------------
+        def get_bn(self, wavinfo):
+            wav = self._to_device(getattr(wavinfo, "wav", wavinfo).detach()).clone()
+            return self.bn_extractor.extract_bn(wav).permute(0, 2, 1)
+
+        def set_f0(self, f0):
+            self.f0 = f0
+
+        def get_f0(self, wavinfo):
+            from . import f0 as f0_hip
+            wav = getattr(wavinfo, "wav", wavinfo).detach()
+            out = f0_hip.yaapt(self._to_device(wav).clone(), self.f0_yaapt_opts)
+            return out.to(wav.device)
+
+        def get_spk_id(self, wavinfo, target=None):
+            if not target:
+                target = [self.utt2spk[wavinfo.name]]
+            return F.one_hot(torch.tensor([self.spk.index(t) for t in ([target] if isinstance(target, str) else target)]),
+                             num_classes=len(self.spk))
+
+        def extract_features(self, x, target):
+            if self.f0 is not None:
+                f0, self.f0 = self.f0, None
+            else:
+                f0 = self.get_f0(x).unsqueeze(0)
+            bn = self.get_bn(x)
+            spk_id = self.get_spk_id(x, target)
+            return (f0, bn, spk_id)
+
+        def convert(self, x, target):
+            (f0, bn, spk_id) = self.extract_features(x, target)
+            return self._forward(f0, bn, spk_id).squeeze(0)
+
+        def f0_transformation(self, f0):
+            """host-level entry kept for API parity (hifigan.py:73-81); [B,1,T] device tensor"""
+            spec = args.f0_transformation
+            quant = f0_transforms.parse_quant_bins(spec) if spec and "quant" in spec else 0
+            noise = None
+            if spec and "awgn" in spec:
+                noise = f0_transforms.draw_awgn(f0.shape, f0_transforms.parse_awgn_db(spec)).to(f0.dtype).to(f0.device)
+            if spec and "mean-reverv" in spec:
+                raise NotImplementedError("f0 transformation 'mean-reverv' is not part of the accelerated path")
+            if quant or noise is not None:
+                f0 = f0.clone()
+                self._apply_transform_(f0, quant, noise)
+            return f0
+
+        @staticmethod
+        def _apply_transform_(f0, quant, noise):
+            n = f0.numel()
+            from ._lib import check, lib, ptr, stream
+            ones = torch.tensor([0.0, 1.0], dtype=torch.float32, device=f0.device)  # identity normalisation
+            check(lib().sat_f0_apply_f32(ptr(f0), n, ptr(ones), int(quant), ptr(noise), stream()), "sat_f0_apply_f32")
+
+        def _forward(self, f0, bn, spk_id):
+            dev = self._device()
+            if dev.type != "cuda":
+                raise _lib.SatError("the model is on the CPU: call .to('cuda') first (no CPU fallback)")
+            # f0 = self.f0_norm(f0): batch-coupled, IN PLACE on the caller's tensor (cmvn.py:143-155)
+            f0_in = f0
+            f0_d = f0_in.to(device=dev, dtype=torch.float32)
+            if not f0_d.is_contiguous():
+                f0_d = f0_d.contiguous()
+            shared = f0_in.is_cuda and f0_d.data_ptr() == f0_in.data_ptr()
+            ops.f0_norm_transform_(f0_d)
+            if not shared:
+                f0_in.copy_(f0_d)  # the reference leaves the normalised values in the caller's tensor
+            if f0_d.dim() == 2:
+                f0_d = f0_d.unsqueeze(0)
+            f0_d = f0_d.permute(1, 0, 2).contiguous()  # [B, 1, T]
+            f0_d = self.f0_transformation(f0_d)
+            bn = bn.to(device=dev, dtype=torch.float32).contiguous()
+            B, c_bn, T = bn.shape
+            if f0_d.shape[0] != B:
+                raise AssertionError("f0 and bn batch sizes differ")
+            spk = spk_id.to(device=dev, dtype=torch.float32).contiguous()
+            assert B == spk.shape[0], \
+                "len(target) != len(input_wav), check if the waveform batch size == target=len(['6081','4214'])"
+            x = ops.assemble_input(bn, f0_d.reshape(B, -1), spk, spk.shape[1])
+            y, _ = self.hifigan(x)
+            return y.to(torch.float32)
+
+        def forward(self, egs_with_feat):
+            return self._forward(egs_with_feat["get_f0"], egs_with_feat["get_bn"], egs_with_feat["get_spk_id"])
+
+    return Net

@@ -1,0 +1,201 @@
+"""ASR-bottleneck extractors behind the reference's `Net.extract_bn` interface.
+
+fbank tag:    egs/asr/librispeech/local/chain/tuning/tdnnf_vq.py:20-286
+wav2vec2 tag: egs/asr/librispeech/local/chain/tuning/tdnnf_wav2vec2_vq.py:21-345
+
+A TDNNF layer (satools/satools/chain/nn.py:267-292) is `unfold` over `context_len` frames
+followed by two matmuls; with activations kept channel-major [B, C, T] that is a *valid*
+conv over frames (kernel = context_len, stride = subsampling_factor) into the bottleneck and a
+1x1 conv out of it, whose epilogue carries the bypass `+0.66*input[:, l:r:sub]`, the eval-mode
+BatchNorm1d(affine=False) and the ReLU (chain/nn.py:338-347).  Both run on the fused MFMA conv
+kernel; the VQ bottleneck (chain/nn.py:402-476) has its own kernel.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops, packing
+from .params import TDNNFBatchNormParams, _InnerNat, tdnnf_stack
+
+
+def get_padding(kernel_sizes, subsampling_factors):
+    """ChainE2EModel.get_padding (satools/satools/chain/model.py:466-473)"""
+    pad, g = 0, 1
+    for k, s in zip(kernel_sizes, subsampling_factors):
+        pad += (k - 1) * g
+        g *= s
+    return int(pad)
+
+
+# ---- fbank tables (kaldifeature.py:144-146 povey window; :386-457 get_mel_banks) ----------
+def povey_window(n=400):
+    return torch.hann_window(n, periodic=False, dtype=torch.float32).pow(0.85)
+
+
+def mel_banks(num_bins=80, n_fft=512, sample_freq=16000.0, low_freq=20.0, high_freq=0.0):
+    """triangular mel filters [num_bins, n_fft/2 + 1] (last column zero), f32, computed with the
+    same operation order as the reference so the table is bit-identical to its `bins`."""
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    bin_width = sample_freq / n_fft
+    mel = lambda f: 1127.0 * math.log(1.0 + f / 700.0)
+    mel_lo, mel_hi = mel(low_freq), mel(high_freq)
+    delta = (mel_hi - mel_lo) / (num_bins + 1)
+    b = torch.arange(num_bins).unsqueeze(1)
+    left = mel_lo + b * delta
+    center = mel_lo + (b + 1.0) * delta
+    right = mel_lo + (b + 2.0) * delta
+    m = (1127.0 * (1.0 + (bin_width * torch.arange(n_fft / 2)) / 700.0).log()).unsqueeze(0)
+    up = (m - left) / (center - left)
+    down = (right - m) / (right - center)
+    bins = torch.max(torch.zeros(1), torch.min(up, down))
+    return torch.nn.functional.pad(bins, (0, 1)).to(torch.float32).contiguous()
+
+
+class _LayerCache:
+    """device-side, kernel-ready form of one TDNNFBatchNorm layer"""
+    __slots__ = ("wB", "bB", "wA", "bA", "scale", "shift", "codebook")
+
+
+class _TdnnfBase(nn.Module):
+    """shared machinery of the two ASR-BN nets: TDNNF stack forward on the HIP kernels"""
+
+    def _init_cache(self):
+        self._cache = None
+        self._cache_key = None
+
+    def _stack_layers(self):
+        return [self.tdnn1] + [m for m in self.tdnnfs if isinstance(m, TDNNFBatchNormParams)]
+
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _prepare(self, device):
+        key = self._param_key()
+        if self._cache_key == key:
+            return
+        cache = []
+        for lay in self._stack_layers():
+            c = _LayerCache()
+            wB = lay.tdnn.linearB.inner_nat.weight.detach().to(device=device, dtype=torch.float32)
+            bott, kin = wB.shape
+            ctx, feat = lay.context_len, lay.feat_dim
+            assert kin == ctx * feat
+            # unfold window = ctx consecutive frames of `feat` values: column j*feat + c
+            c.wB = packing.pack_conv_weight(wB.reshape(bott, ctx, feat).permute(0, 2, 1).contiguous())
+            c.bB = lay.tdnn.linearB.inner_nat.bias.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+            wA = lay.tdnn.linearA.weight.detach().to(device=device, dtype=torch.float32)
+            c.wA = packing.pack_conv_weight(wA.unsqueeze(-1).contiguous())
+            c.bA = lay.tdnn.linearA.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+            mean = lay.bn.running_mean.detach().to(device=device, dtype=torch.float32)
+            var = lay.bn.running_var.detach().to(device=device, dtype=torch.float32)
+            # eval BatchNorm1d(affine=False): y = x*invstd + (-mean*invstd), eps = 1e-5
+            c.scale = (1.0 / torch.sqrt(var + 1e-5)).contiguous()
+            c.shift = (-mean * c.scale).contiguous()
+            c.codebook = None
+            if hasattr(lay, "bottleneck_func"):
+                c.codebook = lay.bottleneck_func.quant._embedding.weight.detach().to(
+                    device=device, dtype=torch.float32).contiguous()
+            cache.append(c)
+        self._cache = cache
+        self._cache_key = key
+
+    def _tdnnf_layer(self, lay, c, x, return_bottleneck=False, want_aux=False):
+        """x [B, feat, T] -> [B, out, T'] (or the bottleneck [B, bott, T'])"""
+        ctx, sub = lay.context_len, int(lay.subsampling_factor)
+        z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, stride=sub, pad_left=0, pad_right=0)
+        aux = None
+        if c.codebook is not None:
+            zq, idx, dist = ops.vq(z, c.codebook, want_dist=want_aux)
+            aux = (z, idx, dist)
+            z = zq
+        if return_bottleneck:
+            return (z, aux) if want_aux else z
+        kw = {}
+        if lay.use_bypass:
+            lidx = ctx // 2 if ctx > 1 else 0
+            if ctx == 2:
+                lidx = 1
+            kw = dict(res=x, res_scale=lay.bypass_scale, res_toff=lidx, res_tstride=sub)
+        return ops.conv1d(z, c.wA, lay.out_dim, 1, bias=c.bA, ch_scale=c.scale, ch_shift=c.shift, relu=True, **kw)
+
+    def _run_stack(self, x, want_aux=False):
+        """x [B, C, T] (already padded) through tdnn1, tdnnfs[:-2], and the bottleneck of tdnnfs[-2]"""
+        self._prepare(x.device)
+        layers = self._stack_layers()
+        for lay, c in zip(layers[:-1], self._cache[:-1]):
+            x = self._tdnnf_layer(lay, c, x)
+        return self._tdnnf_layer(layers[-1], self._cache[-1], x, return_bottleneck=True, want_aux=want_aux)
+
+
+class _AsrHead(nn.Module):
+    """the ASR output half of the reference nets (tdnnfs_after, prefinal_*, *_output): out of
+    the anonymization path but part of the checkpoint, so the tensors are held."""
+
+    @staticmethod
+    def attach(net, hidden, bottleneck, prefinal, ks, subs, output_dim):
+        seq = []
+        from .params import _Identity
+        for k, s in zip(ks, subs):
+            seq += [TDNNFBatchNormParams(hidden, hidden, bottleneck, k, s), _Identity()]
+        net.tdnnfs_after = nn.Sequential(*seq)
+        net.prefinal_chain = TDNNFBatchNormParams(hidden, hidden, prefinal, 1, 1)
+        net.prefinal_xent = TDNNFBatchNormParams(hidden, hidden, prefinal, 1, 1)
+        net.chain_output = _InnerNat(hidden, output_dim)
+        net.xent_output = _InnerNat(hidden, output_dim)
+
+
+class TdnnfVqNet(_TdnnfBase):
+    """fbank front end + 12 TDNNF layers + VQ bottleneck (tdnnf_vq.py:20-168)."""
+
+    def __init__(self, output_dim, hidden_dim=1024, bottleneck_dim=128, prefinal_bottleneck_dim=256,
+                 kernel_size_list=([3, 3, 3, 1, 3, 3, 3, 3, 3, 3, 3, 3], [1, 3, 3, 3]),
+                 subsampling_factor_list=([1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1], [1.5, 1, 1, 1]),
+                 p_dropout=0.1, codebook_size=48):
+        super().__init__()
+        self.input_dim = 80
+        self.output_dim = output_dim
+        self.padding = get_padding(kernel_size_list[0], subsampling_factor_list[0]) // 2
+        self.padding_after = get_padding(kernel_size_list[1], subsampling_factor_list[1]) // 2
+        self.tdnn1, self.tdnnfs = tdnnf_stack(self.input_dim, hidden_dim, bottleneck_dim, prefinal_bottleneck_dim,
+                                              kernel_size_list[0], subsampling_factor_list[0], codebook_size)
+        _AsrHead.attach(self, hidden_dim, bottleneck_dim, prefinal_bottleneck_dim, kernel_size_list[1],
+                        subsampling_factor_list[1], output_dim)
+        self._tables = None
+        self._init_cache()
+
+    def _fbank_tables(self, device):
+        if self._tables is None or self._tables[0].device != device:
+            mel = mel_banks(self.input_dim)
+            nz = mel > 0
+            lo = torch.where(nz.any(1), nz.float().argmax(1), torch.zeros(mel.shape[0], dtype=torch.long))
+            hi = mel.shape[1] - torch.flip(nz, [1]).float().argmax(1)
+            hi = torch.where(nz.any(1), hi, torch.zeros_like(hi))
+            self._tables = (povey_window().to(device), mel.to(device), lo.to(torch.int32).to(device),
+                            hi.to(torch.int32).to(device))
+        return self._tables
+
+    def features(self, x):
+        """fbank + UttCMVN + pad_input -> [N, 80, T + 2*padding] (x already scaled)"""
+        win, mel, lo, hi = self._fbank_tables(x.device)
+        return ops.fbank_cmvn_pad(x, win, mel, lo, hi, scale=1.0, pad=self.padding, cmvn=True)
+
+    def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
+        """inputs [N, n] -> [N, T, 256]   (tdnnf_vq.py:236-257; like the reference this scales
+        its argument in place by 32768 — callers go through get_bn, which clones)"""
+        if not x.is_cuda:
+            raise _lib.SatError("extract_bn runs on the HIP device only (no CPU fallback); move the input to 'cuda'")
+        if x.dim() != 2:
+            raise _lib.SatError("extract_bn expects a 2-dimensional tensor [N, samples]")
+        x *= 32768
+        feats = self.features(x.to(torch.float32))
+        out = self._run_stack(feats, want_aux=want_aux)
+        if want_aux:
+            return out[0].permute(0, 2, 1), out[1]
+        return out.permute(0, 2, 1)
+
+    def forward(self, x):
+        raise NotImplementedError("the ASR output head (chain/xent log-likelihoods) is outside the anonymization "
+                                  "hot path (SURVEY §8 f4); only extract_bn is implemented")

@@ -1,0 +1,224 @@
+// Bottleneck vector quantiser, F0 normalisation / transformation and generator-input assembly.
+//
+// Reference: VectorQuantizerEMA.forward (eval), satools/satools/chain/nn.py:402-476;
+// UttCMVN(var_norm=True, keep_zeros=True), satools/satools/cmvn.py:143-155;
+// quantize_f0 / awgn_f0, satools/satools/hifigan/nn.py:28-62;
+// Net._forward input assembly, egs/vc/libritts/local/tuning/hifigan.py:83-97.
+#include "common.h"
+
+namespace sat {
+
+constexpr int VQ_MAX_CODES = 64;
+
+// One thread per frame; frames of a channel are contiguous so the wave reads z coalesced.
+// The codebook sits transposed in LDS ([d][code]) and is read as a broadcast.
+// Arithmetic follows the reference formula and association exactly:
+//   dist[e] = (sum_d x_d^2 + sum_d e_d^2) - 2 * (x . e)      all f32, first minimum wins.
+template <int NC>
+__global__ void __launch_bounds__(64) vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                float* __restrict__ q, int* __restrict__ idx_out,
+                                                float* __restrict__ dist_out, int D, int T, int n_codes) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [D][NC] codebook^T, then [NC] norms
+  float* et = lds;
+  float* ee = lds + (size_t)D * NC;
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  for (int i = threadIdx.x; i < D * NC; i += 64) {
+    const int d = i / NC, e = i - d * NC;
+    et[i] = e < n_codes ? cb[(size_t)e * D + d] : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < NC) {
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float v = et[d * NC + threadIdx.x];
+      s += v * v;
+    }
+    ee[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (t >= T) return;
+  const float* zb = z + (size_t)b * D * T + t;
+  float dot[NC];
+#pragma unroll
+  for (int e = 0; e < NC; ++e) dot[e] = 0.f;
+  float xx = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float x = zb[(size_t)d * T];
+    xx += x * x;
+    const float* er = et + d * NC;
+#pragma unroll
+    for (int e = 0; e < NC; ++e) dot[e] = fmaf(x, er[e], dot[e]);
+  }
+  int best = 0;
+  float bestd = 0.f;
+#pragma unroll
+  for (int e = 0; e < NC; ++e) {
+    if (e < n_codes) {
+      const float dd = (xx + ee[e]) - 2.f * dot[e];
+      if (dist_out) dist_out[((size_t)b * T + t) * n_codes + e] = dd;
+      if (e == 0 || dd < bestd) {
+        bestd = dd;
+        best = e;
+      }
+    }
+  }
+  idx_out[(size_t)b * T + t] = best;
+  float* qb = q + (size_t)b * D * T + t;
+  for (int d = 0; d < D; ++d) {
+    const float x = zb[(size_t)d * T];
+    const float e = et[d * NC + best];
+    qb[(size_t)d * T] = x + (e - x);  // `inputs + (quantized - inputs)` (chain/nn.py:459)
+  }
+}
+
+// ---- F0 statistics over the voiced (non-zero) entries of the whole batch ----
+__global__ void __launch_bounds__(1024) f0_stats_kernel(const float* __restrict__ f0, int n, float* __restrict__ stats) {
+  __shared__ float s_a[16];
+  __shared__ float s_b[16];
+  __shared__ float s_mean;
+  const int tid = threadIdx.x;
+  float sum = 0.f, cnt = 0.f;
+  for (int i = tid; i < n; i += 1024) {
+    const float v = f0[i];
+    if (v != 0.f) {
+      sum += v;
+      cnt += 1.f;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_xor(sum, off, 64);
+    cnt += __shfl_xor(cnt, off, 64);
+  }
+  if ((tid & 63) == 0) {
+    s_a[tid >> 6] = sum;
+    s_b[tid >> 6] = cnt;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float S = 0.f, C = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      S += s_a[i];
+      C += s_b[i];
+    }
+    s_mean = S / C;  // NaN for an all-unvoiced batch, as torch's mean of an empty tensor
+    s_b[0] = C;
+  }
+  __syncthreads();
+  const float mean = s_mean;
+  const float C = s_b[0];
+  __syncthreads();
+  float ss = 0.f;
+  for (int i = tid; i < n; i += 1024) {
+    const float v = f0[i];
+    if (v != 0.f) {
+      const float d = v - mean;
+      ss += d * d;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  if ((tid & 63) == 0) s_a[tid >> 6] = ss;
+  __syncthreads();
+  if (tid == 0) {
+    float S = 0.f;
+    for (int i = 0; i < 16; ++i) S += s_a[i];
+    const float var = S / (C - 1.f);  // unbiased, NaN when one voiced value (torch.var)
+    stats[0] = mean;
+    stats[1] = sqrtf(var + 1e-6f);
+  }
+}
+
+__global__ void __launch_bounds__(256) f0_apply_kernel(float* __restrict__ f0, int n, const float* __restrict__ stats,
+                                                       int quant_bins, const float* __restrict__ noise) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = f0[i];
+  if (v != 0.f) {
+    v = v - stats[0];
+    v = v / stats[1];
+  }
+  if (quant_bins > 0) {
+    if (v != 0.f) v = rintf(v * (float)quant_bins) / (float)quant_bins;  // torch.round: half to even
+  }
+  if (noise) {
+    if (v != 0.f) v = v + noise[i];  // positions that are 0 after quantisation stay 0
+  }
+  f0[i] = v;
+}
+
+// x[b] = [ bn[b] ; nearest-interpolated f0[b] ; spk[b] (the one-hot row as f32) broadcast over T ]
+__global__ void __launch_bounds__(256) assemble_kernel(const float* __restrict__ bn, const float* __restrict__ f0,
+                                                       const float* __restrict__ spk, float* __restrict__ x, int C_bn,
+                                                       int T, int T_f0, int n_spk) {
+  const int b = blockIdx.z;
+  const int c = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int C = C_bn + 1 + n_spk;
+  float v;
+  if (c < C_bn) {
+    v = bn[((size_t)b * C_bn + c) * T + t];
+  } else if (c == C_bn) {
+    // F.interpolate(mode='nearest'): src = min(floor(dst * (in/out)), in-1), scale in f32
+    const float scale = (float)T_f0 / (float)T;
+    int s = (int)floorf((float)t * scale);
+    s = s < T_f0 - 1 ? s : T_f0 - 1;
+    v = f0[(size_t)b * T_f0 + s];
+  } else {
+    v = spk[(size_t)b * n_spk + (c - C_bn - 1)];  // nearest interpolation of a length-1 axis = broadcast
+  }
+  x[((size_t)b * C + c) * T + t] = v;
+}
+
+}  // namespace sat
+
+using namespace sat;
+
+extern "C" int sat_vq_argmin_gather_f32(const float* z, const float* codebook, float* q, int32_t* idx, float* dist,
+                                        int B, int D, int T, int n_codes, void* stream) {
+  SAT_REQUIRE(z && codebook && q && idx, "vq: null pointer");
+  SAT_REQUIRE(B > 0 && D > 0 && T > 0 && n_codes > 0 && n_codes <= VQ_MAX_CODES, "vq: unsupported sizes (n_codes <= %d)",
+              VQ_MAX_CODES);
+  dim3 grid(ceil_div(T, 64), B);
+  if (n_codes <= 48) {
+    const size_t lds = ((size_t)D * 48 + 48) * sizeof(float);
+    SAT_REQUIRE(lds <= 160 * 1024, "vq: codebook does not fit LDS");
+    if (lds > 64 * 1024)
+      SAT_HIP(hipFuncSetAttribute((const void*)vq_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(vq_kernel<48>, grid, dim3(64), lds, (hipStream_t)stream, z, codebook, q, idx, dist, D, T, n_codes);
+  } else {
+    const size_t lds = ((size_t)D * 64 + 64) * sizeof(float);
+    SAT_REQUIRE(lds <= 160 * 1024, "vq: codebook does not fit LDS");
+    if (lds > 64 * 1024)
+      SAT_HIP(hipFuncSetAttribute((const void*)vq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(vq_kernel<64>, grid, dim3(64), lds, (hipStream_t)stream, z, codebook, q, idx, dist, D, T, n_codes);
+  }
+  SAT_LAUNCH_CHECK("vq_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_f0_stats_f32(const float* f0, int n, float* stats, void* stream) {
+  SAT_REQUIRE(f0 && stats && n > 0, "f0_stats: bad arguments");
+  hipLaunchKernelGGL(f0_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, f0, n, stats);
+  SAT_LAUNCH_CHECK("f0_stats_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_f0_apply_f32(float* f0, int n, const float* stats, int quant_bins, const float* noise,
+                                void* stream) {
+  SAT_REQUIRE(f0 && stats && n > 0 && quant_bins >= 0, "f0_apply: bad arguments");
+  hipLaunchKernelGGL(f0_apply_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, f0, n, stats,
+                     quant_bins, noise);
+  SAT_LAUNCH_CHECK("f0_apply_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_assemble_input_f32(const float* bn, const float* f0, const float* spk, float* x, int B,
+                                      int C_bn, int T, int T_f0, int n_spk, void* stream) {
+  SAT_REQUIRE(bn && f0 && (spk || n_spk == 0) && x, "assemble_input: null pointer");
+  SAT_REQUIRE(B > 0 && C_bn > 0 && T > 0 && T_f0 > 0 && n_spk >= 0, "assemble_input: bad sizes");
+  dim3 grid(ceil_div(T, 256), C_bn + 1 + n_spk, B);
+  hipLaunchKernelGGL(assemble_kernel, grid, dim3(256), 0, (hipStream_t)stream, bn, f0, spk, x, C_bn, T, T_f0, n_spk);
+  SAT_LAUNCH_CHECK("assemble_kernel");
+  return SAT_OK;
+}

@@ -1,0 +1,42 @@
+// Shared host-side helpers for libsatools_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/satools_hip.h"
+
+namespace sat {
+
+void set_error(const char* fmt, ...);
+
+inline int check_hip(hipError_t e, const char* what) {
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return SAT_ERR_HIP;
+  }
+  return SAT_OK;
+}
+
+#define SAT_HIP(call)                                   \
+  do {                                                  \
+    int _s = ::sat::check_hip((call), #call);           \
+    if (_s != SAT_OK) return _s;                        \
+  } while (0)
+
+#define SAT_LAUNCH_CHECK(name) SAT_HIP(hipGetLastError())
+
+#define SAT_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::sat::set_error(__VA_ARGS__);    \
+      return SAT_ERR_INVALID;           \
+    }                                   \
+  } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace sat

@@ -1,0 +1,289 @@
+// HiFi-GAN generator forward on gfx950: orchestration over the fused conv1d kernel plus the
+// streaming output stage.  Reference: CoreHifiGan.forward_resnet, satools/satools/hifigan/
+// archi.py:77-91; ResBlock1.forward, satools/satools/hifigan/nn.py:179-186.
+#include <vector>
+
+#include "common.h"
+
+namespace sat {
+
+// polyphase view of ConvTranspose1d(k, stride u, padding pad): output t = q*u + r reads input
+// positions s = q + delta with tap j = r + pad - u*delta, 0 <= j < k.  Returns the tap window
+// [dmin, dmax] over all phases.
+static void phase_window(int k, int u, int pad, int* dmin, int* dmax) {
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int r = 0; r < u; ++r) {
+    for (int d = -k; d <= k; ++d) {
+      const int j = r + pad - u * d;
+      if (j >= 0 && j < k) {
+        if (d < lo) lo = d;
+        if (d > hi) hi = d;
+      }
+    }
+  }
+  *dmin = lo;
+  *dmax = hi;
+}
+
+// ---- output stage: leaky_relu(0.01) -> ReflectionPad1d((1,0)) -> Conv1d(C,1,7,pad=3) -> tanh ----
+// HBM-streaming kernel: each block produces 1024 output samples of one utterance from a
+// [C][1024+6] LDS tile.  Padded signal p[i] (i in [0,T]) = lrelu(x[i-1]) for i>=1, p[0] = lrelu(x[1]).
+constexpr int POST_TILE = 1024;
+constexpr int POST_MAXC = 64;
+
+__global__ void __launch_bounds__(256) convpost_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ y, int C, int T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int W = POST_TILE + 6;
+  float* wl = lds + (size_t)C * W;  // weights [C][7]
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * POST_TILE;  // first output index of the tile
+  const int To = T + 1;
+  const float* xb = x + (size_t)b * C * T;
+  for (int i = threadIdx.x; i < C * 7; i += 256) wl[i] = w[i];
+  for (int c = 0; c < C; ++c) {
+    const float* xr = xb + (size_t)c * T;
+    for (int col = threadIdx.x; col < W; col += 256) {
+      const int i = t0 - 3 + col;  // index into the reflection-padded signal
+      float v = 0.f;
+      if (i >= 0 && i < To) {
+        const int xi = i == 0 ? 1 : i - 1;
+        v = xr[xi];
+        v = v > 0.f ? v : v * 0.01f;
+      }
+      lds[c * W + col] = v;
+    }
+  }
+  __syncthreads();
+  const float bv = bias[0];
+#pragma unroll
+  for (int k = 0; k < POST_TILE / 256; ++k) {
+    const int lt = threadIdx.x + k * 256;
+    const int t = t0 + lt;
+    if (t >= To) continue;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float* row = lds + c * W + lt;
+      const float* wr = wl + c * 7;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc = fmaf(wr[j], row[j], acc);
+    }
+    y[(size_t)b * To + t] = tanhf(acc + bv);
+  }
+}
+
+}  // namespace sat
+
+using namespace sat;
+
+struct sat_hifigan {
+  int in_ch = 0, c0 = 0;
+  std::vector<int> up_rates, up_kernels, rb_kernels, rb_dil;
+  struct Conv {
+    const float* w = nullptr;
+    const float* bias = nullptr;
+  };
+  std::vector<Conv> convs;
+  int n_ups() const { return (int)up_rates.size(); }
+  int n_rbk() const { return (int)rb_kernels.size(); }
+  int id_up(int i) const { return 1 + i; }
+  int id_rb(int stage, int j, int pair, int which) const {
+    return 1 + n_ups() + ((stage * n_rbk() + j) * 3 + pair) * 2 + which;
+  }
+  int id_post() const { return 1 + n_ups() + n_ups() * n_rbk() * 6; }
+};
+
+extern "C" int sat_convtranspose_phase_dims(int k, int u, int pad, int* ksize, int* pad_left) {
+  SAT_REQUIRE(k > 0 && u > 0 && pad >= 0, "convtranspose_phase_dims: bad arguments");
+  int lo, hi;
+  phase_window(k, u, pad, &lo, &hi);
+  if (ksize) *ksize = hi - lo + 1;
+  if (pad_left) *pad_left = -lo;
+  return SAT_OK;
+}
+
+extern "C" int sat_hifigan_create(sat_hifigan** out, int in_channels, int initial_channels, int n_ups,
+                                  const int* up_rates, const int* up_kernels, int n_rb_kernels,
+                                  const int* rb_kernels, const int* rb_dilations) {
+  SAT_REQUIRE(out && up_rates && up_kernels && rb_kernels && rb_dilations, "hifigan_create: null pointer");
+  SAT_REQUIRE(in_channels > 0 && initial_channels > 0 && n_ups > 0 && n_rb_kernels > 0, "hifigan_create: bad sizes");
+  SAT_REQUIRE((initial_channels >> n_ups) >= 1 && (initial_channels >> n_ups) <= POST_MAXC,
+              "hifigan_create: unsupported channel progression");
+  auto* h = new sat_hifigan();
+  h->in_ch = in_channels;
+  h->c0 = initial_channels;
+  h->up_rates.assign(up_rates, up_rates + n_ups);
+  h->up_kernels.assign(up_kernels, up_kernels + n_ups);
+  h->rb_kernels.assign(rb_kernels, rb_kernels + n_rb_kernels);
+  h->rb_dil.assign(rb_dilations, rb_dilations + 3 * n_rb_kernels);
+  for (int i = 0; i < n_ups; ++i) {
+    if ((up_kernels[i] - up_rates[i]) % 2 != 0 || up_kernels[i] < up_rates[i]) {
+      delete h;
+      set_error("hifigan_create: upsample kernel %d / rate %d not supported", up_kernels[i], up_rates[i]);
+      return SAT_ERR_INVALID;
+    }
+  }
+  h->convs.resize(h->id_post() + 1);
+  *out = h;
+  return SAT_OK;
+}
+
+extern "C" int sat_hifigan_num_convs(const sat_hifigan* h) { return h ? (int)h->convs.size() : SAT_ERR_INVALID; }
+
+extern "C" int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const float* w_packed, const float* bias) {
+  SAT_REQUIRE(h && conv_id >= 0 && conv_id < (int)h->convs.size() && w_packed && bias, "hifigan_set_conv: bad arguments");
+  h->convs[conv_id].w = w_packed;
+  h->convs[conv_id].bias = bias;
+  return SAT_OK;
+}
+
+static size_t hifigan_max_elems(const sat_hifigan* h, int B, int T) {
+  size_t mx = (size_t)h->c0 * T;
+  int C = h->c0;
+  size_t Tc = T;
+  for (int i = 0; i < h->n_ups(); ++i) {
+    C /= 2;
+    Tc *= h->up_rates[i];
+    if ((size_t)C * Tc > mx) mx = (size_t)C * Tc;
+  }
+  return mx * B;
+}
+
+extern "C" size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T) {
+  if (!h || B <= 0 || T <= 0) return 0;
+  return 6 * align_up(hifigan_max_elems(h, B, T) * sizeof(float), 256);
+}
+
+extern "C" void sat_hifigan_destroy(sat_hifigan* h) { delete h; }
+
+extern "C" int sat_hifigan_convpost_f32(const float* x, const float* w, const float* bias, float* y, int B,
+                                        int C, int T, void* stream) {
+  SAT_REQUIRE(x && w && bias && y, "convpost: null pointer");
+  SAT_REQUIRE(B > 0 && C > 0 && C <= POST_MAXC && T >= 2, "convpost: unsupported shape B=%d C=%d T=%d", B, C, T);
+  const size_t lds = ((size_t)C * (POST_TILE + 6) + (size_t)C * 7) * sizeof(float);
+  if (lds > 64 * 1024) {
+    SAT_HIP(hipFuncSetAttribute((const void*)convpost_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  dim3 grid(ceil_div(T + 1, POST_TILE), B);
+  hipLaunchKernelGGL(convpost_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, T);
+  SAT_LAUNCH_CHECK("convpost_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, float* y, void* workspace,
+                                       size_t workspace_bytes, int B, int T, void* stream) {
+  SAT_REQUIRE(h && x && y && workspace, "hifigan_forward: null pointer");
+  SAT_REQUIRE(B > 0 && T > 0, "hifigan_forward: empty batch");
+  for (size_t i = 0; i < h->convs.size(); ++i)
+    SAT_REQUIRE(h->convs[i].w && h->convs[i].bias, "hifigan_forward: conv %zu has no weights", i);
+  SAT_REQUIRE(workspace_bytes >= sat_hifigan_workspace_bytes(h, B, T), "hifigan_forward: workspace too small");
+  const size_t slot = align_up(hifigan_max_elems(h, B, T) * sizeof(float), 256);
+  float* buf[6];
+  for (int i = 0; i < 6; ++i) buf[i] = (float*)((char*)workspace + i * slot);
+  float* X = buf[0];    // stage input
+  float* H = buf[1];    // upsampled
+  float* T1 = buf[2];   // inner activation of a resblock pair
+  float* RA = buf[3];
+  float* RB = buf[4];
+  float* ACC = buf[5];  // MRF sum -> next stage input
+
+  auto base_desc = [&](int Cin, int Cout, int Tin, int Tq, int up) {
+    sat_conv1d_desc d{};
+    d.B = B;
+    d.C_in = Cin;
+    d.T_in = Tin;
+    d.C_out = Cout;
+    d.T_q = Tq;
+    d.ksize = 1;
+    d.dilation = 1;
+    d.stride = 1;
+    d.groups = 1;
+    d.up = up;
+    d.x_cstride = Tin;
+    d.x_bstride = (int64_t)Cin * Tin;
+    d.y_cstride = (int64_t)Tq * up;
+    d.y_bstride = (int64_t)Cout * Tq * up;
+    d.res_tstride = 1;
+    return d;
+  };
+
+  // conv_pre (archi.py:78)
+  {
+    sat_conv1d_desc d = base_desc(h->in_ch, h->c0, T, T, 1);
+    d.ksize = 7;
+    d.pad_left = 3;
+    d.bias = h->convs[0].bias;
+    int s = sat_conv1d_f32(&d, x, h->convs[0].w, X, stream);
+    if (s != SAT_OK) return s;
+  }
+  int C = h->c0;
+  int Tc = T;
+  const int nk = h->n_rbk();
+  for (int i = 0; i < h->n_ups(); ++i) {
+    const int u = h->up_rates[i], k = h->up_kernels[i];
+    const int Cn = C / 2, Tn = Tc * u;
+    // x = leaky_relu(x, 0.1); x = ups[i](x)   (archi.py:80-81)
+    {
+      int lo, hi;
+      phase_window(k, u, (k - u) / 2, &lo, &hi);
+      sat_conv1d_desc d = base_desc(C, Cn, Tc, Tc, u);
+      d.ksize = hi - lo + 1;
+      d.pad_left = -lo;
+      d.in_lrelu = 1;
+      d.in_slope = 0.1f;
+      d.bias = h->convs[h->id_up(i)].bias;
+      int s = sat_conv1d_f32(&d, X, h->convs[h->id_up(i)].w, H, stream);
+      if (s != SAT_OK) return s;
+    }
+    // xs = sum_j resblock_j(x); x = xs / num_kernels   (archi.py:82-86)
+    for (int j = 0; j < nk; ++j) {
+      const int rk = h->rb_kernels[j];
+      const float* r = H;
+      for (int pair = 0; pair < 3; ++pair) {
+        const int dil = h->rb_dil[j * 3 + pair];
+        // xt = c1(leaky_relu(x, 0.1))
+        sat_conv1d_desc d1 = base_desc(Cn, Cn, Tn, Tn, 1);
+        d1.ksize = rk;
+        d1.dilation = dil;
+        d1.pad_left = (rk * dil - dil) / 2;
+        d1.in_lrelu = 1;
+        d1.in_slope = 0.1f;
+        d1.bias = h->convs[h->id_rb(i, j, pair, 0)].bias;
+        int s = sat_conv1d_f32(&d1, r, h->convs[h->id_rb(i, j, pair, 0)].w, T1, stream);
+        if (s != SAT_OK) return s;
+        // x = c2(leaky_relu(xt, 0.1)) + x
+        sat_conv1d_desc d2 = base_desc(Cn, Cn, Tn, Tn, 1);
+        d2.ksize = rk;
+        d2.dilation = 1;
+        d2.pad_left = (rk - 1) / 2;
+        d2.in_lrelu = 1;
+        d2.in_slope = 0.1f;
+        d2.bias = h->convs[h->id_rb(i, j, pair, 1)].bias;
+        d2.res = r;
+        d2.res_scale = 1.f;
+        d2.res_cstride = Tn;
+        d2.res_bstride = (int64_t)Cn * Tn;
+        float* dst;
+        if (pair < 2) {
+          dst = (r == RA) ? RB : RA;
+        } else {
+          dst = ACC;  // xs += resblock(x); the last one also divides by num_kernels
+          d2.accum = j > 0;
+          d2.accum_div = (j == nk - 1) ? (float)nk : 0.f;
+        }
+        s = sat_conv1d_f32(&d2, T1, h->convs[h->id_rb(i, j, pair, 1)].w, dst, stream);
+        if (s != SAT_OK) return s;
+        r = dst;
+      }
+    }
+    float* t = X;
+    X = ACC;
+    ACC = t;
+    C = Cn;
+    Tc = Tn;
+  }
+  // x = leaky_relu(x); reflection_pad; conv_post; tanh   (archi.py:87-90)
+  return sat_hifigan_convpost_f32(X, h->convs[h->id_post()].w, h->convs[h->id_post()].bias, y, B, C, Tc, stream);
+}

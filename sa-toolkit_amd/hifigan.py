@@ -1,0 +1,103 @@
+"""HiFi-GAN generator behind the reference's `CoreHifiGan` interface
+(reference: satools/satools/hifigan/archi.py:21-115).  Parameters live in the reference's
+state-dict layout (params.CoreHifiGanParams); the forward runs entirely in the HIP library
+(sat_hifigan_forward_f32).  Weight-norm is folded once (exact), weights are
+re-laid out for the MFMA conv kernel, and both are cached until parameters change."""
+import ctypes as C
+
+import torch
+
+from . import _lib, packing
+from ._lib import check, lib, ptr, stream
+from .params import CoreHifiGanParams
+
+
+class CoreHifiGan(CoreHifiGanParams):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._handle = None
+        self._packed = None
+        self._packed_key = None
+        self._ws = None
+
+    # -- device-side weight cache ---------------------------------------------------------
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+
+    def invalidate(self):
+        self._packed_key = None
+
+    def _conv_modules(self):
+        mods = [self.conv_pre] + list(self.ups)
+        for rb in self.resblocks:
+            for i in range(3):
+                mods += [rb.convs1[i], rb.convs2[i]]
+        return mods + [self.conv_post]
+
+    def _prepare(self, device):
+        key = self._param_key()
+        if self._packed_key == key and self._handle is not None:
+            return
+        l = lib()
+        if self._handle is None:
+            h = C.c_void_p()
+            dil = [d for ds in self.resblock_dilation_sizes for d in ds]
+            check(l.sat_hifigan_create(C.byref(h), self.imput_dim, self.upsample_initial_channel,
+                                       len(self.upsample_rates), _lib.int_array(self.upsample_rates),
+                                       _lib.int_array(self.upsample_kernel_sizes), len(self.resblock_kernel_sizes),
+                                       _lib.int_array(self.resblock_kernel_sizes), _lib.int_array(dil)),
+                  "sat_hifigan_create")
+            self._handle = h
+        packed = []
+        mods = self._conv_modules()
+        n_ups = len(self.ups)
+        for i, m in enumerate(mods):
+            w = m.folded_weight().to(device=device, dtype=torch.float32)
+            b = m.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+            if i == len(mods) - 1:
+                wp = w.reshape(w.shape[1], w.shape[2]).contiguous()  # conv_post: [C][7]
+            elif 1 <= i <= n_ups:
+                u, k = self.upsample_rates[i - 1], self.upsample_kernel_sizes[i - 1]
+                wc, _, _ = packing.convtranspose_as_phase_conv(w, u, (k - u) // 2)
+                wp = packing.pack_conv_weight(wc, up=u)
+            else:
+                wp = packing.pack_conv_weight(w)
+            packed.append((wp, b))
+            check(l.sat_hifigan_set_conv(self._handle, i, ptr(wp), ptr(b)), "sat_hifigan_set_conv")
+        self._packed = packed  # keeps the device buffers alive
+        self._packed_key = key
+
+    def _workspace(self, B, T, device):
+        need = lib().sat_hifigan_workspace_bytes(self._handle, B, T)
+        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != device:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        return self._ws, need
+
+    # -- reference interface ----------------------------------------------------------------
+    def forward_resnet(self, x):
+        if not x.is_cuda:
+            raise _lib.SatError("CoreHifiGan runs on the HIP device only (no CPU fallback)")
+        x = x.to(torch.float32).contiguous()
+        B, c, T = x.shape
+        if c != self.imput_dim:
+            raise _lib.SatError(f"generator expects {self.imput_dim} input channels, got {c}")
+        self._prepare(x.device)
+        ws, need = self._workspace(B, T, x.device)
+        up = 1
+        for u in self.upsample_rates:
+            up *= u
+        y = torch.empty(B, 1, T * up + 1, dtype=torch.float32, device=x.device)
+        check(lib().sat_hifigan_forward_f32(self._handle, ptr(x), ptr(y), ptr(ws), need, B, T, stream()),
+              "sat_hifigan_forward_f32")
+        return y
+
+    def forward(self, x):
+        # reference returns (signal, torch.empty((1))) when iSTFTNetout is False (archi.py:93-107)
+        return self.forward_resnet(x), torch.empty((1))
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                lib().sat_hifigan_destroy(self._handle)
+        except Exception:
+            pass

@@ -1,0 +1,53 @@
+"""Host-side weight re-layout for the fused conv1d kernel (done once at load time).
+
+packed[g][cin_pad][ksize][co_pad], co fastest: a half-wave's A-fragment read is one 128-B row.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def packed_dims(c_in, c_out, up=1, groups=1):
+    cin_pad, co_pad = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().sat_conv1d_packed_dims(c_in, c_out, up, groups, C.byref(cin_pad), C.byref(co_pad)),
+               "sat_conv1d_packed_dims")
+    return cin_pad.value, co_pad.value
+
+
+def phase_dims(k, u, pad):
+    ks, pl = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().sat_convtranspose_phase_dims(k, u, pad, C.byref(ks), C.byref(pl)),
+               "sat_convtranspose_phase_dims")
+    return ks.value, pl.value
+
+
+def pack_conv_weight(w: torch.Tensor, groups: int = 1, up: int = 1) -> torch.Tensor:
+    """w [rows = C_out*up, C_in/groups, K] (torch Conv1d layout) -> packed, same device as w."""
+    rows, cin_g, k = w.shape
+    assert rows % (groups * up) == 0
+    c_out = rows // up
+    cin_pad, co_pad = packed_dims(cin_g * groups, c_out, up, groups)
+    rows_g = rows // groups
+    out = torch.zeros(groups, cin_pad, k, co_pad, dtype=torch.float32, device=w.device)
+    wg = w.to(torch.float32).reshape(groups, rows_g, cin_g, k)
+    out[:, :cin_g, :, :rows_g] = wg.permute(0, 2, 3, 1)
+    return out.contiguous()
+
+
+def convtranspose_as_phase_conv(w: torch.Tensor, stride: int, padding: int):
+    """ConvTranspose1d weight [C_in, C_out, K] -> equivalent conv weight [C_out*u, C_in, K'] whose
+    row co*u + r produces output phase r (t = q*u + r), plus (K', pad_left).
+    Output t reads input s = q + delta through tap j = r + padding - u*delta."""
+    c_in, c_out, k = w.shape
+    u = stride
+    kp, pad_left = phase_dims(k, u, padding)
+    wc = torch.zeros(c_out * u, c_in, kp, dtype=w.dtype, device=w.device)
+    for r in range(u):
+        for jp in range(kp):
+            delta = jp - pad_left
+            j = r + padding - u * delta
+            if 0 <= j < k:
+                wc[r::u, :, jp] = w[:, :, j].t()
+    return wc, kp, pad_left

@@ -1,0 +1,75 @@
+"""lowpass_biquad / highpass_biquad following torchaudio 2.1's published algorithm:
+coefficients from the RBJ cookbook in the waveform dtype (f32), `lfilter` = FIR part by
+conv1d with the raw b coefficients, division of that and of the a coefficients by a0, then the
+sequential recursion  y[t] = fir[t] - a2'*y[t-2] - a1'*y[t-1]  in f32 (separate multiply and
+subtract, that order), and a final clamp to [-1, 1].  The recursion runs in numpy float32
+scalars behind torch.jit.ignore so that the scripted reference can call it."""
+import math
+
+import numpy as np
+import torch
+from torch import Tensor
+
+
+def _coeffs(kind: str, sample_rate: int, cutoff_freq: float, Q: float):
+    f32 = torch.float32
+    cutoff = torch.as_tensor(cutoff_freq, dtype=f32)
+    q = torch.as_tensor(Q, dtype=f32)
+    w0 = 2 * math.pi * cutoff / sample_rate
+    alpha = torch.sin(w0) / 2 / q
+    if kind == "lp":
+        b0 = (1 - torch.cos(w0)) / 2
+        b1 = 1 - torch.cos(w0)
+    else:
+        b0 = (1 + torch.cos(w0)) / 2
+        b1 = -1 - torch.cos(w0)
+    b2 = b0
+    a0 = 1 + alpha
+    a1 = -2 * torch.cos(w0)
+    a2 = 1 - alpha
+    return (torch.stack([b0, b1, b2]).to(f32), torch.stack([a0, a1, a2]).to(f32))
+
+
+def _lfilter(x: Tensor, b: Tensor, a: Tensor) -> Tensor:
+    shape = x.shape
+    x = x.reshape(-1, shape[-1]).to(torch.float32)
+    padded = torch.nn.functional.pad(x, [2, 0])
+    fir = torch.nn.functional.conv1d(padded.unsqueeze(1), b.flip(0).view(1, 1, 3)).squeeze(1)
+    fir = fir / a[0]
+    af = (a.flip(0) / a[0]).numpy().astype(np.float32)  # [a2', a1', 1]
+    out = np.zeros((x.shape[0], x.shape[1] + 2), dtype=np.float32)
+    firn = fir.numpy()
+    c2, c1 = af[0], af[1]
+    for r in range(x.shape[0]):
+        o = out[r]
+        f = firn[r]
+        y1 = np.float32(0.0)
+        y2 = np.float32(0.0)
+        for t in range(f.shape[0]):
+            v = f[t] - c2 * y2
+            v = v - c1 * y1
+            o[t + 2] = v
+            y2 = y1
+            y1 = v
+    y = torch.from_numpy(out[:, 2:].copy())
+    return torch.clamp(y, -1.0, 1.0).reshape(shape)
+
+
+@torch.jit.ignore
+def _lp(waveform: Tensor, sample_rate: int, cutoff_freq: float, Q: float) -> Tensor:
+    b, a = _coeffs("lp", sample_rate, cutoff_freq, Q)
+    return _lfilter(waveform, b, a)
+
+
+@torch.jit.ignore
+def _hp(waveform: Tensor, sample_rate: int, cutoff_freq: float, Q: float) -> Tensor:
+    b, a = _coeffs("hp", sample_rate, cutoff_freq, Q)
+    return _lfilter(waveform, b, a)
+
+
+def lowpass_biquad(waveform: Tensor, sample_rate: int, cutoff_freq: float, Q: float = 0.707) -> Tensor:
+    return _lp(waveform, sample_rate, cutoff_freq, Q)
+
+
+def highpass_biquad(waveform: Tensor, sample_rate: int, cutoff_freq: float, Q: float = 0.707) -> Tensor:
+    return _hp(waveform, sample_rate, cutoff_freq, Q)
