@@ -1,0 +1,254 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors.  Needs a real MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rms
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from satools_amd import ops, packing
+    return ops, packing
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ---------------------------------------------------------------------------------------------
+# fused conv1d kernel vs torch (f32 CPU) on the shapes the path uses
+# tolerance: f32 re-association only: |err| <= 2e-5 * (|x| . |w|) scale
+# ---------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # (C_in, C_out, K, dilation, stride, pad_left, pad_right, T, B)   generator shapes
+    (16, 16, 3, 1, 1, 1, 1, 700, 2), (16, 16, 7, 3, 1, 9, 9, 1000, 2), (16, 16, 11, 5, 1, 25, 25, 1100, 1),
+    (32, 32, 3, 5, 1, 5, 5, 600, 2), (32, 32, 11, 1, 1, 5, 5, 513, 2),
+    (64, 64, 7, 1, 1, 3, 3, 300, 2), (64, 64, 11, 3, 1, 15, 15, 257, 1),
+    (128, 128, 3, 3, 1, 3, 3, 260, 2), (128, 128, 11, 5, 1, 25, 25, 129, 2),
+    (256, 256, 7, 5, 1, 15, 15, 125, 2), (256, 256, 11, 1, 1, 5, 5, 250, 1),
+    (504, 512, 7, 1, 1, 3, 3, 50, 2),
+    # TDNNF shapes: valid conv over frames, stride 2 layer, 1x1
+    (80, 128, 3, 1, 1, 0, 0, 88, 2), (1024, 128, 3, 1, 1, 0, 0, 70, 2), (1024, 128, 1, 1, 2, 0, 0, 75, 2),
+    (128, 1024, 1, 1, 1, 0, 0, 66, 2), (1024, 256, 3, 1, 1, 0, 0, 40, 1),
+    # odd tap counts through the runtime-tap kernel, strided
+    (512, 512, 2, 1, 2, 0, 0, 99, 2), (64, 96, 10, 1, 5, 0, 0, 400, 1), (48, 40, 5, 2, 1, 4, 4, 150, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv1d_matches_torch(case):
+    ops, packing = _ops()
+    cin, cout, k, d, s, pl, pr, T, B = case
+    x = _rand(B, cin, T, seed=1)
+    w = _rand(cout, cin, k, seed=2, scale=1.0 / np.sqrt(cin * k))
+    b = _rand(cout, seed=3)
+    ref = F.conv1d(F.pad(x, (pl, pr)), w, b, stride=s, dilation=d)
+    wp = packing.pack_conv_weight(w.to(DEV))
+    y = ops.conv1d(x.to(DEV), wp, cout, k, bias=b.to(DEV), dilation=d, stride=s, pad_left=pl, pad_right=pr)
+    assert y.shape == ref.shape
+    assert (y.cpu() - ref).abs().max() < 3e-5
+
+
+def test_conv1d_fused_prologue_epilogue():
+    ops, packing = _ops()
+    B, C, T, k, d = 2, 64, 333, 7, 3
+    x, w, b = _rand(B, C, T, seed=1), _rand(C, C, k, seed=2, scale=0.05), _rand(C, seed=3)
+    res = _rand(B, C, T, seed=4)
+    acc0 = _rand(B, C, T, seed=5)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, dilation=d, padding=(k * d - d) // 2) + res
+    wp = packing.pack_conv_weight(w.to(DEV))
+    y = ops.conv1d(x.to(DEV), wp, C, k, bias=b.to(DEV), dilation=d, pad_left=(k * d - d) // 2, in_lrelu=0.1, res=res.to(DEV))
+    assert (y.cpu() - ref).abs().max() < 3e-5
+    # MRF accumulation: dst = (dst + v) / 3
+    out = acc0.to(DEV).clone()
+    ops.conv1d(x.to(DEV), wp, C, k, bias=b.to(DEV), dilation=d, pad_left=(k * d - d) // 2, in_lrelu=0.1, res=res.to(DEV),
+               out=out, accum=True, accum_div=3.0)
+    assert (out.cpu() - (acc0 + ref) / 3).abs().max() < 3e-5
+    # TDNNF epilogue: bypass with frame offset + stride, folded BatchNorm, ReLU
+    xin = _rand(B, 128, 90, seed=6)
+    w1 = _rand(128, 32, 1, seed=7, scale=0.2)
+    z = _rand(B, 32, 44, seed=8)
+    sc, sh = _rand(128, seed=9).abs() + 0.5, _rand(128, seed=10)
+    ref = F.relu((F.conv1d(z, w1, None) + 0.66 * xin[:, :, 1:89:2]) * sc[None, :, None] + sh[None, :, None])
+    y = ops.conv1d(z.to(DEV), packing.pack_conv_weight(w1.to(DEV)), 128, 1, res=xin.to(DEV), res_scale=0.66, res_toff=1,
+                   res_tstride=2, ch_scale=sc.to(DEV), ch_shift=sh.to(DEV), relu=True)
+    assert (y.cpu() - ref).abs().max() < 3e-5
+
+
+def test_conv1d_groups():
+    ops, packing = _ops()
+    B, C, T, k, g = 2, 128, 120, 16, 4
+    x, w, b = _rand(B, C, T, seed=1), _rand(C, C // g, k, seed=2, scale=0.05), _rand(C, seed=3)
+    ref = F.conv1d(x, w, b, padding=k // 2, groups=g)
+    y = ops.conv1d(x.to(DEV), packing.pack_conv_weight(w.to(DEV), groups=g), C, k, bias=b.to(DEV), pad_left=k // 2,
+                   pad_right=k // 2, groups=g)
+    assert y.shape == ref.shape
+    assert (y.cpu() - ref).abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("cfg", [(64, 32, 11, 5, 77), (128, 64, 8, 4, 50), (32, 16, 4, 2, 301), (512, 256, 11, 5, 25)])
+def test_convtranspose_as_polyphase_conv(cfg):
+    ops, packing = _ops()
+    cin, cout, k, u, T = cfg
+    x = _rand(2, cin, T, seed=1)
+    w = _rand(cin, cout, k, seed=2, scale=1.0 / np.sqrt(cin * k / u))
+    b = _rand(cout, seed=3)
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=u, padding=(k - u) // 2)
+    wc, kp, pl = packing.convtranspose_as_phase_conv(w.to(DEV), u, (k - u) // 2)
+    y = ops.conv1d(x.to(DEV), packing.pack_conv_weight(wc, up=u), cout, kp, bias=b.to(DEV), pad_left=pl, up=u, in_lrelu=0.1)
+    assert y.shape == ref.shape == (2, cout, T * u)
+    assert (y.cpu() - ref).abs().max() < 3e-5
+
+
+def test_convpost_matches_oracle():
+    ops, _ = _ops()
+    x, w, b = _rand(2, 16, 2500, seed=1), _rand(1, 16, 7, seed=2, scale=0.1), _rand(1, seed=3, scale=0.1)
+    ref = torch.tanh(F.conv1d(F.pad(F.leaky_relu(x), (1, 0), mode="reflect"), w, b, padding=3))
+    y = ops.convpost(x.to(DEV), w.reshape(16, 7).contiguous().to(DEV), b.to(DEV))
+    assert y.shape == ref.shape == (2, 1, 2501)
+    assert (y.cpu() - ref).abs().max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# front end and bottleneck
+# ---------------------------------------------------------------------------------------------
+def _model(tag="hifigan_bn_tdnnf_600h_vq_48_v1", **opt):
+    from satools_amd import load_model
+    m = load_model("synthetic:" + tag, option_args=opt or None)
+    m.to(DEV)
+    m.eval()
+    return m
+
+
+@pytest.fixture(scope="module")
+def model():
+    return _model()
+
+
+def test_fbank_cmvn_pad_matches_oracle(model):
+    from oracle import fbank as ofb
+    from oracle import tdnnf as otd
+    from satools_amd import synthetic
+    for wav in (synthetic.harm_batch([0], 8000), synthetic.harm_batch([0, 1, 2], 16384), synthetic.rand_batch(0, 2, 80000)):
+        ref = ofb.fbank(wav * 32768, 80)
+        ref = otd.pad_input(ref - ref.mean(dim=1).unsqueeze(1), 19).permute(0, 2, 1)
+        got = model.bn_extractor.features((wav * 32768).to(DEV))
+        assert got.shape == ref.shape
+        assert (got.cpu() - ref).abs().max() < 3e-4
+
+
+def test_vq_matches_oracle():
+    ops, _ = _ops()
+    from oracle import tdnnf as otd
+    z = _rand(2, 300, 256, seed=1)
+    cb = z.reshape(-1, 256)[torch.randperm(600, generator=torch.Generator().manual_seed(0))[:48]] + _rand(48, 256, seed=2, scale=0.3)
+    qr, ir, dr = otd.vq(z, cb)
+    q, idx, dist = ops.vq(z.permute(0, 2, 1).contiguous().to(DEV), cb.to(DEV), want_dist=True)
+    dr = dr.view(2, 300, 48)
+    assert (dist.cpu() - dr).abs().max() < 1e-3          # expanded-form f32 distances, |z|^2 ~ 256
+    srt = dr.sort(2)[0]
+    margin = srt[..., 1] - srt[..., 0]
+    agree = idx.cpu().long() == ir.view(2, 300)
+    assert agree[margin > 2e-3].all()
+    assert agree.float().mean() > 0.99
+    assert (q.cpu().permute(0, 2, 1) - qr)[agree].abs().max() < 1e-6
+
+
+def test_extract_bn_matches_oracle_and_golden(model, gold, fbank_tag_state):
+    from oracle import convert as oconv
+    from oracle import tdnnf as otd
+    from satools_amd import synthetic
+    state, _ = fbank_tag_state
+    asr, _ = oconv.split_state_dict(state["base_model_state_dict"])
+    fx = gold.npz("fx_tdnnf.npz")
+    wav = synthetic.harm_batch([0, 1], 80000)
+    aux = {}
+    ref = otd.extract_bn_fbank(asr, wav, aux=aux)
+    bn, (z, idx, dist) = model.bn_extractor.extract_bn(wav.clone().to(DEV), want_aux=True)
+    assert bn.shape == ref.shape == (2, 250, 256)
+    assert (z.cpu().permute(0, 2, 1) - aux["z"]).abs().max() < 2e-4   # 11 layers of f32 re-association
+    margin = torch.from_numpy(fx["harm01_80000/margin"])
+    agree = idx.cpu().long() == torch.from_numpy(fx["harm01_80000/idx"]).long()
+    assert agree[margin > 5e-3].all()
+    print("VQ index agreement with the reference:", agree.float().mean().item())
+    assert agree.float().mean() > 0.99
+    assert (bn.cpu() - ref)[agree].abs().max() < 2e-4
+    # get_bn: [B, 256, T], input untouched (clone semantics of parse_wavinfo_wav)
+    w2 = wav.clone().to(DEV)
+    out = model.get_bn(w2)
+    assert out.shape == (2, 256, 250) and torch.equal(w2.cpu(), wav)
+
+
+def test_f0_norm_transform_matches_golden(gold):
+    ops, _ = _ops()
+    from satools_amd import f0_transforms
+    fx = gold.npz("fx_f0norm.npz")
+    for a, b in (("in_1xT", "out_1xT"), ("in_2xT", "out_2xT"), ("in_zero_row", "out_zero_row")):
+        x = torch.from_numpy(fx[a].copy()).to(DEV)
+        ops.f0_norm_transform_(x)
+        assert np.allclose(x.cpu().numpy(), fx[b], atol=2e-6)
+    x = torch.from_numpy(fx["in_2xT"].copy()).to(DEV)
+    ops.f0_norm_transform_(x, quant_bins=16)
+    assert np.abs(x.cpu().numpy() - fx["quant16"][:, 0]).max() < 1e-6
+    torch.manual_seed(1234)
+    noise = f0_transforms.draw_awgn((2, 1, x.shape[1]), 2)
+    x = torch.from_numpy(fx["in_2xT"].copy()).to(DEV)
+    ops.f0_norm_transform_(x, quant_bins=16, noise=noise.to(DEV))
+    assert np.abs(x.cpu().numpy() - fx["quant16_awgn2_seed1234"][:, 0]).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# generator and end to end
+# ---------------------------------------------------------------------------------------------
+def test_generator_matches_golden_teacher_forced(model, gold):
+    """generator alone on the reference's own BN/F0/speaker input (n = 8000): 1e-4 RMS bar of the
+    north star, measured here against the reference's waveform"""
+    fx = gold.npz("fx_gen.npz")
+    spk = F.one_hot(torch.from_numpy(fx["spk_argmax"]), len(model.spk))
+    f0 = torch.from_numpy(fx["f0_raw"].copy())
+    y = model._forward(f0, torch.from_numpy(fx["bn"]), spk)
+    assert np.allclose(f0.numpy(), fx["f0_after"], atol=2e-6)      # normalised in place like the reference
+    assert y.shape == fx["y"].shape
+    err = rms(y.cpu().numpy() - fx["y"])
+    print("generator RMS error vs reference:", err, "signal RMS", rms(fx["y"]))
+    assert err < 1e-5
+
+
+def test_convert_matches_golden(model, gold):
+    """model.convert on 5 s utterances with the reference's F0 track handed over through set_f0
+    (the anonymize pipeline's path, bin/pipeline.py:107-149); YAAPT parity is tested separately"""
+    from satools_amd import synthetic
+    fx, f0fx = gold.npz("fx_e2e.npz"), gold.npz("fx_f0.npz")
+    wav = synthetic.harm_batch([0], 80000)
+    keep = wav.clone()
+    model.set_f0(torch.from_numpy(f0fx["harm0_80000"].copy()))
+    y = model.convert(wav.to(DEV), target=model.spk[3])
+    assert y.shape == (1, 80001) and y.dtype == torch.float32       # B == 1 -> [1, n'] (squeeze(0))
+    assert torch.equal(wav, keep)
+    e1 = rms(y.cpu().numpy() - fx["harm0_80000_str"])
+    wav = synthetic.harm_batch([0, 1], 80000)
+    model.set_f0(torch.from_numpy(f0fx["harm01_80000_batch"].copy()).to(DEV))
+    y = model.convert(wav.to(DEV), target=[model.spk[3], model.spk[10]])
+    assert y.shape == (2, 1, 80001)                                  # B > 1 -> [B, 1, n']
+    e2 = rms(y.cpu().numpy() - fx["harm01_80000_list"])
+    print("convert RMS error vs reference: B=1", e1, "B=2", e2, "signal RMS", rms(fx["harm0_80000_str"]))
+    assert e1 < 1e-4 and e2 < 1e-4
+    assert model.f0 is None                                          # set_f0 is consumed once
+
+
+def test_convert_errors_like_the_reference(model):
+    from satools_amd import synthetic
+    wav = synthetic.harm_batch([0], 8000).to(DEV)
+    model.set_f0(torch.zeros(1, 25))
+    with pytest.raises(ValueError):
+        model.convert(wav, target="no-such-speaker")
+    model.set_f0(torch.zeros(1, 25))
+    with pytest.raises(AssertionError):
+        model.convert(wav, target=[model.spk[0], model.spk[1]])     # len(target) != len(input_wav)
+    assert model.eval() is None                                      # reference quirk: train() returns None
