@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Benchmark of the anonymize / model.convert() hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" = one `model.convert` over one batch of 32 synthetic 5 s @ 16 kHz utterances per rank
+(BASELINE.json configs[1], tag hifigan_bn_tdnnf_600h_vq_48_v1), inputs resident in HBM, followed
+for N > 1 by the RCCL all-gather of the anonymized waveforms (weak scaling: per-GPU work fixed).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TAG = "hifigan_bn_tdnnf_600h_vq_48_v1"
+BATCH = 32
+N_SAMPLES = 80000
+UTT_SECONDS = 5.0
+# algorithmic work per 5 s utterance (SURVEY §8d / DESIGN.md): generator 40.43 GMAC
+GEN_FLOP_PER_UTT = 80.86e9
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def analytic_f0(seeds, frames=250):
+    """F0 track of the `harm` utterances at the YAAPT frame centres (0 where the envelope is off);
+    used while F0 is handed over through set_f0 (the anonymize pipeline's hand-off)"""
+    import math
+    import torch
+    t = (torch.arange(frames, dtype=torch.float64) * 320) / 16000.0
+    rows = []
+    for s in seeds:
+        f0 = (100 + 5 * (s % 16)) + 60 * torch.sin(2 * math.pi * 0.7 * t)
+        env = (torch.sin(2 * math.pi * 1.5 * t) > -0.3).to(torch.float64)
+        rows.append((f0 * env).to(torch.float32))
+    return torch.stack(rows)
+
+
+def cpu_baseline(state, spk, seeds, f0):
+    """the CPU oracle (a port of the reference's PyTorch path) timed on the host cores over a
+    bounded sample of the same workload"""
+    import torch
+    from oracle import convert as oconv
+    from satools_amd import synthetic
+    wav = synthetic.harm_batch(seeds)
+    tg = synthetic.targets(spk, seeds)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        oconv.convert_fbank(state["base_model_state_dict"], spk, wav, tg, f0.clone())
+        dt = time.perf_counter() - t0
+    return {"value": round(len(seeds) * UTT_SECONDS / dt, 3), "unit": "x real-time (audio s / wall s)", "cores": cores,
+            "kind": "port", "sample": f"{len(seeds)} utterances x 5 s, one convert() call, torch CPU f32, "
+                                      f"{cores} threads, F0 handed over like on the GPU leg ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        print(f"bench.py --gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus}",
+              file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import satools_amd
+    from satools_amd import synthetic
+
+    model = satools_amd.load_model("synthetic:" + TAG)
+    model.to(dev)
+    model.eval()
+    seeds = [rank * BATCH + i for i in range(BATCH)]
+    wav = synthetic.harm_batch(seeds).to(dev)
+    f0 = analytic_f0(seeds).to(dev)
+    targets = synthetic.targets(model.spk, seeds)
+    gathered = torch.empty(world * BATCH, 1, N_SAMPLES + 1, dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        model.set_f0(f0.clone())
+        y = model.convert(wav, target=targets)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, y.contiguous())
+        return y
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel family: the fused conv1d MFMA kernel inside the generator.  Timed live with
+    # events on the launch stream (= torch's current stream) around the generator forward.
+    gen_ms = None
+    if rank == 0:
+        with torch.no_grad():
+            f0n = f0.clone()
+            bn = model.get_bn(wav)
+            spk = model.get_spk_id(wav, targets)
+            from satools_amd import ops
+            ops.f0_norm_transform_(f0n)
+            x = ops.assemble_input(bn, f0n, spk.to(dev, torch.float32).contiguous(), spk.shape[1])
+            model.hifigan(x)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(3, min(a.steps, 10))
+            ev0.record()
+            for _ in range(reps):
+                model.hifigan(x)
+            ev1.record()
+            torch.cuda.synchronize()
+            gen_ms = ev0.elapsed_time(ev1) / reps
+
+    if rank == 0:
+        total_audio = world * a.steps * BATCH * UTT_SECONDS
+        achieved = GEN_FLOP_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
+        out = {
+            "metric": "anonymized audio seconds per wall-clock second (real-time factor), 5 s @ 16 kHz utterances",
+            "value": round(total_audio / dt, 2),
+            "unit": "x real-time (audio s / wall s)",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{TAG} model.convert, batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
+                       "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
+                       "f0": "handed over through set_f0 (analytic track), as bin/pipeline.py does",
+                       "parallelism": f"dp{world}" + (" + RCCL all_gather of waveforms per step" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv1d_mfma_kernel family, the 96 MFMA conv launches of one generator forward "
+                                   f"(+ output stage); {gen_ms:.3f} ms per batch of {BATCH}",
+                         "algorithmic_flop_per_launch_group": GEN_FLOP_PER_UTT * BATCH},
+        }
+        if not a.no_cpu_baseline:
+            state, _ = synthetic.checkpoint(TAG)
+            sample = list(range(4))
+            out["cpu_baseline"] = cpu_baseline(state, model.spk, sample, analytic_f0(sample))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
