@@ -2,7 +2,7 @@
 coefficients from the RBJ cookbook in the waveform dtype (f32), `lfilter` = FIR part by
 conv1d with the raw b coefficients, division of that and of the a coefficients by a0, then the
 sequential recursion  y[t] = fir[t] - a2'*y[t-2] - a1'*y[t-1]  in f32 (separate multiply and
-subtract, that order), and a final clamp to [-1, 1].  The recursion runs in numpy float32
+subtract, that order), and a final clamp to [-1, 1].  Same arithmetic as oracle/biquad.py.  The recursion runs in numpy float32
 scalars behind torch.jit.ignore so that the scripted reference can call it."""
 import math
 
@@ -32,26 +32,25 @@ def _coeffs(kind: str, sample_rate: int, cutoff_freq: float, Q: float):
 
 def _lfilter(x: Tensor, b: Tensor, a: Tensor) -> Tensor:
     shape = x.shape
-    x = x.reshape(-1, shape[-1]).to(torch.float32)
-    padded = torch.nn.functional.pad(x, [2, 0])
-    fir = torch.nn.functional.conv1d(padded.unsqueeze(1), b.flip(0).view(1, 1, 3)).squeeze(1)
-    fir = fir / a[0]
-    af = (a.flip(0) / a[0]).numpy().astype(np.float32)  # [a2', a1', 1]
-    out = np.zeros((x.shape[0], x.shape[1] + 2), dtype=np.float32)
-    firn = fir.numpy()
-    c2, c1 = af[0], af[1]
-    for r in range(x.shape[0]):
+    xn = x.reshape(-1, shape[-1]).to(torch.float32).numpy()
+    bn = b.numpy().astype(np.float32)
+    an = a.numpy().astype(np.float32)
+    c1, c2 = np.float32(an[1] / an[0]), np.float32(an[2] / an[0])
+    out = np.empty_like(xn)
+    for r in range(xn.shape[0]):
+        xp = np.concatenate([np.zeros(2, np.float32), xn[r]])
+        # FIR part (torchaudio: conv1d with the flipped b), summed as (b2*x[t-2] + b1*x[t-1]) + b0*x[t]
+        f = ((bn[2] * xp[:-2] + bn[1] * xp[1:-1]) + bn[0] * xp[2:]) / an[0]
         o = out[r]
-        f = firn[r]
         y1 = np.float32(0.0)
         y2 = np.float32(0.0)
         for t in range(f.shape[0]):
             v = f[t] - c2 * y2
             v = v - c1 * y1
-            o[t + 2] = v
+            o[t] = v
             y2 = y1
             y1 = v
-    y = torch.from_numpy(out[:, 2:].copy())
+    y = torch.from_numpy(out)
     return torch.clamp(y, -1.0, 1.0).reshape(shape)
 
 
