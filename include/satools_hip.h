@@ -173,6 +173,38 @@ int sat_f0_apply_f32(float* f0, int n, const float* stats, int quant_bins, const
 int sat_assemble_input_f32(const float* bn, const float* f0, const float* spk, float* x,
                            int B, int C_bn, int T, int T_f0, int n_spk, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * YAAPT pitch tracker (satools/satools/hifigan/yaapt.py:795-951), whole batch per call.
+ * The plan carries every integer / scalar constant the reference derives from its option dict
+ * (yaapt.py:815-886, :156-157, :190-204, :396-406, :686-688); the host computes it
+ * (sa-toolkit_amd/f0.py) so that the rounding of those derivations is done once, in Python, the
+ * way the reference does it.  lp / hp = biquad constants {b0, b1, b2, a0, a1/a0, a2/a0}.
+ *   wav [B][n]  ->  f0 [B][nframes] (Hz, 0 = unvoiced);  status [B] (device int32):
+ *   0 ok, 1 = no voiced frame (the reference raises RuntimeError there), 2 = NCCF window
+ *   invalid (the reference's assert N > 0).
+ * hann [frame_size], kaiser [2*frame_size], twiddle [4096][2] = exp(-2*pi*i*k/8192) are device
+ * tables built by the host.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t n, pad, L, Lz, nfft, frame_size, frame_jump, nframes;
+  int32_t nl_lo, nl_hi;
+  int32_t nframe_size, half_wl, wl, max_shc, min_shc, nharm, maxpeaks;
+  int32_t pk_center, pk_min_lag, pk_max_lag;
+  int32_t tda_len, tda_nframes, maxcands, nccf_center, median_value;
+  float fs, delta;
+  float nlfer_thresh1, nlfer_thresh2;
+  float shc_thresh1, inv_shc_thresh1, shc_thresh2, f0_double, f0_half, merit_extra;
+  float dp5_k1, f0_min, f0_max, spec_pitch_min_std;
+  float nccf_thresh1, nccf_thresh2, merit_boost1, merit_pivot;
+  float dp_w1, dp_w2, dp_w3, dp_w4;
+  float lp[6], hp[6];
+} sat_yaapt_plan;
+
+size_t sat_yaapt_workspace_bytes(const sat_yaapt_plan* plan, int B);
+int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float* f0, int32_t* status,
+                  const float* hann, const float* kaiser, const float* twiddle, void* workspace,
+                  size_t workspace_bytes, int B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

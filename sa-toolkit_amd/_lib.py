@@ -62,6 +62,9 @@ _PROTOS = {
                                         C.c_int, C.c_void_p]),
     "sat_f0_stats_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "sat_f0_apply_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "sat_yaapt_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "sat_yaapt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "sat_assemble_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p]),
 }

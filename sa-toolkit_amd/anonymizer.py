@@ -48,6 +48,7 @@ def build(args):
             self.utt2spk = utt2spk
             self.spk = sorted(set([v for v in utt2spk.values()]))
             self.f0: Optional[torch.Tensor] = None
+            self._defer_f0_status, self._f0_status = False, None
             self.hifigan = CoreHifiGan(
                 imput_dim=256 + 1 + len(self.spk),
                 upsample_rates=[5, 4, 4, 2, 2],
@@ -83,9 +84,11 @@ def build(args):
             self.f0 = f0
 
         def get_f0(self, wavinfo):
+            # the reference computes on the CPU and returns on the input's device (yaapt.py:798-799,940);
+            # here the whole batch is tracked on the GPU
             from . import f0 as f0_hip
             wav = getattr(wavinfo, "wav", wavinfo).detach()
-            out = f0_hip.yaapt(self._to_device(wav).clone(), self.f0_yaapt_opts)
+            out = f0_hip.yaapt(self._to_device(wav), self.f0_yaapt_opts)
             return out.to(wav.device)
 
         def get_spk_id(self, wavinfo, target=None):
@@ -97,6 +100,12 @@ def build(args):
         def extract_features(self, x, target):
             if self.f0 is not None:
                 f0, self.f0 = self.f0, None
+            elif self._defer_f0_status:
+                # inside convert(): launch YAAPT without stalling the stream; its status word is
+                # checked after the generator has been enqueued
+                from . import f0 as f0_hip
+                f0, self._f0_status = f0_hip.yaapt(self._to_device(x.detach()), self.f0_yaapt_opts, defer_status=True)
+                f0 = f0.unsqueeze(0)
             else:
                 f0 = self.get_f0(x).unsqueeze(0)
             bn = self.get_bn(x)
@@ -104,8 +113,16 @@ def build(args):
             return (f0, bn, spk_id)
 
         def convert(self, x, target):
-            (f0, bn, spk_id) = self.extract_features(x, target)
-            return self._forward(f0, bn, spk_id).squeeze(0)
+            self._defer_f0_status, self._f0_status = True, None
+            try:
+                (f0, bn, spk_id) = self.extract_features(x, target)
+            finally:
+                self._defer_f0_status = False
+            y = self._forward(f0, bn, spk_id).squeeze(0)
+            if self._f0_status is not None:
+                st, self._f0_status = self._f0_status, None
+                st.check()
+            return y
 
         def f0_transformation(self, f0):
             """host-level entry kept for API parity (hifigan.py:73-81); [B,1,T] device tensor"""

@@ -1,0 +1,819 @@
+// YAAPT pitch tracking on gfx950, batched over (utterance, frame).
+//
+// Reference: satools/satools/hifigan/yaapt.py:795-951 (`_yaapt`/`yaapt`: a serial Python loop over
+// the batch, forced onto the CPU) with the options of egs/vc/libritts/local/tuning/hifigan.py:31-36.
+// Kernel by kernel:
+//   prefilter     SignalObj.filtered_version :42-51 (torchaudio biquads; third-party)
+//   nlfer_frames  nlfer :148-176                    one 8192-point FFT in LDS per frame
+//   energy_norm   PitchObj.set_energy :125-128
+//   spec_frames   spec_track :209-238 + peaks :383-497   FFT -> |X| -> SHC -> candidate peaks
+//   spec_post     spec_track :241-312, dynamic5 :506-523, path1 :530-570, medfilt :54-69
+//   frame_means   the in-place mean subtraction on overlapping frame views, time_track :711-714 + :589
+//   nccf_frames   crs_corr :577-602 + cmp_rate :609-673 + merit weighting :724-727
+//   refine_dp     refine :732-784, dynamic :321-370, path1
+// Decision rules (strict/non-strict comparisons, first/last extremum on ties, stable ordering) are
+// kept exactly; f32 operation order is kept wherever the reference's order is defined by its source.
+#include <cmath>
+
+#include "common.h"
+
+namespace sat {
+
+typedef sat_yaapt_plan Plan;
+
+constexpr int FFT_N = 8192;
+constexpr int FFT_LOG = 13;
+constexpr int MAXP = 4;   // shc_maxpeaks
+constexpr int NC = 6;     // refine candidates: 2 tracks x nccf_maxcands
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wmin_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// block-wide sum of one float per thread (256 threads), result broadcast; `red` = 8 floats of LDS
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wsum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+  v = wmax(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// torch.maximum / torch.minimum propagate NaN
+__device__ __forceinline__ float tmax(float a, float b) { return (a != a || b != b) ? NAN : fmaxf(a, b); }
+__device__ __forceinline__ float tmin(float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); }
+
+// ------------------------------------------------------------------------------------------------
+// prefilter: zero-pad, (square), low-pass biquad -> clamp -> high-pass biquad -> clamp.
+// One wave per (utterance, signal).  The FIR halves are computed lane-parallel on 64-sample chunks;
+// the two IIR recursions are inherently sequential (y[t] depends on y[t-1], y[t-2]) and are run
+// redundantly by all lanes from LDS broadcasts, in the exact f32 order of the restated lfilter:
+//   f = ((b2*x[t-2] + b1*x[t-1]) + b0*x[t]) / a0 ;  v = f - c2*y[t-2] ;  v = v - c1*y[t-1]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) yaapt_prefilter_kernel(const float* __restrict__ wav, float* __restrict__ filt,
+                                                             const Plan P) {
+  __shared__ float s_f[64];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x, sig = blockIdx.y;
+  const float* w = wav + (size_t)b * P.n;
+  float* out = filt + ((size_t)b * 2 + sig) * P.Lz;
+  const float lb0 = P.lp[0], lb1 = P.lp[1], lb2 = P.lp[2], la0 = P.lp[3], lc1 = P.lp[4], lc2 = P.lp[5];
+  const float hb0 = P.hp[0], hb1 = P.hp[1], hb2 = P.hp[2], ha0 = P.hp[3], hc1 = P.hp[4], hc2 = P.hp[5];
+  float x_m1 = 0.f, x_m2 = 0.f;   // last two inputs of the previous chunk
+  float u_m1 = 0.f, u_m2 = 0.f;   // last two clamped low-pass outputs of the previous chunk
+  float ly1 = 0.f, ly2 = 0.f, hy1 = 0.f, hy2 = 0.f;
+  for (int t0 = 0; t0 < P.L; t0 += 64) {
+    const int t = t0 + lane;
+    float x = 0.f;
+    const int src = t - P.pad;
+    if (src >= 0 && src < P.n) x = w[src];
+    if (sig) x = x * x;
+    float x1 = __shfl_up(x, 1, 64), x2 = __shfl_up(x, 2, 64);
+    if (lane == 0) { x1 = x_m1; x2 = x_m2; }
+    if (lane == 1) { x2 = x_m1; }
+    x_m1 = __shfl(x, 63, 64);
+    x_m2 = __shfl(x, 62, 64);
+    s_f[lane] = ((lb2 * x2 + lb1 * x1) + lb0 * x) / la0;
+    __syncthreads();
+    float mine = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+      float v = s_f[i] - lc2 * ly2;
+      v = v - lc1 * ly1;
+      ly2 = ly1;
+      ly1 = v;
+      mine = (lane == i) ? v : mine;
+    }
+    __syncthreads();
+    const float u = fminf(fmaxf(mine, -1.f), 1.f);
+    float u1 = __shfl_up(u, 1, 64), u2 = __shfl_up(u, 2, 64);
+    if (lane == 0) { u1 = u_m1; u2 = u_m2; }
+    if (lane == 1) { u2 = u_m1; }
+    u_m1 = __shfl(u, 63, 64);
+    u_m2 = __shfl(u, 62, 64);
+    s_f[lane] = ((hb2 * u2 + hb1 * u1) + hb0 * u) / ha0;
+    __syncthreads();
+    mine = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+      float v = s_f[i] - hc2 * hy2;
+      v = v - hc1 * hy1;
+      hy2 = hy1;
+      hy1 = v;
+      mine = (lane == i) ? v : mine;
+    }
+    __syncthreads();
+    if (t < P.L) out[t] = fminf(fmaxf(mine, -1.f), 1.f);
+  }
+  for (int t = P.L + lane; t < P.Lz; t += 64) out[t] = 0.f;  // zero extension read by spec_track
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8192-point complex FFT in LDS, radix-2 decimation in time, 256 threads.  Input already stored in
+// bit-reversed order.  tw[k] = exp(-2*pi*i*k/8192), k < 4096 (host table, f64 -> f32).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int brev13(int j) { return (int)(__brev((unsigned)j) >> (32 - FFT_LOG)); }
+
+__device__ void fft8192(float* re, float* im, const float2* __restrict__ tw) {
+  const int tid = threadIdx.x;
+#pragma unroll 1
+  for (int s = 1; s <= FFT_LOG; ++s) {
+    const int half = 1 << (s - 1);
+    const int tstep = (FFT_N / 2) >> (s - 1);
+#pragma unroll 4
+    for (int k = 0; k < FFT_N / 2 / 256; ++k) {
+      const int i = tid + 256 * k;
+      const int pos = i & (half - 1);
+      const int a = ((i >> (s - 1)) << s) + pos;
+      const int c = a + half;
+      const float2 w = tw[pos * tstep];
+      const float xr = re[c], xi = im[c];
+      const float tr = xr * w.x - xi * w.y;
+      const float ti = xr * w.y + xi * w.x;
+      const float ur = re[a], ui = im[a];
+      re[a] = ur + tr;
+      im[a] = ui + ti;
+      re[c] = ur - tr;
+      im[c] = ui - ti;
+    }
+    __syncthreads();
+  }
+}
+
+// nlfer: frame (560 samples) x hann -> FFT -> sum |X[nl_lo:nl_hi]|
+__global__ void __launch_bounds__(256) yaapt_nlfer_kernel(const float* __restrict__ filt, const float* __restrict__ hann,
+                                                         const float2* __restrict__ tw, float* __restrict__ e_raw,
+                                                         const Plan P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* re = lds;
+  float* im = lds + FFT_N;
+  __shared__ float red[8];
+  const int f = blockIdx.x, b = blockIdx.y;
+  const float* x = filt + ((size_t)b * 2 + 0) * P.Lz + (size_t)f * P.frame_jump;
+  for (int i = threadIdx.x; i < FFT_N; i += 256) { re[i] = 0.f; im[i] = 0.f; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < P.frame_size; j += 256) re[brev13(j)] = x[j] * hann[j];
+  __syncthreads();
+  fft8192(re, im, tw);
+  float part = 0.f;
+  for (int k = P.nl_lo + threadIdx.x; k < P.nl_hi; k += 256) part += hypotf(re[k], im[k]);
+  const float tot = block_sum256(part, red);
+  if (threadIdx.x == 0) e_raw[(size_t)b * P.nframes + f] = tot;
+}
+
+// energy / mean(energy), vuv = energy > nlfer_thresh1   (one block per utterance)
+__global__ void __launch_bounds__(256) yaapt_energy_norm_kernel(const float* __restrict__ e_raw, float* __restrict__ energy,
+                                                               int* __restrict__ vuv, const Plan P) {
+  __shared__ float red[8];
+  const int b = blockIdx.x;
+  const float* e = e_raw + (size_t)b * P.nframes;
+  float part = 0.f;
+  for (int f = threadIdx.x; f < P.nframes; f += 256) part += e[f];
+  const float mean = block_sum256(part, red) / (float)P.nframes;
+  for (int f = threadIdx.x; f < P.nframes; f += 256) {
+    const float v = e[f] / mean;
+    energy[(size_t)b * P.nframes + f] = v;
+    vuv[(size_t)b * P.nframes + f] = v > P.nlfer_thresh1 ? 1 : 0;
+  }
+}
+
+// spectral track, per voiced frame: 1120 samples x kaiser, minus mean -> FFT -> |X| -> SHC -> peaks
+// cand layout: [b][8][nframes] = pitch[0..3], merit[0..3]
+__global__ void __launch_bounds__(256) yaapt_spec_kernel(const float* __restrict__ filt, const float* __restrict__ kaiser,
+                                                        const float2* __restrict__ tw, const int* __restrict__ vuv,
+                                                        float* __restrict__ cand, const Plan P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* re = lds;
+  float* im = lds + FFT_N;
+  __shared__ float red[8];
+  __shared__ float s_shc[256];
+  __shared__ unsigned char s_flag[256];
+  const int tid = threadIdx.x;
+  const int f = blockIdx.x, b = blockIdx.y;
+  const int nf = P.nframes;
+  float* cp = cand + (size_t)b * 8 * nf;
+  float* cm = cp + 4 * (size_t)nf;
+  if (!vuv[(size_t)b * nf + f]) {
+    if (tid < MAXP) { cp[(size_t)tid * nf + f] = 0.f; cm[(size_t)tid * nf + f] = 1.f; }
+    return;
+  }
+  const float* x = filt + ((size_t)b * 2 + 1) * P.Lz + (size_t)f * P.frame_jump;
+  for (int i = tid; i < FFT_N; i += 256) { re[i] = 0.f; im[i] = 0.f; }
+  // windowed slice and its mean (nframe_size <= 5*256)
+  float xv[5];
+  float part = 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = tid + 256 * k;
+    float v = 0.f;
+    if (j < P.nframe_size) v = x[j] * kaiser[j];
+    xv[k] = v;
+    part += v;
+  }
+  const float mean = block_sum256(part, red) / (float)P.nframe_size;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = tid + 256 * k;
+    if (j < P.nframe_size) re[brev13(j)] = xv[k] - mean;
+  }
+  __syncthreads();
+  fft8192(re, im, tw);
+  // magnitude[i] = i < half_wl ? 0 : |X[i - half_wl]| ; written over the front of `im` is unsafe
+  // (both are inputs), so it goes to a separate region: reuse re[] after reading (two passes).
+  const int n_mag = P.min_shc * (P.nharm + 1) + (P.max_shc - P.min_shc) * (P.nharm + 1) + P.wl;  // exclusive bound
+  float mg[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = tid + 256 * k;
+    float v = 0.f;
+    if (i < n_mag && i >= P.half_wl) v = hypotf(re[i - P.half_wl], im[i - P.half_wl]);
+    mg[k] = v;
+  }
+  __syncthreads();
+  float* mag = re;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = tid + 256 * k;
+    if (i < n_mag) mag[i] = mg[k];
+  }
+  __syncthreads();
+  // SHC[min_shc-1 + r] = sum_w prod_h mag[min_shc*(h+1) + r*(h+1) + w]
+  const int rows = P.max_shc - P.min_shc + 1;
+  float shc = 0.f;
+  if (tid >= P.min_shc - 1 && tid < P.min_shc - 1 + rows) {
+    const int r = tid - (P.min_shc - 1);
+    float s = 0.f;
+    for (int w = 0; w < P.wl; ++w) {
+      float pr = mag[P.min_shc + r + w];
+      for (int h = 1; h <= P.nharm; ++h) pr = pr * mag[(P.min_shc + r) * (h + 1) + w];
+      s += pr;
+    }
+    shc = s;
+  }
+  // ---- peaks() on the 256-vector (yaapt.py:383-497) ----
+  const int lo = P.pk_min_lag, hi = P.pk_max_lag, c = P.pk_center;
+  const bool in_rng = tid >= lo && tid <= hi;
+  const float mx = block_max256(in_rng ? shc : -INFINITY, red);
+  if (mx > 1e-14f) shc = shc / mx;
+  s_shc[tid] = shc;
+  const float avg = block_sum256(in_rng ? shc : 0.f, red) / (float)(hi - lo + 1);
+  bool ispk = false;
+  if (tid >= lo + c + 1 && tid <= hi - c) {
+    const float v = s_shc[tid];
+    if (v > s_shc[tid - 1] && v > s_shc[tid + 1] && v > P.shc_thresh2 * avg) {
+      ispk = true;  // argmax(data[n-c : n+c+1]) == c  <=>  strictly above everything before, >= everything after
+      for (int i = tid - c; i < tid; ++i) ispk = ispk && (s_shc[i] < v);
+      for (int i = tid + 1; i <= tid + c; ++i) ispk = ispk && (s_shc[i] <= v);
+    }
+  }
+  s_flag[tid] = ispk ? 1 : 0;
+  __syncthreads();
+  if (tid != 0) return;
+  float pit[MAXP], mer[MAXP];
+  for (int i = 0; i < MAXP; ++i) { pit[i] = 0.f; mer[i] = 1.f; }
+  bool done = avg > P.inv_shc_thresh1;
+  if (!done) {
+    // collect peaks in ascending lag; keep the MAXP largest merits, earlier index first on ties
+    float sp[MAXP], sm[MAXP];
+    int np = 0, total = 0;
+    float maxm = 0.f;
+    for (int n = lo + c + 1; n <= hi - c; ++n) {
+      if (!s_flag[n]) continue;
+      const float m = s_shc[n];
+      const float pv = (float)n * P.delta;
+      ++total;
+      maxm = total == 1 ? m : fmaxf(maxm, m);
+      int pos = np;
+      while (pos > 0 && sm[pos - 1] < m) --pos;   // stable descending insertion
+      if (pos < MAXP) {
+        const int last = np < MAXP ? np : MAXP - 1;
+        for (int i = last; i > pos; --i) { sp[i] = sp[i - 1]; sm[i] = sm[i - 1]; }
+        sp[pos] = pv;
+        sm[pos] = m;
+        if (np < MAXP) ++np;
+      }
+    }
+    if (total == 0) maxm = 0.f;
+    if (maxm / avg < P.shc_thresh1) {
+      done = true;
+    } else if (np > 0) {
+      for (int i = 0; i < MAXP; ++i) { pit[i] = i < np ? sp[i] : 0.f; mer[i] = i < np ? sm[i] : 0.f; }
+      int k = np;
+      if (pit[0] > P.f0_double) { k = k + 1 < MAXP ? k + 1 : MAXP; pit[k - 1] = pit[0] / 2.0f; mer[k - 1] = P.merit_extra; }
+      if (pit[0] < P.f0_half) { k = k + 1 < MAXP ? k + 1 : MAXP; pit[k - 1] = pit[0] * 2.0f; mer[k - 1] = P.merit_extra; }
+      for (int i = k; i < MAXP; ++i) { pit[i] = pit[0]; mer[i] = mer[0]; }
+    }
+  }
+  for (int i = 0; i < MAXP; ++i) { cp[(size_t)i * nf + f] = pit[i]; cm[(size_t)i * nf + f] = mer[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// serial per-utterance helpers (lane 0 of one wave; data in LDS)
+// ------------------------------------------------------------------------------------------------
+__device__ float median_small(float* v, int k) {  // k odd, <= 7: middle order statistic
+  for (int i = 1; i < k; ++i) {
+    const float x = v[i];
+    int j = i - 1;
+    while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; }
+    v[j + 1] = x;
+  }
+  return v[k / 2];
+}
+__device__ void medfilt_lds(const float* in, float* out, int n, int k) {  // zero-padded sliding median
+  const int pad = k / 2;
+  for (int i = 0; i < n; ++i) {
+    float w[7];
+    for (int j = 0; j < k; ++j) {
+      const int s = i + j - pad;
+      w[j] = (s >= 0 && s < n) ? in[s] : 0.f;
+    }
+    out[i] = median_small(w, k);
+  }
+}
+__device__ float mean_f(const float* v, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += (double)v[i];
+  return (float)(s / (double)n);   // n == 0 -> NaN like torch.mean of an empty tensor
+}
+__device__ float std_unbiased_f(const float* v, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += (double)v[i];
+  const double m = s / (double)n;
+  double q = 0.0;
+  for (int i = 0; i < n; ++i) { const double d = (double)v[i] - m; q += d * d; }
+  return (float)sqrt(q / (double)(n - 1));  // n == 1 -> NaN
+}
+
+// path1 (yaapt.py:530-570).  local [C][T] (row stride ls), trans(i, j, t) supplied by a functor.
+// aux[i][j] = PCOST[j] + trans[i][j][t]; K[i] = LAST argmin_j; CCOST[i] = PCOST[K[i]] + trans[K[i]][i][t]
+// + local[i][t]; p_small[t] = LAST argmin_i CCOST.  Back-trace P[t] = PRED[P[t+1]][t+1].
+template <int C, class TransFn>
+__device__ void path1(const float* local, int ls, int T, TransFn trans, unsigned char* pred, int* path_last,
+                      unsigned char* path_out) {
+  float pc[C], cc[C];
+  for (int i = 0; i < C; ++i) pc[i] = local[i * ls];
+  int psmall = 0;
+  for (int t = 1; t < T; ++t) {
+    int K[C];
+    for (int i = 0; i < C; ++i) {
+      int best = 0;
+      float bv = pc[0] + trans(i, 0, t);
+      for (int j = 1; j < C; ++j) {
+        const float v = pc[j] + trans(i, j, t);
+        if (v <= bv) { bv = v; best = j; }   // last minimum wins
+      }
+      K[i] = best;
+      pred[(size_t)i * T + t] = (unsigned char)best;
+    }
+    for (int i = 0; i < C; ++i) cc[i] = (pc[K[i]] + trans(K[i], i, t)) + local[i * ls + t];
+    int jb = 0;
+    float jv = cc[0];
+    for (int i = 1; i < C; ++i)
+      if (cc[i] <= jv) { jv = cc[i]; jb = i; }
+    for (int i = 0; i < C; ++i) pc[i] = cc[i];
+    psmall = jb;
+  }
+  // P = ones; P[-1] = p_small[-1] (0 when T == 1)
+  int p = T > 1 ? psmall : 0;
+  path_out[T - 1] = (unsigned char)p;
+  for (int t = T - 2; t >= 0; --t) {
+    p = pred[(size_t)p * T + (t + 1)];
+    path_out[t] = (unsigned char)p;
+  }
+  (void)path_last;
+}
+
+// spec_track after the per-frame candidates: selection, smoothing, Viterbi, interpolation.
+// One wave per utterance, lane 0 does the serial work.  LDS (floats): vcp[4*nf] vcm[4*nf] a[nf] b[nf]
+// spec[nf]; bytes: pred[4*nf] path[nf]; shorts: vidx[nf], index[nf]
+__global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __restrict__ cand, float* __restrict__ spec_out,
+                                                            float* __restrict__ scal, int* __restrict__ status,
+                                                            const Plan P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nf = P.nframes;
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  float* vcp = lds;
+  float* vcm = vcp + 4 * (size_t)nf;
+  float* ta = vcm + 4 * (size_t)nf;
+  float* tb = ta + nf;
+  float* spec = tb + nf;
+  short* vidx = (short*)(spec + nf);
+  short* index = vidx + nf;
+  unsigned char* pred = (unsigned char*)(index + nf);
+  unsigned char* path = pred + 4 * (size_t)nf;
+  const float* cp = cand + (size_t)b * 8 * nf;
+  const float* cm = cp + 4 * (size_t)nf;
+  int nv = 0;
+  for (int f = 0; f < nf; ++f) {
+    spec[f] = cp[f];
+    if (cp[f] > 0.f) {
+      vidx[nv] = (short)f;
+      for (int c = 0; c < 4; ++c) { vcp[c * nf + nv] = cp[(size_t)c * nf + f]; vcm[c * nf + nv] = cm[(size_t)c * nf + f]; }
+      ++nv;
+    }
+  }
+  float pitch_avg, pitch_std;
+  if (nv == 0) {
+    // the reference fails here (medfilt of an empty tensor, yaapt.py:257 -> :54-69); report it
+    status[b] = 1;
+    pitch_avg = 150.f;
+    pitch_std = NAN;
+  } else {
+    const float avg_v = mean_f(vcp, nv);
+    const float std_v = std_unbiased_f(vcp, nv);
+    const float ref = 0.8f * avg_v;
+    for (int i = 0; i < nv; ++i) {
+      int bi = 0;
+      float bv = fabsf(vcp[i] - ref) * (3.f - vcm[i]);
+      for (int c = 1; c < 4; ++c) {
+        const float d = fabsf(vcp[c * nf + i] - ref) * (3.f - vcm[c * nf + i]);
+        if (d < bv) { bv = d; bi = c; }   // first minimum
+      }
+      index[i] = (short)bi;
+      ta[i] = vcp[bi * nf + i];
+    }
+    const int mk = P.median_value - 2 > 1 ? P.median_value - 2 : 1;
+    medfilt_lds(ta, tb, nv, mk);
+    for (int i = 0; i < nv; ++i) vcp[index[i] * nf + i] = tb[i];
+    const float k1 = (P.dp5_k1 * std_v) / avg_v;
+    float* vpitch = ta;
+    if (nv > 2) {
+      // dynamic5 (yaapt.py:506-523): local = 1 - merit (in place), trans = k1*(0.05*d + d*d), d = |p_j(t) - p_i(t-1)|/f0_min
+      for (int i = 0; i < 4 * nf; ++i) vcm[i] = 1.f - vcm[i];
+      const float f0min = P.f0_min;
+      auto tr = [&](int i, int j, int t) {
+        const float d = fabsf(vcp[j * nf + t] - vcp[i * nf + (t - 1)]) / f0min;
+        return k1 * (0.05f * d + d * d);
+      };
+      path1<4>(vcm, nf, nv, tr, pred, nullptr, path);
+      for (int t = 0; t < nv; ++t) tb[t] = vcp[path[t] * nf + t];
+      medfilt_lds(tb, ta, nv, mk);
+    } else {
+      for (int i = 0; i < nv; ++i) ta[i] = 150.f;
+    }
+    pitch_avg = mean_f(vpitch, nv);
+    pitch_std = tmax(std_unbiased_f(vpitch, nv), pitch_avg * P.spec_pitch_min_std);
+    for (int i = 0; i < nv; ++i) spec[vidx[i]] = vpitch[i];
+  }
+  if (spec[0] < pitch_avg / 2.f) spec[0] = pitch_avg;
+  if (spec[nf - 1] < pitch_avg / 2.f) spec[nf - 1] = pitch_avg;
+  // F.interpolate(non-zero values, size=nf, mode='linear', align_corners=False)
+  int nz = 0;
+  for (int f = 0; f < nf; ++f)
+    if (spec[f] != 0.f) tb[nz++] = spec[f];
+  float* out = spec_out + (size_t)b * nf;
+  if (nz == nf) {
+    for (int f = 0; f < nf; ++f) spec[f] = tb[f];
+  } else {
+    const float scale = (float)nz / (float)nf;
+    for (int f = 0; f < nf; ++f) {
+      // torch's CPU kernel contracts both expressions into fused multiply-adds (checked bit for
+      // bit against F.interpolate): src = fma(scale, f + 0.5, -0.5), out = fma(l0, x0, l1*x1)
+      float src = fmaf(scale, (float)f + 0.5f, -0.5f);
+      if (src < 0.f) src = 0.f;
+      int i0 = (int)floorf(src);
+      if (i0 > nz - 1) i0 = nz - 1;
+      float l1 = src - (float)i0;
+      l1 = fminf(fmaxf(l1, 0.f), 1.f);
+      const int i1 = i0 + (i0 < nz - 1 ? 1 : 0);
+      const float l0 = 1.f - l1;
+      spec[f] = fmaf(l0, tb[i0], l1 * tb[i1]);
+    }
+  }
+  if (nf >= 4) { spec[0] = spec[2]; spec[1] = spec[3]; }
+  for (int f = 0; f < nf; ++f) out[f] = spec[f];
+  scal[b * 4 + 0] = pitch_std;
+}
+
+// frame means of time_track's in-place subtraction on overlapping views: frame k's first `ov`
+// samples already carry frame k-1's mean.  One wave per (utterance, signal); frames are sequential.
+__global__ void __launch_bounds__(64) yaapt_frame_means_kernel(const float* __restrict__ filt, float* __restrict__ fmean,
+                                                              const Plan P) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x, sig = blockIdx.y;
+  const float* x = filt + ((size_t)b * 2 + sig) * P.Lz;
+  float* m = fmean + ((size_t)b * 2 + sig) * P.nframes;
+  const int ov = P.tda_len - P.frame_jump;
+  float prev = 0.f;
+  for (int k = 0; k < P.tda_nframes; ++k) {
+    float part = 0.f;
+    for (int j = lane; j < P.tda_len; j += 64) {
+      float v = x[(size_t)k * P.frame_jump + j];
+      if (k > 0 && j < ov) v = v - prev;
+      part += v;
+    }
+    const float mean = wsum(part) / (float)P.tda_len;
+    if (lane == 0) m[k] = mean;
+    prev = mean;
+  }
+}
+
+// NCCF candidate of one (utterance, signal, frame)
+__global__ void __launch_bounds__(256) yaapt_nccf_kernel(const float* __restrict__ filt, const float* __restrict__ fmean,
+                                                        const float* __restrict__ spec, const float* __restrict__ scal,
+                                                        float* __restrict__ tp, float* __restrict__ tm,
+                                                        int* __restrict__ status, const Plan P) {
+  __shared__ float d[1024];
+  __shared__ float phi[1024];
+  __shared__ float red[8];
+  __shared__ int s_first;
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x, sig = blockIdx.y, b = blockIdx.z;
+  const int nf = P.nframes;
+  const size_t oidx = ((size_t)b * 2 + sig) * nf + k;
+  const float sp = spec[(size_t)b * nf + k];
+  const float pstd = scal[b * 4 + 0];
+  const float fthr = 5.0f * pstd;
+  const float rlo = tmax(sp - 2.0f * pstd, P.f0_min);
+  const float rhi = tmin(sp + 2.0f * pstd, P.f0_max);
+  const float fa = floorf(P.fs / rhi), fb = floorf(P.fs / rlo);
+  float pitch = 0.f, merit = 0.f;
+  const int n = P.tda_len;
+  if (!(fa != fa) && !(fb != fb)) {
+    const int lag_min = (int)fa - P.nccf_center;
+    const int lag_max = (int)fb + P.nccf_center;
+    const int N = n - lag_max;
+    if (N <= 0 || lag_min < 1) {
+      if (tid == 0) status[b] = 2;  // the reference asserts N > 0 (yaapt.py:586)
+    } else {
+      const float* x = filt + ((size_t)b * 2 + sig) * P.Lz + (size_t)k * P.frame_jump;
+      const float* fm = fmean + ((size_t)b * 2 + sig) * nf;
+      const float mk = fm[k];
+      const float mprev = k > 0 ? fm[k - 1] : 0.f;
+      const int ov = P.tda_len - P.frame_jump;
+      for (int j = tid; j < n; j += 256) {
+        float v = x[j];
+        if (k > 0 && j < ov) v = v - mprev;
+        d[j] = v - mk;
+        phi[j] = 0.f;
+      }
+      __syncthreads();
+      float part = 0.f;
+      for (int j = tid; j < N; j += 256) part += d[j] * d[j];
+      const float pw = block_sum256(part, red);
+      const int nl = lag_max - lag_min;
+      for (int l = tid; l < nl; l += 256) {
+        const float* row = d + lag_min + l;
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= N; j += 4) {
+          n0 = fmaf(row[j], d[j], n0); q0 = fmaf(row[j], row[j], q0);
+          n1 = fmaf(row[j + 1], d[j + 1], n1); q1 = fmaf(row[j + 1], row[j + 1], q1);
+          n2 = fmaf(row[j + 2], d[j + 2], n2); q2 = fmaf(row[j + 2], row[j + 2], q2);
+          n3 = fmaf(row[j + 3], d[j + 3], n3); q3 = fmaf(row[j + 3], row[j + 3], q3);
+        }
+        for (; j < N; ++j) { n0 = fmaf(row[j], d[j], n0); q0 = fmaf(row[j], row[j], q0); }
+        const float nume = (n0 + n1) + (n2 + n3);
+        const float den = (q0 + q1) + (q2 + q3);
+        phi[lag_min + l] = nume / sqrtf(den * pw + 0.0f);
+      }
+      __syncthreads();
+      // cmp_rate: first index with phi[n] > phi[n-1], > phi[n+1], > nccf_thresh1 inside [lag_min+c, lag_max-c]
+      const int c = P.nccf_center;
+      int first = 1 << 30;
+      float amax = 0.f;  // phi is zero outside the lag window
+      for (int i = tid; i < n; i += 256) {
+        const float v = phi[i];
+        amax = fmaxf(amax, v);   // NaN entries are skipped by fmaxf, like they never win a '>' test
+        if (i >= lag_min + c && i <= lag_max - c && v > phi[i - 1] && v > phi[i + 1] && v > P.nccf_thresh1)
+          first = min(first, i);
+      }
+      amax = block_max256(amax, red);
+      first = wmin_i(first);
+      if (tid == 0) s_first = 1 << 30;
+      __syncthreads();
+      if ((tid & 63) == 0) atomicMin(&s_first, first);
+      __syncthreads();
+      first = s_first;
+      if (first < (1 << 30)) {
+        bool take = amax > P.nccf_thresh2;
+        if (!take) {
+          const float v = phi[first];
+          take = true;  // argmax(phi[first-c : first+c+1]) == c
+          for (int i = first - c; i < first; ++i) take = take && (phi[i] < v);
+          for (int i = first + 1; i <= first + c; ++i) take = take && (phi[i] <= v);
+        }
+        if (take) {
+          pitch = (float)((double)P.fs / (double)(first + 1));
+          merit = phi[first];
+          if (merit > 1.0f) merit = merit / merit;
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    const float diff = fabsf(pitch - sp);
+    const float m1 = diff < fthr ? 1.f : 0.f;
+    const float match = (1.f - diff / fthr) * m1;
+    tp[oidx] = pitch;
+    tm[oidx] = (P.merit_boost1 * merit) * match;
+  }
+}
+
+// refine + dynamic + path1 -> final pitch.  One wave per utterance, lane 0.
+// LDS floats: rp[6*nf] rm[6*nf] ta[nf] tb[nf]; bytes pred[6*nf] path[nf]
+__global__ void __launch_bounds__(64) yaapt_refine_dp_kernel(const float* __restrict__ tp, const float* __restrict__ tm,
+                                                            const float* __restrict__ spec, const float* __restrict__ energy,
+                                                            const int* __restrict__ vuv, float* __restrict__ f0,
+                                                            const Plan P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (threadIdx.x != 0) return;
+  const int nf = P.nframes;
+  const int b = blockIdx.x;
+  float* rp = lds;
+  float* rm = rp + NC * (size_t)nf;
+  float* ta = rm + NC * (size_t)nf;
+  float* tb = ta + nf;
+  unsigned char* pred = (unsigned char*)(tb + nf);
+  unsigned char* path = pred + NC * (size_t)nf;
+  const float* tp1 = tp + ((size_t)b * 2 + 0) * nf;
+  const float* tp2 = tp + ((size_t)b * 2 + 1) * nf;
+  const float* tm1 = tm + ((size_t)b * 2 + 0) * nf;
+  const float* tm2 = tm + ((size_t)b * 2 + 1) * nf;
+  const float* sp = spec + (size_t)b * nf;
+  const float* en = energy + (size_t)b * nf;
+  const int* vv = vuv + (size_t)b * nf;
+  const int nt = P.tda_nframes;
+  // concatenate the two tracks (rows 0 and 3 carry the single NCCF candidate), order by merit
+  // descending with a stable sort (torch CPU argsort keeps equal keys in index order)
+  for (int k = 0; k < nf; ++k) {
+    float p[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, m[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (k < nt) { p[0] = tp1[k]; m[0] = tm1[k]; p[3] = tp2[k]; m[3] = tm2[k]; }
+    int ord[NC];
+    for (int i = 0; i < NC; ++i) {
+      int pos = i;
+      // key = -m ascending, NaN last; insertion keeps earlier rows first on ties
+      while (pos > 0) {
+        const float a = m[ord[pos - 1]], c = m[i];
+        const bool a_nan = a != a, c_nan = c != c;
+        const bool c_before_a = c_nan ? false : (a_nan ? true : (c > a));
+        if (!c_before_a) break;
+        ord[pos] = ord[pos - 1];
+        --pos;
+      }
+      ord[pos] = i;
+    }
+    // values: flip(sort ascending) ; NaN (sorted last ascending) comes first after the flip
+    float ms[NC];
+    {
+      float t[NC];
+      for (int i = 0; i < NC; ++i) t[i] = m[i];
+      for (int i = 1; i < NC; ++i) {
+        const float x = t[i];
+        int j = i - 1;
+        while (j >= 0 && ((t[j] != t[j]) ? !(x != x) : (x == x && t[j] > x))) { t[j + 1] = t[j]; --j; }
+        t[j + 1] = x;
+      }
+      for (int i = 0; i < NC; ++i) ms[i] = t[NC - 1 - i];
+    }
+    for (int i = 0; i < NC; ++i) { rp[i * nf + k] = p[ord[i]]; rm[i * nf + k] = ms[i]; }
+  }
+  // best_pitch = medfilt(time_pitch[0], median_value) * vuv
+  medfilt_lds(rp, ta, nf, P.median_value);
+  for (int k = 0; k < nf; ++k) ta[k] = ta[k] * (vv[k] ? 1.f : 0.f);
+  const float th2 = P.nlfer_thresh2;
+  for (int k = 0; k < nf; ++k) {
+    const float e = en[k];
+    const float tp0 = rp[k];
+    const bool i1 = e <= th2;
+    const bool i2 = (e > th2) && (tp0 > 0.f);
+    const bool i3 = (e > th2) && (tp0 <= 0.f);
+    bool mm[NC];
+    for (int r = 0; r < NC; ++r) mm[r] = (r >= 1 && r <= NC - 2) && (rp[r * nf + k] == 0.f) && i2;
+    if (i1) for (int r = 0; r < NC; ++r) { rp[r * nf + k] = 0.f; rm[r * nf + k] = P.merit_pivot; }
+    if (i2) { rp[(NC - 1) * nf + k] = 0.f; rm[(NC - 1) * nf + k] = 1.0f - rm[k]; }
+    for (int r = 0; r < NC; ++r) if (mm[r]) rm[r * nf + k] = 0.f;
+    if (i3) {
+      rp[k] = sp[k];
+      rm[k] = tmin(1.f, e / 2.0f);
+      for (int r = 1; r < NC; ++r) { rp[r * nf + k] = 0.f; rm[r * nf + k] = 1.0f - rm[k]; }
+    }
+    const float best = ta[k];
+    rp[(NC - 2) * nf + k] = best;
+    if (best > 0.f) rm[(NC - 2) * nf + k] = rm[k];
+    else rm[(NC - 2) * nf + k] = 1.0f - tmin(1.f, e / 2.0f);
+    rp[(NC - 3) * nf + k] = sp[k];
+    rm[(NC - 3) * nf + k] = e / 5.0f;
+  }
+  // dynamic (yaapt.py:321-370)
+  int cnt = 0;
+  double acc = 0.0;
+  for (int k = 0; k < nf; ++k) if (ta[k] > 0.f) { acc += (double)ta[k]; ++cnt; }
+  const float mean_pitch = (float)(acc / (double)cnt);
+  for (int i = 0; i < NC * nf; ++i) rm[i] = 1.f - rm[i];   // local cost
+  const float w1 = P.dp_w1, w2 = P.dp_w2, w3 = P.dp_w3, w4 = P.dp_w4;
+  auto tr = [&](int i, int j, int t) {
+    const float p1 = rp[j * nf + t], p2 = rp[i * nf + (t - 1)];
+    float v = 1.f;
+    if (p1 > 0.f && p2 > 0.f) v = w1 * (fabsf(p1 - p2) / mean_pitch);
+    else if ((p1 == 0.f && p2 > 0.f) || (p1 > 0.f && p2 == 0.f)) v = w2 * (1.f - tmin(1.f, fabsf(en[t - 1] - en[t])));
+    else if (p1 == 0.f && p2 == 0.f) v = w3;
+    return v / w4;
+  };
+  path1<NC>(rm, nf, nf, tr, pred, nullptr, path);
+  float* out = f0 + (size_t)b * nf;
+  for (int k = 0; k < nf; ++k) out[k] = rp[path[k] * nf + k];
+}
+
+}  // namespace sat
+
+using namespace sat;
+
+static size_t yaapt_ws_floats(const Plan& P, int B) {
+  const size_t nf = P.nframes;
+  return (size_t)B * (2 * (size_t)P.Lz + 3 * nf /*e_raw, energy, vuv*/ + 8 * nf /*cand*/ + nf /*spec*/ + 4 /*scal*/ +
+                      2 * nf /*fmean*/ + 4 * nf /*tp, tm*/) + 64;
+}
+
+extern "C" size_t sat_yaapt_workspace_bytes(const sat_yaapt_plan* plan, int B) {
+  if (!plan || B <= 0) return 0;
+  return align_up(yaapt_ws_floats(*plan, B) * sizeof(float), 256);
+}
+
+extern "C" int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float* f0, int32_t* status,
+                             const float* hann, const float* kaiser, const float* twiddle, void* workspace,
+                             size_t workspace_bytes, int B, void* stream) {
+  SAT_REQUIRE(plan && wav && f0 && status && hann && kaiser && twiddle && workspace, "yaapt: null pointer");
+  const Plan& P = *plan;
+  SAT_REQUIRE(B > 0 && P.n > 0, "yaapt: empty batch");
+  SAT_REQUIRE(P.nfft == FFT_N, "yaapt: fft_length %d not supported (8192 only)", P.nfft);
+  SAT_REQUIRE(P.maxpeaks == MAXP && P.maxcands * 2 == NC, "yaapt: shc_maxpeaks/nccf_maxcands must be 4/3");
+  SAT_REQUIRE(P.nharm >= 1 && P.nharm <= 7, "yaapt: shc_numharms out of range");
+  // reference asserts 15 < frame_size < 2048 (yaapt.py:885-886)
+  SAT_REQUIRE(P.frame_size > 15, "Frame length value %d is too short.", P.frame_size);
+  SAT_REQUIRE(P.frame_size < 2048, "Frame length value %d exceeds the limit.", P.frame_size);
+  SAT_REQUIRE(P.nframe_size <= 5 * 256 && P.frame_size <= FFT_N, "yaapt: frame_length too long for the spectral kernel");
+  SAT_REQUIRE(P.max_shc <= 256 && P.pk_max_lag + 1 < 256 && P.pk_min_lag + P.pk_center + 1 >= 1 &&
+                  P.pk_min_lag - 0 >= 0, "yaapt: SHC range out of the 256-bin kernel window");
+  SAT_REQUIRE(P.min_shc * (P.nharm + 1) + (P.max_shc - P.min_shc) * (P.nharm + 1) + P.wl <= 5 * 256,
+              "yaapt: SHC harmonics exceed the spectral kernel's magnitude window");
+  SAT_REQUIRE(P.tda_len <= 1024 && P.tda_len > P.frame_jump, "yaapt: tda_frame_length not supported");
+  SAT_REQUIRE(P.median_value >= 1 && P.median_value <= 7 && (P.median_value & 1), "yaapt: median_value must be odd <= 7");
+  SAT_REQUIRE(P.nframes >= 4 && P.nframes <= 2048, "yaapt: %d frames not supported (4..2048, i.e. up to ~40 s)", P.nframes);
+  SAT_REQUIRE(P.tda_nframes == P.nframes, "yaapt: tda frame count differs from the analysis frame count");
+  SAT_REQUIRE(workspace_bytes >= sat_yaapt_workspace_bytes(plan, B), "yaapt: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nf = P.nframes;
+  float* w = (float*)workspace;
+  float* filt = w;            w += (size_t)B * 2 * P.Lz;
+  float* e_raw = w;           w += (size_t)B * nf;
+  float* energy = w;          w += (size_t)B * nf;
+  int* vuv = (int*)w;         w += (size_t)B * nf;
+  float* cand = w;            w += (size_t)B * 8 * nf;
+  float* spec = w;            w += (size_t)B * nf;
+  float* scal = w;            w += (size_t)B * 4;
+  float* fmean = w;           w += (size_t)B * 2 * nf;
+  float* tp = w;              w += (size_t)B * 2 * nf;
+  float* tm = w;              w += (size_t)B * 2 * nf;
+  const float2* tw = (const float2*)twiddle;
+  SAT_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
+
+  hipLaunchKernelGGL(yaapt_prefilter_kernel, dim3(B, 2), dim3(64), 0, s, wav, filt, P);
+  SAT_LAUNCH_CHECK("yaapt_prefilter_kernel");
+  const size_t fft_lds = 2 * FFT_N * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SAT_HIP(hipFuncSetAttribute((const void*)yaapt_nlfer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds));
+    SAT_HIP(hipFuncSetAttribute((const void*)yaapt_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds));
+    SAT_HIP(hipFuncSetAttribute((const void*)yaapt_spec_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SAT_HIP(hipFuncSetAttribute((const void*)yaapt_refine_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(yaapt_nlfer_kernel, dim3(P.nframes, B), dim3(256), fft_lds, s, filt, hann, tw, e_raw, P);
+  SAT_LAUNCH_CHECK("yaapt_nlfer_kernel");
+  hipLaunchKernelGGL(yaapt_energy_norm_kernel, dim3(B), dim3(256), 0, s, e_raw, energy, vuv, P);
+  SAT_LAUNCH_CHECK("yaapt_energy_norm_kernel");
+  hipLaunchKernelGGL(yaapt_spec_kernel, dim3(P.nframes, B), dim3(256), fft_lds, s, filt, kaiser, tw, vuv, cand, P);
+  SAT_LAUNCH_CHECK("yaapt_spec_kernel");
+  const size_t post_lds = (size_t)nf * (4 + 4 + 3) * sizeof(float) + nf * 2 * sizeof(short) + nf * 5;
+  hipLaunchKernelGGL(yaapt_spec_post_kernel, dim3(B), dim3(64), post_lds, s, cand, spec, scal, status, P);
+  SAT_LAUNCH_CHECK("yaapt_spec_post_kernel");
+  hipLaunchKernelGGL(yaapt_frame_means_kernel, dim3(B, 2), dim3(64), 0, s, filt, fmean, P);
+  SAT_LAUNCH_CHECK("yaapt_frame_means_kernel");
+  hipLaunchKernelGGL(yaapt_nccf_kernel, dim3(P.nframes, 2, B), dim3(256), 0, s, filt, fmean, spec, scal, tp, tm, status, P);
+  SAT_LAUNCH_CHECK("yaapt_nccf_kernel");
+  const size_t dp_lds = (size_t)nf * (2 * NC + 2) * sizeof(float) + nf * (NC + 1);
+  hipLaunchKernelGGL(yaapt_refine_dp_kernel, dim3(B), dim3(64), dp_lds, s, tp, tm, spec, energy, vuv, f0, P);
+  SAT_LAUNCH_CHECK("yaapt_refine_dp_kernel");
+  return SAT_OK;
+}
