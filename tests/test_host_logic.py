@@ -1,0 +1,166 @@
+"""Host-side logic and the C-ABI surface, CPU only (no GPU compute calls)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import satools_amd
+from satools_amd import _lib, f0, f0_transforms, infer_helper, packing, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.lib()
+    assert lib.sat_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "satools_hip.h")).read()
+    declared = set(re.findall(r"\b(sat_[a-z0-9_]+)\s*\(", header))
+    declared -= {"sat_status"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/satools_hip.h but not exported"
+    assert set(_lib.exported_symbols()) <= declared
+
+
+def test_hip_calls_fail_loudly_without_a_device_tensor():
+    with pytest.raises(_lib.SatError):
+        _lib.ptr(torch.zeros(4))
+    model = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1")
+    with pytest.raises(_lib.SatError):
+        model.get_bn(torch.zeros(1, 8000))            # model on the CPU: no fallback
+
+
+def test_state_dict_keys_match_the_reference(gold, fbank_tag_state):
+    state, net = fbank_tag_state
+    ref = gold.json("state_dict_keys_fbank.json")
+    mine = [[k, list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()]
+    assert mine == ref
+    # a reference-format checkpoint round-trips, and remove_weight_norm keeps the folded weights
+    net.load_state_dict(state["base_model_state_dict"])
+    w = net.hifigan.ups[0].folded_weight().clone()
+    net.remove_weight_norm()
+    assert "hifigan.ups.0.weight" in net.state_dict() and "hifigan.ups.0.weight_v" not in net.state_dict()
+    assert torch.equal(net.hifigan.ups[0].folded_weight(), w)
+
+
+def test_speaker_ids_are_bit_exact(gold):
+    fx = gold.json("fx_spk.json")
+    net = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1")
+    assert net.spk == fx["spk"]                       # Python string sort order ('1000' < '101' < '99')
+    one = net.get_spk_id(torch.zeros(1, 400), fx["str_target"])
+    assert list(one.shape) == fx["shape_str"] and str(one.dtype) == fx["dtype"]
+    assert int(one.argmax()) == fx["str_onehot_argmax"] and int(one.sum()) == 1
+    many = net.get_spk_id(torch.zeros(3, 400), fx["list_target"])
+    assert many.argmax(1).tolist() == fx["list_onehot_argmax"]
+    with pytest.raises(ValueError):
+        net.get_spk_id(torch.zeros(1, 400), "unknown")
+
+
+def test_load_model_resolution_and_errors(tmp_path):
+    with pytest.raises(RuntimeError):
+        satools_amd.load_model("https://github.com/deep-privacy/SA-toolkit/releases/download/x/final.pt")
+    with pytest.raises(FileNotFoundError):
+        satools_amd.load_model(str(tmp_path / "nope" / "final.pt"))
+    state, _ = synthetic.checkpoint("bn_tdnnf_600h_vq_48_v1")
+    p = tmp_path / "bn_tdnnf_600h_vq_48_v1"
+    p.mkdir()
+    torch.save(state, p / "final.pt")
+    m = satools_amd.load_model(str(p / "final.pt"))
+    assert m.padding == 19 and m.padding_after == 4   # get_padding(chain/model.py:466-473) // 2
+    state["base_model_path"] = "local/chain/tuning/tdnnf_dp.py"
+    torch.save(state, p / "final.pt")
+    with pytest.raises(NotImplementedError):
+        satools_amd.load_model(str(p / "final.pt"))
+    conf = infer_helper.asrbn_conf_from_name("../../asr/librispeech/exp/chain/bn_tdnnf_wav2vec2_vq_48/final.pt")
+    assert conf["base_model_path"].endswith("tdnnf_wav2vec2_vq.py") and conf["base_model_args"]["codebook_size"] == 48
+
+
+def test_hub_tag_grammar(monkeypatch):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hubconf", os.path.join(ROOT, "hubconf.py"))
+    hub = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hub)
+    seen = {}
+    monkeypatch.setattr(satools_amd, "load_model", lambda f, option_args=None: seen.update(f=f, o=option_args) or "m")
+    assert hub._load("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1+f0-transformation=quant_16_awgn_2") == "m"
+    assert seen == {"f": "synthetic:hifigan_bn_tdnnf_600h_vq_48_v1", "o": {"f0_transformation": "quant_16_awgn_2"}}
+    assert f0_transforms.parse_quant_bins("quant_16_awgn_2") == 16 and f0_transforms.parse_awgn_db("quant_16_awgn_2") == 2
+
+
+def test_packing_layout_and_polyphase_equivalence():
+    cin_pad, co_pad = packing.packed_dims(504, 512)
+    assert (cin_pad, co_pad) == (512, 512)
+    assert packing.packed_dims(16, 16) == (16, 64)
+    w = torch.randn(20, 12, 3)
+    p = packing.pack_conv_weight(w)
+    assert p.shape == (1, 16, 3, 64)
+    assert torch.equal(p[0, :12, :, :20], w.permute(1, 2, 0)) and not p[0, 12:].any() and not p[0, :, :, 20:].any()
+    # ConvTranspose1d == conv with `u` output phases (the arithmetic the kernel relies on), on the CPU
+    for k, u in ((11, 5), (8, 4), (4, 2), (16, 8)):
+        x, wt = torch.randn(2, 6, 37), torch.randn(6, 5, k)
+        ref = F.conv_transpose1d(x, wt, stride=u, padding=(k - u) // 2)
+        wc, kp, pl = packing.convtranspose_as_phase_conv(wt, u, (k - u) // 2)
+        y = F.conv1d(F.pad(x, (pl, kp - 1 - pl)), wc)              # [2, 5*u, 37], row co*u + r
+        y = y.view(2, 5, u, 37).permute(0, 1, 3, 2).reshape(2, 5, 37 * u)
+        assert torch.allclose(y, ref, atol=1e-5)
+
+
+def test_yaapt_plan_matches_the_oracle_plan():
+    from oracle import yaapt as oy
+    opts = {"frame_length": 35.0, "frame_space": 20.0, "nccf_thresh1": 0.25, "tda_frame_length": 25.0}
+    for n in (8000, 16384, 77040, 80000):
+        P, Q = f0.make_plan(n, opts), oy.Plan(n, opts)
+        for a, b in (("pad", "pad"), ("L", "L"), ("nframes", "nframes"), ("nl_lo", "nl_lo"), ("nl_hi", "nl_hi"),
+                     ("wl", "wl"), ("half_wl", "half_wl"), ("min_shc", "min_shc"), ("max_shc", "max_shc"),
+                     ("pk_center", "pk_center"), ("pk_min_lag", "pk_min_lag"), ("pk_max_lag", "pk_max_lag"),
+                     ("tda_len", "tda_len"), ("tda_nframes", "tda_nframes"), ("nccf_center", "nccf_center")):
+            assert getattr(P, a) == getattr(Q, b), (n, a)
+    from oracle import biquad
+    P = f0.make_plan(8000, opts)
+    assert np.allclose(list(P.lp), [float(v) for v in biquad.kernel_constants("lp", 16000, 50.0)], rtol=0, atol=0)
+    assert np.allclose(list(P.hp), [float(v) for v in biquad.kernel_constants("hp", 16000, 1500.0)], rtol=0, atol=0)
+
+
+def test_fbank_tables_match_the_oracle():
+    from oracle import fbank as ofb
+    from satools_amd import asrbn
+    assert torch.equal(asrbn.mel_banks(80), ofb.mel_banks(80).to(torch.float32))
+    assert torch.equal(asrbn.povey_window(), ofb.povey_window())
+
+
+def test_sharding_and_all_gather_two_ranks_gloo(tmp_path):
+    """world_size 2 on the CPU (gloo): contiguous shards, fixed batches, one all-gather"""
+    script = tmp_path / "w.py"
+    script.write_text(f'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {ROOT!r})
+import satools_amd
+from satools_amd import dist as sdist
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+N = 11
+calls = []
+def conv(lo, hi):
+    calls.append((lo, hi))
+    return (torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1) * torch.ones(1, 1, 5))
+out = sdist.convert_sharded(conv, N, batch_size=4)
+assert out.shape == (N, 1, 5) and torch.equal(out[:, 0, 0], torch.arange(N, dtype=torch.float32)), out[:, 0, 0]
+exp = {{0: [(0, 4), (4, 6)], 1: [(6, 10), (10, 11)]}}[rank]
+assert calls == exp, (rank, calls)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    from satools_amd import dist as sdist
+    assert [sdist.shard_bounds(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
