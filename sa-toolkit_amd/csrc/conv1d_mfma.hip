@@ -36,9 +36,10 @@ struct ConvArgs {
   int in_lrelu, relu, accum;
   float in_slope, accum_div, res_scale;
   int res_toff, res_tstride;
+  int fast_epi;  // up == 1 and every (utterance, group) slab addressable with 31-bit byte offsets
 };
 
-template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1>
+template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1, int XWI>
 __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CO_B = 32 * MT * WM;
@@ -63,11 +64,16 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
 
   const int ks = KS > 0 ? KS : p.ksize;
   const int st = STRIDE1 ? 1 : p.stride;
-  const int XW = p.xw;
+  const int XW = XWI > 0 ? 64 * XWI : p.xw;  // LDS row pitch (columns past the tile are never read)
   const int xi0 = q_b * st - p.pad_left;
 
   const float* __restrict__ xg = p.x + (long long)b * p.x_bs + (long long)(g * p.cin_g) * p.x_cs;
-  const float* __restrict__ wg = p.w + (long long)g * p.w_gs + co_w + l31;
+  // weights of this group behind one buffer descriptor; per-lane part of the A-fragment address in
+  // ONE 32-bit VGPR (channel half lh, row l31), everything else (chunk, pair, tap, m) scalar/immediate
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.w + (long long)g * p.w_gs), 0, (unsigned)(p.w_gs * 4), 0x00020000);
+  const int w_ci_bytes = ks * p.co_pad * 4;            // bytes between input channels
+  const int a_voff = lh * w_ci_bytes + (co_w + l31) * 4;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -77,49 +83,83 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const long long w_ci_stride = (long long)ks * p.co_pad;  // elements between input channels
 
   for (int c0 = 0; c0 < p.cin_pad; c0 += CI_CHUNK) {
     __syncthreads();
     // ---- stage the input tile: 16 channels x XW columns, pre-activation fused ----
+    if constexpr (XWI > 0) {
+      // compile-time trip counts: every global load of the chunk is issued before the first LDS
+      // store, so the loads overlap each other instead of running one dependent round trip each
+      float stg[CI_CHUNK / 4][XWI];
+      const int voff = (xi0 + lane) * 4;  // byte offset inside the row; negative / past-the-end -> 0 by the range check
 #pragma unroll
-    for (int rr = 0; rr < CI_CHUNK / 4; ++rr) {
-      const int r = wave + rr * 4;
-      const int ci = c0 + r;
-      const bool cok = ci < p.cin_g;
-      const float* __restrict__ src = xg + (long long)ci * p.x_cs;
-      float* dst = lds + r * XW;
-      for (int col = lane; col < XW; col += 64) {
-        const int xi = xi0 + col;
-        float v = 0.f;
-        if (cok && xi >= 0 && xi < p.T_in) {
-          v = src[xi];
+      for (int rr = 0; rr < CI_CHUNK / 4; ++rr) {
+        const int ci = c0 + wave + rr * 4;
+        // one buffer descriptor per (utterance, channel) row: the hardware range check supplies the
+        // conv's zero padding on both sides; descriptor inputs are wave-uniform (readfirstlane, T20)
+        const unsigned long long a = (unsigned long long)(xg + (long long)ci * p.x_cs);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const unsigned nbytes = __builtin_amdgcn_readfirstlane(ci < p.cin_g ? (unsigned)p.T_in * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((unsigned long long)hi << 32) | lo), 0, nbytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < XWI; ++it)
+          stg[rr][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 256 * it, 0, 0));
+      }
+#pragma unroll
+      for (int rr = 0; rr < CI_CHUNK / 4; ++rr) {
+        float* dst = lds + (wave + rr * 4) * XW;
+#pragma unroll
+        for (int it = 0; it < XWI; ++it) {
+          const int col = lane + 64 * it;
+          float v = stg[rr][it];
           if (p.in_lrelu) v = v > 0.f ? v : v * p.in_slope;
+          dst[col] = v;
         }
-        dst[col] = v;
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < CI_CHUNK / 4; ++rr) {
+        const int r = wave + rr * 4;
+        const int ci = c0 + r;
+        const bool cok = ci < p.cin_g;
+        const float* __restrict__ src = xg + (long long)ci * p.x_cs;
+        float* dst = lds + r * XW;
+        for (int col = lane; col < XW; col += 64) {
+          const int xi = xi0 + col;
+          float v = 0.f;
+          if (cok && xi >= 0 && xi < p.T_in) {
+            v = src[xi];
+            if (p.in_lrelu) v = v > 0.f ? v : v * p.in_slope;
+          }
+          dst[col] = v;
+        }
       }
     }
     __syncthreads();
     if (!wave_active) continue;
 
-    const float* __restrict__ wc = wg + (long long)(c0 + lh) * w_ci_stride;
+    const int wc_soff = c0 * w_ci_bytes;   // scalar byte offset of this chunk's first channel
     const float* xrow = lds + lh * XW + (wn * (32 * NT) + l31) * st;
+#define SAT_LOAD_A(pair, tap, m) \
+  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32( \
+      wrsrc, a_voff + (m) * 128, wc_soff + (2 * (pair)) * w_ci_bytes + (tap) * p.co_pad * 4, 0))
 
     if constexpr (KS > 0) {
       float a_cur[KS][MT];
 #pragma unroll
       for (int t = 0; t < KS; ++t)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a_cur[t][m] = wc[(long long)t * p.co_pad + m * 32];
+        for (int m = 0; m < MT; ++m) a_cur[t][m] = SAT_LOAD_A(0, t, m);
 #pragma unroll
       for (int pr = 0; pr < CI_CHUNK / 2; ++pr) {
         float a_nxt[KS][MT];
         if (pr + 1 < CI_CHUNK / 2) {
-          const float* __restrict__ wn_ = wc + (long long)(2 * (pr + 1)) * w_ci_stride;
 #pragma unroll
           for (int t = 0; t < KS; ++t)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a_nxt[t][m] = wn_[(long long)t * p.co_pad + m * 32];
+            for (int m = 0; m < MT; ++m) a_nxt[t][m] = SAT_LOAD_A(pr + 1, t, m);
         }
         const float* xp = xrow + (2 * pr) * XW;
 #pragma unroll
@@ -140,16 +180,18 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) a_cur[t][m] = a_nxt[t][m];
         }
+        // keep the software pipeline one channel pair deep: without this fence the scheduler hoists
+        // the weight loads of all 8 unrolled pairs to the top of the chunk and spills
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       // runtime tap count (k = 2, 10, 128 ...): taps looped, one k-pair of channels at a time
 #pragma unroll 1
       for (int pr = 0; pr < CI_CHUNK / 2; ++pr) {
-        const float* __restrict__ wp = wc + (long long)(2 * pr) * w_ci_stride;
         const float* xp = xrow + (2 * pr) * XW;
         float a_nx[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a_nx[m] = wp[m * 32];
+        for (int m = 0; m < MT; ++m) a_nx[m] = SAT_LOAD_A(pr, 0, m);
 #pragma unroll 2
         for (int t = 0; t < ks; ++t) {
           float a[MT];
@@ -157,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
           for (int m = 0; m < MT; ++m) a[m] = a_nx[m];
           if (t + 1 < ks) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a_nx[m] = wp[(long long)(t + 1) * p.co_pad + m * 32];
+            for (int m = 0; m < MT; ++m) a_nx[m] = SAT_LOAD_A(pr, t + 1, m);
           }
           float bf[NT];
           const float* xt = xp + t * p.dil;
@@ -173,11 +215,80 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
     }
   }
 
+#undef SAT_LOAD_A
   if (!wave_active) return;
 
   // ---- epilogue ----
   const int up = p.up;
-  const int T_out = p.T_q * up;
+  if (p.fast_epi) {
+    // plain conv (up == 1): every row of this (utterance, group) sits behind one buffer descriptor
+    // whose range check masks rows >= rows_g; lanes past T_q get an out-of-range offset.  Loads of
+    // a 32x32 sub-tile (residual, accumulator) are issued back to back before the arithmetic, so
+    // the epilogue pays one memory round trip per sub-tile instead of one per element.
+    const unsigned OOB = 0x80000000u;
+    const long long yb = (long long)b * p.y_bs + (long long)(g * p.cout_g) * p.y_cs;
+    const __amdgpu_buffer_rsrc_t yrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + yb), 0, (unsigned)(p.rows_g * p.y_cs * 4), 0x00020000);
+    const long long rb = (long long)b * p.r_bs + (long long)(g * p.cout_g) * p.r_cs;
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.res ? p.res + rb : p.y), 0, p.res ? (unsigned)(p.rows_g * p.r_cs * 4) : 0u, 0x00020000);
+    const unsigned chn = (unsigned)(p.rows_g * 4);
+    const int chb = g * p.cout_g;
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.bias ? p.bias + chb : p.y), 0, p.bias ? chn : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t scs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.ch_scale ? p.ch_scale + chb : p.y), 0, p.ch_scale ? chn : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t shs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.ch_shift ? p.ch_shift + chb : p.y), 0, p.ch_shift ? chn : 0u, 0x00020000);
+    const int y_rb = (int)p.y_cs * 4, r_rb = (int)p.r_cs * 4;  // bytes per row
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row0 = co_w + m * 32 + 4 * lh;
+      float bi[16], sc[16], sh[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = ((r & 3) + 8 * (r >> 2)) * 4;
+        bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, row0 * 4 + ro, 0, 0));
+        if (p.ch_scale) {
+          sc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scs, row0 * 4 + ro, 0, 0));
+          sh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shs, row0 * 4 + ro, 0, 0));
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int q = q_w + n * 32 + l31;
+        const bool qok = q < p.T_q;
+        const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
+        const unsigned roff = qok ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : OOB;
+        float rv[16], yv[16];
+        if (p.res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  rrs, roff + ((r & 3) + 8 * (r >> 2)) * r_rb, 0, 0));
+        }
+        if (p.accum) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  yrs, yoff + ((r & 3) + 8 * (r >> 2)) * y_rb, 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[m][n][r] + bi[r];
+          if (p.res) v += p.res_scale * rv[r];
+          if (p.ch_scale) v = v * sc[r] + sh[r];
+          if (p.relu) v = v > 0.f ? v : 0.f;
+          if (p.accum) v = yv[r] + v;
+          if (p.accum_div != 0.f) v = v / p.accum_div;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                                yoff + ((r & 3) + 8 * (r >> 2)) * y_rb, 0, 0);
+        }
+      }
+    }
+    return;
+  }
+  // general path: polyphase rows (transposed conv) or tensors too large for 32-bit row offsets
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -217,18 +328,17 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
       }
     }
   }
-  (void)T_out;
 }
 
-template <int MT, int NT, int WM, int WN, int KS, bool S1>
+template <int MT, int NT, int WM, int WN, int KS, bool S1, int XWI>
 static int launch_cfg(const ConvArgs& a, int B, int groups, hipStream_t s) {
   constexpr int CO_B = 32 * MT * WM;
   constexpr int T_B = 32 * NT * WN;
   ConvArgs p = a;
   p.xw = (T_B - 1) * p.stride + (p.ksize - 1) * p.dil + 1;
   p.co_tiles_g = ceil_div(p.rows_g, CO_B);
-  const size_t lds_bytes = (size_t)CI_CHUNK * p.xw * sizeof(float);
-  auto kern = conv1d_mfma_kernel<MT, NT, WM, WN, KS, S1>;
+  const size_t lds_bytes = (size_t)CI_CHUNK * (XWI > 0 ? 64 * XWI : p.xw) * sizeof(float);
+  auto kern = conv1d_mfma_kernel<MT, NT, WM, WN, KS, S1, XWI>;
   if (lds_bytes > 160 * 1024) {
     set_error("conv1d: input tile of %zu bytes does not fit LDS (stride %d, ksize %d, dilation %d)",
               lds_bytes, p.stride, p.ksize, p.dil);
@@ -244,18 +354,30 @@ static int launch_cfg(const ConvArgs& a, int B, int groups, hipStream_t s) {
   return SAT_OK;
 }
 
+// batched staging needs a compile-time bound on the tile width: tile + (KS-1)*dilation columns,
+// instantiated for dilation <= 5 (every dilated layer of the generator); wider halos fall back to
+// the dynamic staging loop
+template <int MT, int NT, int WM, int WN, int KS>
+static int launch_xwi(const ConvArgs& a, int B, int groups, hipStream_t s) {
+  constexpr int T_B = 32 * NT * WN;
+  constexpr int XWI = (T_B + (KS - 1) * 5 + 63) / 64;
+  const int xw = T_B + (a.ksize - 1) * a.dil;
+  if (xw <= 64 * XWI) return launch_cfg<MT, NT, WM, WN, KS, true, XWI>(a, B, groups, s);
+  return launch_cfg<MT, NT, WM, WN, KS, true, 0>(a, B, groups, s);
+}
+
 template <int MT, int NT, int WM, int WN>
 static int launch_ks(const ConvArgs& a, int B, int groups, hipStream_t s) {
   if (a.stride == 1) {
     switch (a.ksize) {
-      case 1: return launch_cfg<MT, NT, WM, WN, 1, true>(a, B, groups, s);
-      case 3: return launch_cfg<MT, NT, WM, WN, 3, true>(a, B, groups, s);
-      case 7: return launch_cfg<MT, NT, WM, WN, 7, true>(a, B, groups, s);
-      case 11: return launch_cfg<MT, NT, WM, WN, 11, true>(a, B, groups, s);
-      default: return launch_cfg<MT, NT, WM, WN, 0, true>(a, B, groups, s);
+      case 1: return launch_xwi<MT, NT, WM, WN, 1>(a, B, groups, s);
+      case 3: return launch_xwi<MT, NT, WM, WN, 3>(a, B, groups, s);
+      case 7: return launch_xwi<MT, NT, WM, WN, 7>(a, B, groups, s);
+      case 11: return launch_xwi<MT, NT, WM, WN, 11>(a, B, groups, s);
+      default: return launch_cfg<MT, NT, WM, WN, 0, true, 0>(a, B, groups, s);
     }
   }
-  return launch_cfg<MT, NT, WM, WN, 0, false>(a, B, groups, s);
+  return launch_cfg<MT, NT, WM, WN, 0, false, 0>(a, B, groups, s);
 }
 
 }  // namespace sat
@@ -315,6 +437,11 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const fl
   a.res_scale = d->res_scale;
   a.res_toff = d->res_toff;
   a.res_tstride = d->res_tstride > 0 ? d->res_tstride : 1;
+  {
+    const long long ylim = (long long)a.rows_g * a.y_cs * 4;
+    const long long rlim = d->res ? ((long long)a.rows_g * a.r_cs + (long long)a.T_q * a.res_tstride + a.res_toff) * 4 : 0;
+    a.fast_epi = d->up == 1 && ylim < (1LL << 31) && rlim < (1LL << 31) && ylim > 0;
+  }
   hipStream_t s = (hipStream_t)stream;
   // tile shape by output rows per group: wide-in-time tiles for thin layers
   if (a.rows_g > 64) return launch_ks<2, 2, 2, 2>(a, d->B, d->groups, s);   // 128 rows x 128 positions
