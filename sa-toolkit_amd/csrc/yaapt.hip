@@ -64,67 +64,84 @@ __device__ __forceinline__ float tmin(float a, float b) { return (a != a || b !=
 
 // ------------------------------------------------------------------------------------------------
 // prefilter: zero-pad, (square), low-pass biquad -> clamp -> high-pass biquad -> clamp.
-// One wave per (utterance, signal).  The FIR halves are computed lane-parallel on 64-sample chunks;
-// the two IIR recursions are inherently sequential (y[t] depends on y[t-1], y[t-2]) and are run
-// redundantly by all lanes from LDS broadcasts, in the exact f32 order of the restated lfilter:
+// The FIR halves are lane-parallel on 64-sample chunks; the two IIR recursions are inherently
+// sequential (y[t] depends on y[t-1], y[t-2]) and keep the exact f32 order of the restated lfilter
 //   f = ((b2*x[t-2] + b1*x[t-1]) + b0*x[t]) / a0 ;  v = f - c2*y[t-2] ;  v = v - c1*y[t-1]
+// One block of two waves per (utterance, signal): wave 0 runs the low-pass on chunk i while wave 1
+// runs the high-pass on chunk i-1 (hand-off through a double-buffered LDS line), so the two
+// dependent chains overlap.  Inside a wave the 64 steps of a chunk are unrolled on wave-uniform
+// values and each lane then picks its own sample with a 6-level select tree.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) yaapt_prefilter_kernel(const float* __restrict__ wav, float* __restrict__ filt,
-                                                             const Plan P) {
-  __shared__ float s_f[64];
-  const int lane = threadIdx.x;
+__device__ __forceinline__ float iir_chunk(const float* __restrict__ f, float c1, float c2, float& y1, float& y2,
+                                           int lane) {
+  float r[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    float v = f[i] - c2 * y2;
+    v = v - c1 * y1;
+    y2 = y1;
+    y1 = v;
+    r[i] = v;
+  }
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const bool hi = (lane & w) != 0;
+#pragma unroll
+    for (int k = 0; k < w; ++k) r[k] = hi ? r[k + w] : r[k];
+  }
+  return r[0];
+}
+
+__global__ void __launch_bounds__(128) yaapt_prefilter_kernel(const float* __restrict__ wav, float* __restrict__ filt,
+                                                              const Plan P) {
+  __shared__ __attribute__((aligned(16))) float s_f[2][64];   // per-wave FIR outputs feeding the recursion
+  __shared__ __attribute__((aligned(16))) float s_u[2][64];   // clamped low-pass chunks handed to wave 1
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int b = blockIdx.x, sig = blockIdx.y;
   const float* w = wav + (size_t)b * P.n;
   float* out = filt + ((size_t)b * 2 + sig) * P.Lz;
-  const float lb0 = P.lp[0], lb1 = P.lp[1], lb2 = P.lp[2], la0 = P.lp[3], lc1 = P.lp[4], lc2 = P.lp[5];
-  const float hb0 = P.hp[0], hb1 = P.hp[1], hb2 = P.hp[2], ha0 = P.hp[3], hc1 = P.hp[4], hc2 = P.hp[5];
-  float x_m1 = 0.f, x_m2 = 0.f;   // last two inputs of the previous chunk
-  float u_m1 = 0.f, u_m2 = 0.f;   // last two clamped low-pass outputs of the previous chunk
-  float ly1 = 0.f, ly2 = 0.f, hy1 = 0.f, hy2 = 0.f;
-  for (int t0 = 0; t0 < P.L; t0 += 64) {
-    const int t = t0 + lane;
+  const float* k = wave == 0 ? P.lp : P.hp;
+  const float b0 = k[0], b1 = k[1], b2 = k[2], a0 = k[3], c1 = k[4], c2 = k[5];
+  float h1 = 0.f, h2 = 0.f;   // last two inputs of the previous chunk
+  float y1 = 0.f, y2 = 0.f;
+  const int nchunks = (P.L + 63) / 64;
+  auto load_x = [&](int c) {   // padded (and squared) input sample of chunk c for this lane
     float x = 0.f;
-    const int src = t - P.pad;
-    if (src >= 0 && src < P.n) x = w[src];
-    if (sig) x = x * x;
-    float x1 = __shfl_up(x, 1, 64), x2 = __shfl_up(x, 2, 64);
-    if (lane == 0) { x1 = x_m1; x2 = x_m2; }
-    if (lane == 1) { x2 = x_m1; }
-    x_m1 = __shfl(x, 63, 64);
-    x_m2 = __shfl(x, 62, 64);
-    s_f[lane] = ((lb2 * x2 + lb1 * x1) + lb0 * x) / la0;
-    __syncthreads();
-    float mine = 0.f;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-      float v = s_f[i] - lc2 * ly2;
-      v = v - lc1 * ly1;
-      ly2 = ly1;
-      ly1 = v;
-      mine = (lane == i) ? v : mine;
+    const int src = c * 64 + lane - P.pad;
+    if (c < nchunks && src >= 0 && src < P.n) x = w[src];
+    return sig ? x * x : x;
+  };
+  float x_next = wave == 0 ? load_x(0) : 0.f;
+  for (int it = 0; it <= nchunks; ++it) {
+    const int c = wave == 0 ? it : it - 1;        // chunk this wave works on
+    const bool live = c >= 0 && c < nchunks;
+    const int t = c * 64 + lane;
+    if (live) {
+      float x;
+      if (wave == 0) {
+        x = x_next;
+        x_next = load_x(c + 1);                   // in flight during this chunk's recursion
+      } else {
+        x = s_u[c & 1][lane];
+      }
+      float x1 = __shfl_up(x, 1, 64), x2 = __shfl_up(x, 2, 64);
+      if (lane == 0) { x1 = h1; x2 = h2; }
+      if (lane == 1) { x2 = h1; }
+      h1 = __shfl(x, 63, 64);
+      h2 = __shfl(x, 62, 64);
+      s_f[wave][lane] = ((b2 * x2 + b1 * x1) + b0 * x) / a0;
     }
     __syncthreads();
-    const float u = fminf(fmaxf(mine, -1.f), 1.f);
-    float u1 = __shfl_up(u, 1, 64), u2 = __shfl_up(u, 2, 64);
-    if (lane == 0) { u1 = u_m1; u2 = u_m2; }
-    if (lane == 1) { u2 = u_m1; }
-    u_m1 = __shfl(u, 63, 64);
-    u_m2 = __shfl(u, 62, 64);
-    s_f[lane] = ((hb2 * u2 + hb1 * u1) + hb0 * u) / ha0;
-    __syncthreads();
-    mine = 0.f;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-      float v = s_f[i] - hc2 * hy2;
-      v = v - hc1 * hy1;
-      hy2 = hy1;
-      hy1 = v;
-      mine = (lane == i) ? v : mine;
+    if (live) {
+      const float v = iir_chunk(s_f[wave], c1, c2, y1, y2, lane);
+      const float u = fminf(fmaxf(v, -1.f), 1.f);
+      if (wave == 0) s_u[c & 1][lane] = u;
+      else if (t < P.L) out[t] = u;
     }
     __syncthreads();
-    if (t < P.L) out[t] = fminf(fmaxf(mine, -1.f), 1.f);
   }
-  for (int t = P.L + lane; t < P.Lz; t += 64) out[t] = 0.f;  // zero extension read by spec_track
+  for (int t = P.L + (int)threadIdx.x; t < P.Lz; t += 128) out[t] = 0.f;  // zero extension read by spec_track
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -327,7 +344,9 @@ __global__ void __launch_bounds__(256) yaapt_spec_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// serial per-utterance helpers (lane 0 of one wave; data in LDS)
+// per-utterance helpers: ONE wave per utterance, data in LDS, all 64 lanes work (frames are spread
+// over lanes; only the Viterbi recursion itself is sequential in time, and it runs its C x C
+// transitions on C*C lanes).  Callers separate phases with __syncthreads() (a one-wave block).
 // ------------------------------------------------------------------------------------------------
 __device__ float median_small(float* v, int k) {  // k odd, <= 7: middle order statistic
   for (int i = 1; i < k; ++i) {
@@ -338,80 +357,109 @@ __device__ float median_small(float* v, int k) {  // k odd, <= 7: middle order s
   }
   return v[k / 2];
 }
-__device__ void medfilt_lds(const float* in, float* out, int n, int k) {  // zero-padded sliding median
+__device__ void medfilt_par(const float* in, float* out, int n, int k) {  // zero-padded sliding median
   const int pad = k / 2;
-  for (int i = 0; i < n; ++i) {
+  for (int i = threadIdx.x; i < n; i += 64) {
     float w[7];
-    for (int j = 0; j < k; ++j) {
+    for (int j = 0; j < 7; ++j) {
       const int s = i + j - pad;
-      w[j] = (s >= 0 && s < n) ? in[s] : 0.f;
+      w[j] = (j < k && s >= 0 && s < n) ? in[s] : 0.f;
     }
     out[i] = median_small(w, k);
   }
 }
-__device__ float mean_f(const float* v, int n) {
-  double s = 0.0;
-  for (int i = 0; i < n; ++i) s += (double)v[i];
-  return (float)(s / (double)n);   // n == 0 -> NaN like torch.mean of an empty tensor
+__device__ double wsum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
 }
-__device__ float std_unbiased_f(const float* v, int n) {
+__device__ float mean_par(const float* v, int n) {   // f64 accumulation, rounded once
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += (double)v[i];
-  const double m = s / (double)n;
+  for (int i = threadIdx.x; i < n; i += 64) s += (double)v[i];
+  return (float)(wsum_d(s) / (double)n);   // n == 0 -> NaN like torch.mean of an empty tensor
+}
+__device__ float std_unbiased_par(const float* v, int n) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += (double)v[i];
+  const double m = wsum_d(s) / (double)n;
   double q = 0.0;
-  for (int i = 0; i < n; ++i) { const double d = (double)v[i] - m; q += d * d; }
-  return (float)sqrt(q / (double)(n - 1));  // n == 1 -> NaN
+  for (int i = threadIdx.x; i < n; i += 64) { const double d = (double)v[i] - m; q += d * d; }
+  return (float)sqrt(wsum_d(q) / (double)(n - 1));  // n == 1 -> NaN
 }
 
-// path1 (yaapt.py:530-570).  local [C][T] (row stride ls), trans(i, j, t) supplied by a functor.
-// aux[i][j] = PCOST[j] + trans[i][j][t]; K[i] = LAST argmin_j; CCOST[i] = PCOST[K[i]] + trans[K[i]][i][t]
-// + local[i][t]; p_small[t] = LAST argmin_i CCOST.  Back-trace P[t] = PRED[P[t+1]][t+1].
+// path1 (yaapt.py:530-570) on one wave.  local [C][T] (row stride ls), trans(i, j, t) supplied by
+// a functor.  aux[i][j] = PCOST[j] + trans[i][j][t]; K[i] = LAST argmin_j; CCOST[i] = PCOST[K[i]] +
+// trans[K[i]][i][t] + local[i][t]; p_small = LAST argmin_i CCOST.  Back-trace P[t] = PRED[P[t+1]][t+1].
+// Lane (i*C + j) evaluates transition (i, j); lane l < C carries PCOST[l].
 template <int C, class TransFn>
-__device__ void path1(const float* local, int ls, int T, TransFn trans, unsigned char* pred, int* path_last,
-                      unsigned char* path_out) {
-  float pc[C], cc[C];
-  for (int i = 0; i < C; ++i) pc[i] = local[i * ls];
-  int psmall = 0;
+__device__ void path1_wave(const float* local, int ls, int T, TransFn trans, unsigned char* pred,
+                           unsigned char* path_out) {
+  const int lane = threadIdx.x;
+  const bool act = lane < C * C;
+  const int i = act ? lane / C : 0;
+  const int j = act ? lane % C : 0;
+  float pc = lane < C ? local[lane * ls] : 0.f;
   for (int t = 1; t < T; ++t) {
-    int K[C];
-    for (int i = 0; i < C; ++i) {
-      int best = 0;
-      float bv = pc[0] + trans(i, 0, t);
-      for (int j = 1; j < C; ++j) {
-        const float v = pc[j] + trans(i, j, t);
-        if (v <= bv) { bv = v; best = j; }   // last minimum wins
-      }
-      K[i] = best;
-      pred[(size_t)i * T + t] = (unsigned char)best;
+    const float pcj = __shfl(pc, j, 64);
+    const float v = pcj + trans(i, j, t);
+    int K = 0;
+    float bv = __shfl(v, i * C, 64);
+#pragma unroll
+    for (int jj = 1; jj < C; ++jj) {
+      const float vv = __shfl(v, i * C + jj, 64);
+      if (vv <= bv) { bv = vv; K = jj; }   // last minimum wins
     }
-    for (int i = 0; i < C; ++i) cc[i] = (pc[K[i]] + trans(K[i], i, t)) + local[i * ls + t];
-    int jb = 0;
-    float jv = cc[0];
-    for (int i = 1; i < C; ++i)
-      if (cc[i] <= jv) { jv = cc[i]; jb = i; }
-    for (int i = 0; i < C; ++i) pc[i] = cc[i];
-    psmall = jb;
+    const float pcK = __shfl(pc, K, 64);
+    const float cc = (pcK + trans(K, i, t)) + local[i * ls + t];
+    if (act && j == 0) pred[(size_t)i * T + t] = (unsigned char)K;
+    pc = __shfl(cc, (lane * C) & 63, 64);   // lane l < C <- CCOST[l] (held by lane l*C)
   }
-  // P = ones; P[-1] = p_small[-1] (0 when T == 1)
-  int p = T > 1 ? psmall : 0;
-  path_out[T - 1] = (unsigned char)p;
-  for (int t = T - 2; t >= 0; --t) {
-    p = pred[(size_t)p * T + (t + 1)];
-    path_out[t] = (unsigned char)p;
+  __syncthreads();
+  // p_small[T-1] = last argmin_i PCOST (0 when T == 1); every lane computes it from the shuffles
+  int p = 0;
+  {
+    float jv = __shfl(pc, 0, 64);
+#pragma unroll
+    for (int ii = 1; ii < C; ++ii) {
+      const float cv = __shfl(pc, ii, 64);
+      if (cv <= jv) { jv = cv; p = ii; }
+    }
+    if (T <= 1) p = 0;
   }
-  (void)path_last;
+  if (lane == 0) {
+    path_out[T - 1] = (unsigned char)p;
+    for (int t = T - 2; t >= 0; --t) {
+      p = pred[(size_t)p * T + (t + 1)];
+      path_out[t] = (unsigned char)p;
+    }
+  }
+  __syncthreads();
+}
+
+// stable compaction of the frames selected by `flag(f)` (ascending frame order): returns the count,
+// writes the selected frame indices to idx[]
+template <class Pred>
+__device__ int compact_frames(int nf, Pred flag, short* idx) {
+  int base = 0;
+  for (int f0 = 0; f0 < nf; f0 += 64) {
+    const int f = f0 + threadIdx.x;
+    const bool on = f < nf && flag(f);
+    const unsigned long long mask = __ballot(on);
+    if (on) idx[base + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (short)f;
+    base += __popcll(mask);
+  }
+  return base;
 }
 
 // spec_track after the per-frame candidates: selection, smoothing, Viterbi, interpolation.
-// One wave per utterance, lane 0 does the serial work.  LDS (floats): vcp[4*nf] vcm[4*nf] a[nf] b[nf]
-// spec[nf]; bytes: pred[4*nf] path[nf]; shorts: vidx[nf], index[nf]
+// LDS (floats): vcp[4*nf] vcm[4*nf] a[nf] b[nf] spec[nf]; shorts: vidx[nf], index[nf]; bytes pred[4*nf] path[nf]
 __global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __restrict__ cand, float* __restrict__ spec_out,
                                                             float* __restrict__ scal, int* __restrict__ status,
                                                             const Plan P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nf = P.nframes;
   const int b = blockIdx.x;
-  if (threadIdx.x != 0) return;
+  const int lane = threadIdx.x;
   float* vcp = lds;
   float* vcm = vcp + 4 * (size_t)nf;
   float* ta = vcm + 4 * (size_t)nf;
@@ -423,26 +471,25 @@ __global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __rest
   unsigned char* path = pred + 4 * (size_t)nf;
   const float* cp = cand + (size_t)b * 8 * nf;
   const float* cm = cp + 4 * (size_t)nf;
-  int nv = 0;
-  for (int f = 0; f < nf; ++f) {
-    spec[f] = cp[f];
-    if (cp[f] > 0.f) {
-      vidx[nv] = (short)f;
-      for (int c = 0; c < 4; ++c) { vcp[c * nf + nv] = cp[(size_t)c * nf + f]; vcm[c * nf + nv] = cm[(size_t)c * nf + f]; }
-      ++nv;
-    }
+  for (int f = lane; f < nf; f += 64) spec[f] = cp[f];
+  const int nv = compact_frames(nf, [&](int f) { return cp[f] > 0.f; }, vidx);
+  __syncthreads();
+  for (int i = lane; i < nv; i += 64) {
+    const int f = vidx[i];
+    for (int c = 0; c < 4; ++c) { vcp[c * nf + i] = cp[(size_t)c * nf + f]; vcm[c * nf + i] = cm[(size_t)c * nf + f]; }
   }
+  __syncthreads();
   float pitch_avg, pitch_std;
   if (nv == 0) {
     // the reference fails here (medfilt of an empty tensor, yaapt.py:257 -> :54-69); report it
-    status[b] = 1;
+    if (lane == 0) status[b] = 1;
     pitch_avg = 150.f;
     pitch_std = NAN;
   } else {
-    const float avg_v = mean_f(vcp, nv);
-    const float std_v = std_unbiased_f(vcp, nv);
+    const float avg_v = mean_par(vcp, nv);
+    const float std_v = std_unbiased_par(vcp, nv);
     const float ref = 0.8f * avg_v;
-    for (int i = 0; i < nv; ++i) {
+    for (int i = lane; i < nv; i += 64) {
       int bi = 0;
       float bv = fabsf(vcp[i] - ref) * (3.f - vcm[i]);
       for (int c = 1; c < 4; ++c) {
@@ -452,41 +499,51 @@ __global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __rest
       index[i] = (short)bi;
       ta[i] = vcp[bi * nf + i];
     }
+    __syncthreads();
     const int mk = P.median_value - 2 > 1 ? P.median_value - 2 : 1;
-    medfilt_lds(ta, tb, nv, mk);
-    for (int i = 0; i < nv; ++i) vcp[index[i] * nf + i] = tb[i];
+    medfilt_par(ta, tb, nv, mk);
+    __syncthreads();
+    for (int i = lane; i < nv; i += 64) vcp[index[i] * nf + i] = tb[i];
+    __syncthreads();
     const float k1 = (P.dp5_k1 * std_v) / avg_v;
-    float* vpitch = ta;
     if (nv > 2) {
       // dynamic5 (yaapt.py:506-523): local = 1 - merit (in place), trans = k1*(0.05*d + d*d), d = |p_j(t) - p_i(t-1)|/f0_min
-      for (int i = 0; i < 4 * nf; ++i) vcm[i] = 1.f - vcm[i];
+      for (int c = 0; c < 4; ++c)
+        for (int i = lane; i < nv; i += 64) vcm[c * nf + i] = 1.f - vcm[c * nf + i];
+      __syncthreads();
       const float f0min = P.f0_min;
       auto tr = [&](int i, int j, int t) {
         const float d = fabsf(vcp[j * nf + t] - vcp[i * nf + (t - 1)]) / f0min;
         return k1 * (0.05f * d + d * d);
       };
-      path1<4>(vcm, nf, nv, tr, pred, nullptr, path);
-      for (int t = 0; t < nv; ++t) tb[t] = vcp[path[t] * nf + t];
-      medfilt_lds(tb, ta, nv, mk);
+      path1_wave<4>(vcm, nf, nv, tr, pred, path);
+      for (int t = lane; t < nv; t += 64) tb[t] = vcp[path[t] * nf + t];
+      __syncthreads();
+      medfilt_par(tb, ta, nv, mk);
     } else {
-      for (int i = 0; i < nv; ++i) ta[i] = 150.f;
+      for (int i = lane; i < nv; i += 64) ta[i] = 150.f;
     }
-    pitch_avg = mean_f(vpitch, nv);
-    pitch_std = tmax(std_unbiased_f(vpitch, nv), pitch_avg * P.spec_pitch_min_std);
-    for (int i = 0; i < nv; ++i) spec[vidx[i]] = vpitch[i];
+    __syncthreads();
+    pitch_avg = mean_par(ta, nv);
+    pitch_std = tmax(std_unbiased_par(ta, nv), pitch_avg * P.spec_pitch_min_std);
+    for (int i = lane; i < nv; i += 64) spec[vidx[i]] = ta[i];
   }
-  if (spec[0] < pitch_avg / 2.f) spec[0] = pitch_avg;
-  if (spec[nf - 1] < pitch_avg / 2.f) spec[nf - 1] = pitch_avg;
+  __syncthreads();
+  if (lane == 0) {
+    if (spec[0] < pitch_avg / 2.f) spec[0] = pitch_avg;
+    if (spec[nf - 1] < pitch_avg / 2.f) spec[nf - 1] = pitch_avg;
+  }
+  __syncthreads();
   // F.interpolate(non-zero values, size=nf, mode='linear', align_corners=False)
-  int nz = 0;
-  for (int f = 0; f < nf; ++f)
-    if (spec[f] != 0.f) tb[nz++] = spec[f];
-  float* out = spec_out + (size_t)b * nf;
+  const int nz = compact_frames(nf, [&](int f) { return spec[f] != 0.f; }, vidx);
+  __syncthreads();
+  for (int i = lane; i < nz; i += 64) tb[i] = spec[vidx[i]];
+  __syncthreads();
   if (nz == nf) {
-    for (int f = 0; f < nf; ++f) spec[f] = tb[f];
+    for (int f = lane; f < nf; f += 64) ta[f] = tb[f];
   } else {
     const float scale = (float)nz / (float)nf;
-    for (int f = 0; f < nf; ++f) {
+    for (int f = lane; f < nf; f += 64) {
       // torch's CPU kernel contracts both expressions into fused multiply-adds (checked bit for
       // bit against F.interpolate): src = fma(scale, f + 0.5, -0.5), out = fma(l0, x0, l1*x1)
       float src = fmaf(scale, (float)f + 0.5f, -0.5f);
@@ -497,12 +554,15 @@ __global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __rest
       l1 = fminf(fmaxf(l1, 0.f), 1.f);
       const int i1 = i0 + (i0 < nz - 1 ? 1 : 0);
       const float l0 = 1.f - l1;
-      spec[f] = fmaf(l0, tb[i0], l1 * tb[i1]);
+      ta[f] = fmaf(l0, tb[i0], l1 * tb[i1]);
     }
   }
-  if (nf >= 4) { spec[0] = spec[2]; spec[1] = spec[3]; }
-  for (int f = 0; f < nf; ++f) out[f] = spec[f];
-  scal[b * 4 + 0] = pitch_std;
+  __syncthreads();
+  if (lane == 0 && nf >= 4) { ta[0] = ta[2]; ta[1] = ta[3]; }
+  __syncthreads();
+  float* out = spec_out + (size_t)b * nf;
+  for (int f = lane; f < nf; f += 64) out[f] = ta[f];
+  if (lane == 0) scal[b * 4 + 0] = pitch_std;
 }
 
 // frame means of time_track's in-place subtraction on overlapping views: frame k's first `ov`
@@ -630,33 +690,33 @@ __global__ void __launch_bounds__(256) yaapt_nccf_kernel(const float* __restrict
   }
 }
 
-// refine + dynamic + path1 -> final pitch.  One wave per utterance, lane 0.
+// refine + dynamic + path1 -> final pitch.  One wave per utterance; frames spread over lanes.
 // LDS floats: rp[6*nf] rm[6*nf] ta[nf] tb[nf]; bytes pred[6*nf] path[nf]
 __global__ void __launch_bounds__(64) yaapt_refine_dp_kernel(const float* __restrict__ tp, const float* __restrict__ tm,
                                                             const float* __restrict__ spec, const float* __restrict__ energy,
                                                             const int* __restrict__ vuv, float* __restrict__ f0,
                                                             const Plan P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if (threadIdx.x != 0) return;
+  const int lane = threadIdx.x;
   const int nf = P.nframes;
   const int b = blockIdx.x;
   float* rp = lds;
   float* rm = rp + NC * (size_t)nf;
   float* ta = rm + NC * (size_t)nf;
-  float* tb = ta + nf;
-  unsigned char* pred = (unsigned char*)(tb + nf);
+  float* en = ta + nf;
+  unsigned char* pred = (unsigned char*)(en + nf);
   unsigned char* path = pred + NC * (size_t)nf;
   const float* tp1 = tp + ((size_t)b * 2 + 0) * nf;
   const float* tp2 = tp + ((size_t)b * 2 + 1) * nf;
   const float* tm1 = tm + ((size_t)b * 2 + 0) * nf;
   const float* tm2 = tm + ((size_t)b * 2 + 1) * nf;
   const float* sp = spec + (size_t)b * nf;
-  const float* en = energy + (size_t)b * nf;
   const int* vv = vuv + (size_t)b * nf;
   const int nt = P.tda_nframes;
   // concatenate the two tracks (rows 0 and 3 carry the single NCCF candidate), order by merit
   // descending with a stable sort (torch CPU argsort keeps equal keys in index order)
-  for (int k = 0; k < nf; ++k) {
+  for (int k = lane; k < nf; k += 64) {
+    en[k] = energy[(size_t)b * nf + k];
     float p[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, m[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (k < nt) { p[0] = tp1[k]; m[0] = tm1[k]; p[3] = tp2[k]; m[3] = tm2[k]; }
     int ord[NC];
@@ -688,11 +748,17 @@ __global__ void __launch_bounds__(64) yaapt_refine_dp_kernel(const float* __rest
     }
     for (int i = 0; i < NC; ++i) { rp[i * nf + k] = p[ord[i]]; rm[i * nf + k] = ms[i]; }
   }
+  __syncthreads();
   // best_pitch = medfilt(time_pitch[0], median_value) * vuv
-  medfilt_lds(rp, ta, nf, P.median_value);
-  for (int k = 0; k < nf; ++k) ta[k] = ta[k] * (vv[k] ? 1.f : 0.f);
+  medfilt_par(rp, ta, nf, P.median_value);
+  __syncthreads();
   const float th2 = P.nlfer_thresh2;
-  for (int k = 0; k < nf; ++k) {
+  double acc = 0.0;
+  int cnt = 0;
+  for (int k = lane; k < nf; k += 64) {
+    const float best = ta[k] * (vv[k] ? 1.f : 0.f);
+    ta[k] = best;
+    if (best > 0.f) { acc += (double)best; ++cnt; }
     const float e = en[k];
     const float tp0 = rp[k];
     const bool i1 = e <= th2;
@@ -708,19 +774,18 @@ __global__ void __launch_bounds__(64) yaapt_refine_dp_kernel(const float* __rest
       rm[k] = tmin(1.f, e / 2.0f);
       for (int r = 1; r < NC; ++r) { rp[r * nf + k] = 0.f; rm[r * nf + k] = 1.0f - rm[k]; }
     }
-    const float best = ta[k];
     rp[(NC - 2) * nf + k] = best;
     if (best > 0.f) rm[(NC - 2) * nf + k] = rm[k];
     else rm[(NC - 2) * nf + k] = 1.0f - tmin(1.f, e / 2.0f);
     rp[(NC - 3) * nf + k] = sp[k];
     rm[(NC - 3) * nf + k] = e / 5.0f;
+    for (int r = 0; r < NC; ++r) rm[r * nf + k] = 1.f - rm[r * nf + k];   // local cost of dynamic()
   }
   // dynamic (yaapt.py:321-370)
-  int cnt = 0;
-  double acc = 0.0;
-  for (int k = 0; k < nf; ++k) if (ta[k] > 0.f) { acc += (double)ta[k]; ++cnt; }
+  acc = wsum_d(acc);
+  cnt = (int)wsum((float)cnt);
   const float mean_pitch = (float)(acc / (double)cnt);
-  for (int i = 0; i < NC * nf; ++i) rm[i] = 1.f - rm[i];   // local cost
+  __syncthreads();
   const float w1 = P.dp_w1, w2 = P.dp_w2, w3 = P.dp_w3, w4 = P.dp_w4;
   auto tr = [&](int i, int j, int t) {
     const float p1 = rp[j * nf + t], p2 = rp[i * nf + (t - 1)];
@@ -730,9 +795,9 @@ __global__ void __launch_bounds__(64) yaapt_refine_dp_kernel(const float* __rest
     else if (p1 == 0.f && p2 == 0.f) v = w3;
     return v / w4;
   };
-  path1<NC>(rm, nf, nf, tr, pred, nullptr, path);
+  path1_wave<NC>(rm, nf, nf, tr, pred, path);
   float* out = f0 + (size_t)b * nf;
-  for (int k = 0; k < nf; ++k) out[k] = rp[path[k] * nf + k];
+  for (int k = lane; k < nf; k += 64) out[k] = rp[path[k] * nf + k];
 }
 
 }  // namespace sat
@@ -788,7 +853,7 @@ extern "C" int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float
   const float2* tw = (const float2*)twiddle;
   SAT_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
 
-  hipLaunchKernelGGL(yaapt_prefilter_kernel, dim3(B, 2), dim3(64), 0, s, wav, filt, P);
+  hipLaunchKernelGGL(yaapt_prefilter_kernel, dim3(B, 2), dim3(128), 0, s, wav, filt, P);
   SAT_LAUNCH_CHECK("yaapt_prefilter_kernel");
   const size_t fft_lds = 2 * FFT_N * sizeof(float);
   static bool attr_set = false;
