@@ -566,25 +566,42 @@ __global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __rest
 }
 
 // frame means of time_track's in-place subtraction on overlapping views: frame k's first `ov`
-// samples already carry frame k-1's mean.  One wave per (utterance, signal); frames are sequential.
-__global__ void __launch_bounds__(64) yaapt_frame_means_kernel(const float* __restrict__ filt, float* __restrict__ fmean,
-                                                              const Plan P) {
-  const int lane = threadIdx.x;
+// samples already carry frame k-1's mean, so  mean_k = (sum_{j<ov} (x_j - mean_{k-1}) + sum_{j>=ov} x_j) / n.
+// One block per (utterance, signal): all four waves first reduce the recurrence-free tails of every
+// frame (LDS), then wave 0 walks the frames with only the `ov`-sample head on the critical path
+// (next frame's head prefetched).
+__global__ void __launch_bounds__(256) yaapt_frame_means_kernel(const float* __restrict__ filt, float* __restrict__ fmean,
+                                                               const Plan P) {
+  __shared__ float s_tail[2048];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x, sig = blockIdx.y;
   const float* x = filt + ((size_t)b * 2 + sig) * P.Lz;
   float* m = fmean + ((size_t)b * 2 + sig) * P.nframes;
   const int ov = P.tda_len - P.frame_jump;
-  float prev = 0.f;
-  for (int k = 0; k < P.tda_nframes; ++k) {
+  const int T = P.tda_nframes;
+  for (int k = wave; k < T; k += 4) {
     float part = 0.f;
-    for (int j = lane; j < P.tda_len; j += 64) {
-      float v = x[(size_t)k * P.frame_jump + j];
-      if (k > 0 && j < ov) v = v - prev;
-      part += v;
+    for (int j = ov + lane; j < P.tda_len; j += 64) part += x[(size_t)k * P.frame_jump + j];
+    part = wsum(part);
+    if (lane == 0) s_tail[k] = part;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  auto head = [&](int k, int j) { return (k < T && j < ov) ? x[(size_t)k * P.frame_jump + j] : 0.f; };
+  float h0 = head(0, lane), h1 = head(0, lane + 64);
+  float prev = 0.f;
+  for (int k = 0; k < T; ++k) {
+    const float n0 = head(k + 1, lane), n1 = head(k + 1, lane + 64);   // prefetch
+    float v0 = h0, v1 = h1;
+    if (k > 0) {
+      if (lane < ov) v0 = v0 - prev;
+      if (lane + 64 < ov) v1 = v1 - prev;
     }
-    const float mean = wsum(part) / (float)P.tda_len;
+    const float mean = (wsum(v0 + v1) + s_tail[k]) / (float)P.tda_len;
     if (lane == 0) m[k] = mean;
     prev = mean;
+    h0 = n0;
+    h1 = n1;
   }
 }
 
@@ -832,7 +849,8 @@ extern "C" int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float
                   P.pk_min_lag - 0 >= 0, "yaapt: SHC range out of the 256-bin kernel window");
   SAT_REQUIRE(P.min_shc * (P.nharm + 1) + (P.max_shc - P.min_shc) * (P.nharm + 1) + P.wl <= 5 * 256,
               "yaapt: SHC harmonics exceed the spectral kernel's magnitude window");
-  SAT_REQUIRE(P.tda_len <= 1024 && P.tda_len > P.frame_jump, "yaapt: tda_frame_length not supported");
+  SAT_REQUIRE(P.tda_len <= 1024 && P.tda_len > P.frame_jump && P.tda_len - P.frame_jump <= 128,
+              "yaapt: tda_frame_length / frame_space combination not supported");
   SAT_REQUIRE(P.median_value >= 1 && P.median_value <= 7 && (P.median_value & 1), "yaapt: median_value must be odd <= 7");
   SAT_REQUIRE(P.nframes >= 4 && P.nframes <= 2048, "yaapt: %d frames not supported (4..2048, i.e. up to ~40 s)", P.nframes);
   SAT_REQUIRE(P.tda_nframes == P.nframes, "yaapt: tda frame count differs from the analysis frame count");
@@ -873,7 +891,7 @@ extern "C" int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float
   const size_t post_lds = (size_t)nf * (4 + 4 + 3) * sizeof(float) + nf * 2 * sizeof(short) + nf * 5;
   hipLaunchKernelGGL(yaapt_spec_post_kernel, dim3(B), dim3(64), post_lds, s, cand, spec, scal, status, P);
   SAT_LAUNCH_CHECK("yaapt_spec_post_kernel");
-  hipLaunchKernelGGL(yaapt_frame_means_kernel, dim3(B, 2), dim3(64), 0, s, filt, fmean, P);
+  hipLaunchKernelGGL(yaapt_frame_means_kernel, dim3(B, 2), dim3(256), 0, s, filt, fmean, P);
   SAT_LAUNCH_CHECK("yaapt_frame_means_kernel");
   hipLaunchKernelGGL(yaapt_nccf_kernel, dim3(P.nframes, 2, B), dim3(256), 0, s, filt, fmean, spec, scal, tp, tm, status, P);
   SAT_LAUNCH_CHECK("yaapt_nccf_kernel");
