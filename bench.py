@@ -24,7 +24,10 @@ N_SAMPLES = 80000
 UTT_SECONDS = 5.0
 # algorithmic work per 5 s utterance (SURVEY §8d / DESIGN.md): generator 40.43 GMAC
 GEN_FLOP_PER_UTT = 80.86e9
+GEN_BYTES_PER_UTT = 731.4e6      # per-layer streaming model of the generator
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0    # dense f16/bf16 MFMA (MI355X_MICROARCH.md); split-f16 issues 3 MFMA products per product
+PEAK_HBM_TBS = 8.0
 
 
 def analytic_f0(seeds, frames=250):
@@ -147,6 +150,19 @@ def main():
     if rank == 0:
         total_audio = world * a.steps * BATCH * UTT_SECONDS
         achieved = GEN_FLOP_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
+        split = model.hifigan.precision == "f16x3"
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+        hbm = GEN_BYTES_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "kernel": ("conv1d_f16x3_kernel" if split else "conv1d_mfma_kernel") + " family: the 96 MFMA conv "
+                              f"launches of one generator forward (+ output stage), {gen_ms:.3f} ms per batch of {BATCH}",
+                    "arithmetic": ("f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = "
+                                   "dense f16 MFMA peak / 3" if split else "exact f32 MFMA"),
+                    "algorithmic_flop_per_launch_group": GEN_FLOP_PER_UTT * BATCH,
+                    "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "hbm_model": {"achieved_TBps": round(hbm, 3), "peak_TBps": PEAK_HBM_TBS, "frac": round(hbm / PEAK_HBM_TBS, 4),
+                                  "bytes_per_launch_group": GEN_BYTES_PER_UTT * BATCH}}
         out = {
             "metric": "anonymized audio seconds per wall-clock second (real-time factor), 5 s @ 16 kHz utterances",
             "value": round(total_audio / dt, 2),
@@ -158,17 +174,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (generator matrix products as split-f16 x3 with f32 accumulate)" if model.hifigan.precision == "f16x3" else "f32",
             "data": "synthetic",
             "config": {"workload": f"{TAG} model.convert, batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
                        "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
                        "f0": "YAAPT computed on-path on the GPU inside convert()",
                        "parallelism": f"dp{world}" + (" + RCCL all_gather of waveforms per step" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv1d_mfma_kernel family, the 96 MFMA conv launches of one generator forward "
-                                   f"(+ output stage); {gen_ms:.3f} ms per batch of {BATCH}",
-                         "algorithmic_flop_per_launch_group": GEN_FLOP_PER_UTT * BATCH},
+            "roofline": roofline,
         }
         if not a.no_cpu_baseline:
             state, _ = synthetic.checkpoint(TAG)

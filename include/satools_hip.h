@@ -65,10 +65,20 @@ int sat_device_info(char* name, int name_len, int* cu_count);
  *   w_packed[g][cin_pad][ksize][co_pad],  co fastest, cin_pad = roundup(C_in/groups, 16),
  *   co_pad = roundup(rows_per_group, 64), rows = C_out*up, zero filled.
  * ------------------------------------------------------------------------------------------ */
+/* arithmetic of the matrix products:
+ *   SAT_CONV_F32   v_mfma_f32_32x32x2_f32, exact f32 (bit-for-bit a k-ordered fma chain)
+ *   SAT_CONV_F16X3 operands split as hi + lo f16 (22 significand bits), products hi*hi + hi*lo + lo*hi
+ *                  on v_mfma_f32_32x32x16_f16 with f32 accumulation (~2^-21 relative per product);
+ *                  weights packed as w16[g][cin_pad/16][ksize][co_pad][hi16|lo16] f16; stride 1,
+ *                  ksize in {3, 7, 11}; operands must lie inside the f16 range (|x| < 65504). */
+#define SAT_CONV_F32 0
+#define SAT_CONV_F16X3 1
+
 typedef struct {
   int32_t B, C_in, T_in;       /* input  [B][C_in][T_in]  */
   int32_t C_out, T_q;          /* output [B][C_out][T_q*up]; T_q = positions per phase */
   int32_t ksize, dilation, stride, pad_left;
+  int32_t mode;                /* SAT_CONV_F32 (exact f32 MFMA) or SAT_CONV_F16X3 (split-f16, see below) */
   int32_t groups;              /* C_in and C_out divisible by groups */
   int32_t up;                  /* 1 for a plain conv */
   int32_t in_lrelu;  float in_slope;
@@ -84,7 +94,7 @@ typedef struct {
   const float* ch_shift;   /* [C_out] or NULL (-mean/sqrt(var+eps)) */
 } sat_conv1d_desc;
 
-int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const float* w_packed, float* y,
+int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
                    void* stream);
 /* cin_pad / co_pad the packed layout must use for this shape (host-side helper, no GPU needed) */
 int sat_conv1d_packed_dims(int C_in, int C_out, int up, int groups, int* cin_pad, int* co_pad);
@@ -106,7 +116,7 @@ int sat_hifigan_create(sat_hifigan** out, int in_channels, int initial_channels,
                        const int* up_rates, const int* up_kernels, int n_rb_kernels,
                        const int* rb_kernels, const int* rb_dilations /* [n_rb_kernels][3] */);
 int sat_hifigan_num_convs(const sat_hifigan* h);
-int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const float* w_packed, const float* bias);
+int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const void* w_packed, const float* bias, int mode);
 size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T);
 /* x [B][in_channels][T] -> y [B][1][T*prod(up_rates)+1]  (tanh output, archi.py:87-90) */
 int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, float* y, void* workspace,

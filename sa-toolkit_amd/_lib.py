@@ -17,13 +17,16 @@ class SatError(RuntimeError):
     pass
 
 
+CONV_F32, CONV_F16X3 = 0, 1
+
+
 class ConvDesc(C.Structure):
     """mirror of sat_conv1d_desc"""
     _fields_ = [
         ("B", C.c_int32), ("C_in", C.c_int32), ("T_in", C.c_int32),
         ("C_out", C.c_int32), ("T_q", C.c_int32),
         ("ksize", C.c_int32), ("dilation", C.c_int32), ("stride", C.c_int32), ("pad_left", C.c_int32),
-        ("groups", C.c_int32), ("up", C.c_int32),
+        ("mode", C.c_int32), ("groups", C.c_int32), ("up", C.c_int32),
         ("in_lrelu", C.c_int32), ("in_slope", C.c_float),
         ("relu", C.c_int32),
         ("accum", C.c_int32), ("accum_div", C.c_float),
@@ -45,7 +48,7 @@ _PROTOS = {
     "sat_hifigan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sat_hifigan_num_convs": (C.c_int, [C.c_void_p]),
-    "sat_hifigan_set_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "sat_hifigan_set_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "sat_hifigan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "sat_hifigan_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                           C.c_int, C.c_void_p]),

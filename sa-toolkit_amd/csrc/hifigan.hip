@@ -82,8 +82,9 @@ struct sat_hifigan {
   int in_ch = 0, c0 = 0;
   std::vector<int> up_rates, up_kernels, rb_kernels, rb_dil;
   struct Conv {
-    const float* w = nullptr;
+    const void* w = nullptr;
     const float* bias = nullptr;
+    int mode = SAT_CONV_F32;
   };
   std::vector<Conv> convs;
   int n_ups() const { return (int)up_rates.size(); }
@@ -132,10 +133,13 @@ extern "C" int sat_hifigan_create(sat_hifigan** out, int in_channels, int initia
 
 extern "C" int sat_hifigan_num_convs(const sat_hifigan* h) { return h ? (int)h->convs.size() : SAT_ERR_INVALID; }
 
-extern "C" int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const float* w_packed, const float* bias) {
+extern "C" int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const void* w_packed, const float* bias, int mode) {
   SAT_REQUIRE(h && conv_id >= 0 && conv_id < (int)h->convs.size() && w_packed && bias, "hifigan_set_conv: bad arguments");
+  SAT_REQUIRE(mode == SAT_CONV_F32 || mode == SAT_CONV_F16X3, "hifigan_set_conv: unknown mode");
+  SAT_REQUIRE(conv_id != h->id_post() || mode == SAT_CONV_F32, "hifigan_set_conv: the output stage is f32 only");
   h->convs[conv_id].w = w_packed;
   h->convs[conv_id].bias = bias;
+  h->convs[conv_id].mode = mode;
   return SAT_OK;
 }
 
@@ -215,6 +219,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
     d.ksize = 7;
     d.pad_left = 3;
     d.bias = h->convs[0].bias;
+    d.mode = h->convs[0].mode;
     int s = sat_conv1d_f32(&d, x, h->convs[0].w, X, stream);
     if (s != SAT_OK) return s;
   }
@@ -234,6 +239,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
       d.in_lrelu = 1;
       d.in_slope = 0.1f;
       d.bias = h->convs[h->id_up(i)].bias;
+      d.mode = h->convs[h->id_up(i)].mode;
       int s = sat_conv1d_f32(&d, X, h->convs[h->id_up(i)].w, H, stream);
       if (s != SAT_OK) return s;
     }
@@ -251,6 +257,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         d1.in_lrelu = 1;
         d1.in_slope = 0.1f;
         d1.bias = h->convs[h->id_rb(i, j, pair, 0)].bias;
+        d1.mode = h->convs[h->id_rb(i, j, pair, 0)].mode;
         int s = sat_conv1d_f32(&d1, r, h->convs[h->id_rb(i, j, pair, 0)].w, T1, stream);
         if (s != SAT_OK) return s;
         // x = c2(leaky_relu(xt, 0.1)) + x
@@ -261,6 +268,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         d2.in_lrelu = 1;
         d2.in_slope = 0.1f;
         d2.bias = h->convs[h->id_rb(i, j, pair, 1)].bias;
+        d2.mode = h->convs[h->id_rb(i, j, pair, 1)].mode;
         d2.res = r;
         d2.res_scale = 1.f;
         d2.res_cstride = Tn;
@@ -285,5 +293,5 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
     Tc = Tn;
   }
   // x = leaky_relu(x); reflection_pad; conv_post; tanh   (archi.py:87-90)
-  return sat_hifigan_convpost_f32(X, h->convs[h->id_post()].w, h->convs[h->id_post()].bias, y, B, C, Tc, stream);
+  return sat_hifigan_convpost_f32(X, (const float*)h->convs[h->id_post()].w, h->convs[h->id_post()].bias, y, B, C, Tc, stream);
 }

@@ -4,6 +4,7 @@ state-dict layout (params.CoreHifiGanParams); the forward runs entirely in the H
 (sat_hifigan_forward_f32).  Weight-norm is folded once (exact), weights are
 re-laid out for the MFMA conv kernel, and both are cached until parameters change."""
 import ctypes as C
+import os
 
 import torch
 
@@ -13,6 +14,10 @@ from .params import CoreHifiGanParams
 
 
 class CoreHifiGan(CoreHifiGanParams):
+    #: matrix-product arithmetic of the generator convs: "f16x3" (split-f16 on the f16 matrix cores,
+    #: ~2^-21 relative per product) or "f32" (exact f32 MFMA).  The output stage is always f32.
+    precision = os.environ.get("SATOOLS_AMD_GEN_PRECISION", "f16x3")
+
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._handle = None
@@ -22,7 +27,7 @@ class CoreHifiGan(CoreHifiGanParams):
 
     # -- device-side weight cache ---------------------------------------------------------
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        return (self.precision,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
 
     def invalidate(self):
         self._packed_key = None
@@ -54,16 +59,20 @@ class CoreHifiGan(CoreHifiGanParams):
         for i, m in enumerate(mods):
             w = m.folded_weight().to(device=device, dtype=torch.float32)
             b = m.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+            split = self.precision == "f16x3"
+            mode = _lib.CONV_F16X3 if split else _lib.CONV_F32
+            pack = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight
             if i == len(mods) - 1:
-                wp = w.reshape(w.shape[1], w.shape[2]).contiguous()  # conv_post: [C][7]
+                wp = w.reshape(w.shape[1], w.shape[2]).contiguous()  # conv_post: [C][7], f32 streaming kernel
+                mode = _lib.CONV_F32
             elif 1 <= i <= n_ups:
                 u, k = self.upsample_rates[i - 1], self.upsample_kernel_sizes[i - 1]
                 wc, _, _ = packing.convtranspose_as_phase_conv(w, u, (k - u) // 2)
-                wp = packing.pack_conv_weight(wc, up=u)
+                wp = pack(wc, up=u)
             else:
-                wp = packing.pack_conv_weight(w)
+                wp = pack(w)
             packed.append((wp, b))
-            check(l.sat_hifigan_set_conv(self._handle, i, ptr(wp), ptr(b)), "sat_hifigan_set_conv")
+            check(l.sat_hifigan_set_conv(self._handle, i, ptr(wp), ptr(b), mode), "sat_hifigan_set_conv")
         self._packed = packed  # keeps the device buffers alive
         self._packed_key = key
 

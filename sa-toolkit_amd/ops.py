@@ -16,7 +16,7 @@ def _f32c(t):
 
 def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_left=0, pad_right=None, groups=1,
            up=1, in_lrelu=None, res=None, res_scale=1.0, res_toff=0, res_tstride=1, ch_scale=None, ch_shift=None,
-           relu=False, out=None, accum=False, accum_div=0.0):
+           relu=False, out=None, accum=False, accum_div=0.0, mode=0):
     """Fused conv (see include/satools_hip.h sat_conv1d_f32).  `pad_right` defaults to the
     'same'-style value implied by pad_left for stride 1; T_q is derived like torch does:
     T_q = (T_in + pad_left + pad_right - dilation*(ksize-1) - 1)//stride + 1."""
@@ -35,6 +35,7 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
     d = ConvDesc()
     d.B, d.C_in, d.T_in, d.C_out, d.T_q = B, c_in, t_in, c_out, t_q
     d.ksize, d.dilation, d.stride, d.pad_left, d.groups, d.up = ksize, dilation, stride, pad_left, groups, up
+    d.mode = int(mode)
     d.in_lrelu = 0 if in_lrelu is None else 1
     d.in_slope = 0.0 if in_lrelu is None else float(in_lrelu)
     d.relu = int(relu)

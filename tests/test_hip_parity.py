@@ -55,6 +55,33 @@ def test_conv1d_matches_torch(case):
     assert (y.cpu() - ref).abs().max() < 3e-5
 
 
+F16X3_CASES = [(16, 16, 3, 1, 700), (16, 16, 11, 5, 1100), (32, 32, 7, 3, 600), (64, 64, 11, 1, 257), (128, 128, 3, 5, 260),
+               (256, 256, 7, 5, 125), (256, 256, 11, 3, 250), (504, 512, 7, 1, 50)]
+
+
+@pytest.mark.parametrize("case", F16X3_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv1d_split_f16_matches_torch(case):
+    """SAT_CONV_F16X3: operands carried as hi+lo f16 (22 bits), products hi*hi + hi*lo + lo*hi with f32
+    accumulation.  Bound: 2^-21 per product on top of f32 re-association -> same 3e-5 absolute bar as
+    the exact-f32 kernel on these O(1) outputs, and an RMS error within 2x of the f32 kernel's"""
+    ops, packing = _ops()
+    cin, cout, k, d, T = case
+    x = _rand(2, cin, T, seed=1)
+    w = _rand(cout, cin, k, seed=2, scale=1.0 / np.sqrt(cin * k))
+    b = _rand(cout, seed=3)
+    res = _rand(2, cout, T, seed=4)
+    pl = (k * d - d) // 2
+    ref = (F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), dilation=d, padding=pl) + res.double())
+    y16 = ops.conv1d(x.to(DEV), packing.pack_conv_weight_f16x3(w.to(DEV)), cout, k, bias=b.to(DEV), dilation=d,
+                     pad_left=pl, in_lrelu=0.1, res=res.to(DEV), mode=1)
+    y32 = ops.conv1d(x.to(DEV), packing.pack_conv_weight(w.to(DEV)), cout, k, bias=b.to(DEV), dilation=d,
+                     pad_left=pl, in_lrelu=0.1, res=res.to(DEV))
+    e16, e32 = rms(y16.cpu().double() - ref), rms(y32.cpu().double() - ref)
+    print(f"rms error vs f64: split-f16 {e16:.2e}, exact f32 {e32:.2e}")
+    assert (y16.cpu().double() - ref).abs().max() < 3e-5
+    assert e16 < 2.5 * e32 + 1e-8
+
+
 def test_conv1d_fused_prologue_epilogue():
     ops, packing = _ops()
     B, C, T, k, d = 2, 64, 333, 7, 3

@@ -9,7 +9,8 @@ from satools_amd import ops, packing
 B = 32
 SHAPES = [  # (C, T) per stage
     (256, 1250), (128, 5000), (64, 20000), (32, 40000), (16, 80000)]
-only = [int(a) for a in sys.argv[1:]] or list(range(5))
+MODE = 1 if 'f16' in sys.argv else 0
+only = [int(a) for a in sys.argv[1:] if a.isdigit()] or list(range(5))
 dev = "cuda"
 rows = []
 for si in only:
@@ -19,10 +20,10 @@ for si in only:
     out = torch.empty(B, C, T, device=dev)
     for k in (3, 7, 11):
         for d in (1, 5):
-            w = packing.pack_conv_weight(torch.randn(C, C, k, device=dev) * 0.05)
+            w = (packing.pack_conv_weight_f16x3 if MODE else packing.pack_conv_weight)(torch.randn(C, C, k, device=dev) * 0.05)
             b = torch.randn(C, device=dev)
             pl = (k * d - d) // 2
-            f = lambda: ops.conv1d(x, w, C, k, bias=b, dilation=d, pad_left=pl, in_lrelu=0.1, res=res, out=out)
+            f = lambda: ops.conv1d(x, w, C, k, bias=b, dilation=d, pad_left=pl, in_lrelu=0.1, res=res, out=out, mode=MODE)
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
