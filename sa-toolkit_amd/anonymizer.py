@@ -48,7 +48,7 @@ def build(args):
             self.utt2spk = utt2spk
             self.spk = sorted(set([v for v in utt2spk.values()]))
             self.f0: Optional[torch.Tensor] = None
-            self._defer_f0_status, self._f0_status = False, None
+            self._defer_f0_status, self._f0_status, self._f0_stream = False, None, None
             self.hifigan = CoreHifiGan(
                 imput_dim=256 + 1 + len(self.spk),
                 upsample_rates=[5, 4, 4, 2, 2],
@@ -101,11 +101,25 @@ def build(args):
             if self.f0 is not None:
                 f0, self.f0 = self.f0, None
             elif self._defer_f0_status:
-                # inside convert(): launch YAAPT without stalling the stream; its status word is
-                # checked after the generator has been enqueued
+                # inside convert(): YAAPT's kernels are latency-bound and occupy few CUs, so they run
+                # on a side stream next to the bottleneck extractor; the status word is checked after
+                # the generator has been enqueued (no stall of the launch stream)
                 from . import f0 as f0_hip
-                f0, self._f0_status = f0_hip.yaapt(self._to_device(x.detach()), self.f0_yaapt_opts, defer_status=True)
-                f0 = f0.unsqueeze(0)
+                xd = self._to_device(x.detach())
+                cur = torch.cuda.current_stream(xd.device)
+                if self._f0_stream is None:
+                    self._f0_stream = torch.cuda.Stream(device=xd.device)
+                side = self._f0_stream
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    f0, self._f0_status = f0_hip.yaapt(xd, self.f0_yaapt_opts, defer_status=True)
+                    f0 = f0.unsqueeze(0)
+                xd.record_stream(side)
+                bn = self.get_bn(x)
+                cur.wait_stream(side)
+                f0.record_stream(cur)
+                spk_id = self.get_spk_id(x, target)
+                return (f0, bn, spk_id)
             else:
                 f0 = self.get_f0(x).unsqueeze(0)
             bn = self.get_bn(x)

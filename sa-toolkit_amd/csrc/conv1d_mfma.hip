@@ -342,53 +342,56 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
 // together 22 significand bits) and a product is hi*hi + hi*lo + lo*hi on the f16 matrix cores with
 // f32 accumulation (v_mfma_f32_32x32x16_f16: 16 input channels per instruction in 32 cycles, i.e.
 // 16x the f32-MFMA rate, x3 instructions).  The dropped lo*lo term and the lo rounding are ~2^-21
-// relative per product, two orders of magnitude below the path's 1e-4 RMS parity bar and well
-// below the f32 re-association noise measured against the CPU oracle.  Used for the generator
+// relative per product, two orders of magnitude below the path's 1e-4 RMS parity bar and at the
+// level of the f32 re-association noise measured against the CPU oracle.  Used for the generator
 // (activations O(1), inside f16 range); the TDNNF/VQ path stays on the exact-f32 kernel because its
 // arg-min decisions are sensitive to 1e-6 perturbations.
-// Weights arrive pre-split: w16[g][chunk][tap][co_pad][hi16 | lo16] f16 (64 bytes per row).
-// LDS input tile: planes (hi|lo) x (channel half) x [column] of 8 f16 = 16 bytes, so a B fragment is
-// one conflict-free ds_read_b128 per lane.
+//
+// At these MFMA rates the weight fragments can no longer be streamed from L2 per wave (that alone
+// would need ~43 B/clk/CU): a block = 4 waves side by side in time over ONE 32*MT-row weight tile, and
+// per 16-channel chunk both operands are staged in LDS:
+//   W  [tap][hi|lo][channel half][row]      x 16 B (8 f16)  — a straight copy of the packed weights
+//   X  [hi|lo][channel half][column]        x 16 B          — lrelu + hi/lo split while staging
+// so every A and B fragment is one conflict-free ds_read_b128 and the main loop issues no global
+// loads.  Weights arrive packed as w16[g][chunk][tap][hi|lo][half][co_pad][8] f16.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-template <int MT, int NT, int WM, int WN, int KS, int XWI>
+template <int MT, int NT, int KS, int XWI>
 __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-  constexpr int CO_B = 32 * MT * WM;
-  constexpr int T_B = 32 * NT * WN;
+  constexpr int CO_B = 32 * MT;
+  constexpr int T_B = 128 * NT;          // 4 waves x NT x 32 positions
   constexpr int XWP = 64 * XWI;
   constexpr int NIT = (XWI + 1) / 2;
-  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int W_UNITS = KS * 4 * CO_B;  // 16-byte units of one weight chunk
+  constexpr int W_IT = (W_UNITS + 255) / 256;
+  uint4* ldsx = lds4;                     // [4][XWP]
+  uint4* ldsw = lds4 + 4 * XWP;           // [KS][2][2][CO_B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave % WM;
-  const int wn = wave / WM;
   const int l31 = lane & 31;
   const int lh = lane >> 5;
 
   const int b = blockIdx.z;
   const int g = blockIdx.y / p.co_tiles_g;
   const int cot = blockIdx.y - g * p.co_tiles_g;
-  const int co_w = cot * CO_B + wm * (32 * MT);
+  const int co_w = cot * CO_B;            // every wave of the block works on the same rows
   const int q_b = blockIdx.x * T_B;
-  const int q_w = q_b + wn * (32 * NT);
-  const bool wave_active = co_w < p.rows_g;
+  const int q_w = q_b + wave * (32 * NT);
   const int xi0 = q_b - p.pad_left;
 
-  // input slab of this (utterance, group): one descriptor, rows addressed by a scalar offset
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.x + (long long)b * p.x_bs + (long long)(g * p.cin_g) * p.x_cs), 0,
       (unsigned)((long long)p.cin_g * p.x_cs * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.w + (long long)g * p.w_gs), 0, (unsigned)p.w_gs, 0x00020000);
-  const int a_voff = (co_w + l31) * 64 + lh * 16;
-  const int w_tap_bytes = p.co_pad * 64;
   const int sh = __builtin_amdgcn_readfirstlane(wave & 1);   // channel half staged by this wave
   const int sp = __builtin_amdgcn_readfirstlane(wave >> 1);  // parity of the 64-column slices it stages
   const int x_row_bytes = (int)p.x_cs * 4;
+  const int seg_bytes = p.co_pad * 16;                        // one (tap, part, half) segment of all rows
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -401,8 +404,18 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) 
   int chunk = 0;
   for (int c0 = 0; c0 < p.cin_pad; c0 += CI_CHUNK, ++chunk) {
     __syncthreads();
-    // ---- stage 16 channels x XW columns: all loads first, then lrelu + hi/lo split + LDS stores ----
     {
+      // ---- issue every load of the chunk first: weights (copy) then the input tile ----
+      uint4 wst[W_IT];
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i) {
+        const int u = tid + 256 * i;
+        const int seg = u / CO_B, r = u % CO_B;
+        wst[i] = make_uint4(0, 0, 0, 0);
+        if (u < W_UNITS)
+          wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 wrs, (co_w + r) * 16 + seg * seg_bytes, chunk * (KS * 4) * seg_bytes, 0));
+      }
       float stg[NIT][8];
 #pragma unroll
       for (int ii = 0; ii < NIT; ++ii) {
@@ -416,6 +429,11 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) 
           if (ci < p.cin_g) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, ci * x_row_bytes, 0));
           stg[ii][j] = v;
         }
+      }
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i) {
+        const int u = tid + 256 * i;
+        if (u < W_UNITS) ldsw[u] = wst[i];
       }
 #pragma unroll
       for (int ii = 0; ii < NIT; ++ii) {
@@ -435,37 +453,24 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) 
             lo[j] = __builtin_bit_cast(unsigned, l);
           }
           const int col = lane + 64 * it;
-          lds4[(0 * 2 + sh) * XWP + col] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-          lds4[(1 * 2 + sh) * XWP + col] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+          ldsx[(0 * 2 + sh) * XWP + col] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+          ldsx[(1 * 2 + sh) * XWP + col] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
       }
     }
     __syncthreads();
-    if (!wave_active) continue;
 
-    const int w_soff = chunk * KS * w_tap_bytes;
-    const uint4* xb = lds4 + lh * XWP + wn * (32 * NT) + l31;
-#define SAT_LOAD_A16(tap, m, part) \
-  __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(wrs, a_voff + (m) * 2048 + (part) * 32, \
-                                                                w_soff + (tap) * w_tap_bytes, 0))
-    h8 a_hi[MT], a_lo[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      a_hi[m] = SAT_LOAD_A16(0, m, 0);
-      a_lo[m] = SAT_LOAD_A16(0, m, 1);
-    }
+    const uint4* xb = ldsx + lh * XWP + wave * (32 * NT) + l31;
+    const uint4* wb = ldsw + lh * CO_B + l31;
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
-      h8 n_hi[MT], n_lo[MT];
-      if (t + 1 < KS) {
+      h8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          n_hi[m] = SAT_LOAD_A16(t + 1, m, 0);
-          n_lo[m] = SAT_LOAD_A16(t + 1, m, 1);
-        }
+      for (int m = 0; m < MT; ++m) {
+        a_hi[m] = __builtin_bit_cast(h8, wb[(t * 4 + 0) * CO_B + m * 32]);
+        a_lo[m] = __builtin_bit_cast(h8, wb[(t * 4 + 2) * CO_B + m * 32]);
       }
       const uint4* xt = xb + t * p.dil;
-      h8 b_hi[NT], b_lo[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         b_hi[n] = __builtin_bit_cast(h8, xt[n * 32]);
@@ -479,24 +484,15 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) 
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[m], b_lo[n], acc[m][n], 0, 0, 0);
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[m], b_hi[n], acc[m][n], 0, 0, 0);
         }
-      if (t + 1 < KS) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          a_hi[m] = n_hi[m];
-          a_lo[m] = n_lo[m];
-        }
-      }
     }
-#undef SAT_LOAD_A16
   }
-  if (!wave_active) return;
   conv_epilogue<MT, NT>(p, acc, b, g, co_w, q_w, l31, lh);
 }
 
-template <int MT, int NT, int WM, int WN, int KS>
+template <int MT, int NT, int KS>
 static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
-  constexpr int CO_B = 32 * MT * WM;
-  constexpr int T_B = 32 * NT * WN;
+  constexpr int CO_B = 32 * MT;
+  constexpr int T_B = 128 * NT;
   constexpr int XWI = (T_B + (KS - 1) * 5 + 63) / 64;
   ConvArgs p = a;
   p.xw = T_B + (p.ksize - 1) * p.dil;
@@ -505,20 +501,22 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
     return SAT_ERR_INVALID;
   }
   p.co_tiles_g = ceil_div(p.rows_g, CO_B);
-  const size_t lds_bytes = (size_t)4 * 64 * XWI * 16;
-  auto kern = conv1d_f16x3_kernel<MT, NT, WM, WN, KS, XWI>;
+  const size_t lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * CO_B) * 16;
+  auto kern = conv1d_f16x3_kernel<MT, NT, KS, XWI>;
+  if (lds_bytes > 64 * 1024)
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   dim3 grid(ceil_div(p.T_q, T_B), p.co_tiles_g * groups, B);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
   SAT_LAUNCH_CHECK("conv1d_f16x3_kernel");
   return SAT_OK;
 }
 
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT>
 static int launch_f16x3_ks(const ConvArgs& a, int B, int groups, hipStream_t s) {
   switch (a.ksize) {
-    case 3: return launch_f16x3<MT, NT, WM, WN, 3>(a, B, groups, s);
-    case 7: return launch_f16x3<MT, NT, WM, WN, 7>(a, B, groups, s);
-    case 11: return launch_f16x3<MT, NT, WM, WN, 11>(a, B, groups, s);
+    case 3: return launch_f16x3<MT, NT, 3>(a, B, groups, s);
+    case 7: return launch_f16x3<MT, NT, 7>(a, B, groups, s);
+    case 11: return launch_f16x3<MT, NT, 11>(a, B, groups, s);
     default:
       set_error("conv1d(f16x3): kernel size %d not instantiated (3, 7, 11)", a.ksize);
       return SAT_ERR_INVALID;
@@ -642,13 +640,18 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     SAT_REQUIRE(d->stride == 1, "conv1d(f16x3): stride 1 only");
     SAT_REQUIRE((long long)a.cin_g * a.x_cs * 4 < (1LL << 31), "conv1d(f16x3): input slab too large for 31-bit offsets");
     a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;   // bytes per group
-    if (a.rows_g > 64) return launch_f16x3_ks<2, 2, 2, 2>(a, d->B, d->groups, s);
-    if (a.rows_g > 32) return launch_f16x3_ks<2, 2, 1, 4>(a, d->B, d->groups, s);
-    return launch_f16x3_ks<1, 4, 1, 4>(a, d->B, d->groups, s);
+    if (a.rows_g > 32) return launch_f16x3_ks<2, 2>(a, d->B, d->groups, s);   // 64 rows x 256 positions
+    return launch_f16x3_ks<1, 4>(a, d->B, d->groups, s);                       // 32 rows x 512 positions
   }
   SAT_REQUIRE(d->mode == SAT_CONV_F32, "conv1d: unknown mode %d", d->mode);
   // tile shape by output rows per group: wide-in-time tiles for thin layers
-  if (a.rows_g > 64) return launch_ks<2, 2, 2, 2>(a, d->B, d->groups, s);   // 128 rows x 128 positions
+  if (a.rows_g > 64) {
+    // few, long GEMM-like layers (TDNNF: 128 rows x ~530 frames per utterance, K = 3072) would
+    // launch fewer 128x128 blocks than there are CUs: cut the time tile to 32 positions instead
+    const long long blocks128 = (long long)ceil_div(a.T_q, 128) * ceil_div(a.rows_g, 128) * d->groups * d->B;
+    if (blocks128 < 2 * 256) return launch_ks<1, 1, 4, 1>(a, d->B, d->groups, s);   // 128 rows x 32 positions
+    return launch_ks<2, 2, 2, 2>(a, d->B, d->groups, s);                              // 128 rows x 128 positions
+  }
   if (a.rows_g > 32) return launch_ks<2, 2, 1, 4>(a, d->B, d->groups, s);   //  64 rows x 256 positions
   return launch_ks<1, 4, 1, 4>(a, d->B, d->groups, s);                       //  32 rows x 512 positions
 }

@@ -55,11 +55,12 @@ def convtranspose_as_phase_conv(w: torch.Tensor, stride: int, padding: int):
 
 def pack_conv_weight_f16x3(w: torch.Tensor, groups: int = 1, up: int = 1) -> torch.Tensor:
     """split-f16 packing for SAT_CONV_F16X3: w [rows, C_in/groups, K] f32 ->
-    [g][cin_pad/16][K][co_pad][2][16] f16 with [..., 0, :] = hi = f16(w) and [..., 1, :] = lo = f16(w - hi)
-    (w - hi is exact in f32, so hi + lo carries 22 significand bits of w)."""
+    [g][cin_pad/16][K][2 (hi|lo)][2 (channel half)][co_pad][8] f16, hi = f16(w), lo = f16(w - hi)
+    (w - hi is exact in f32, so hi + lo carries 22 significand bits of w).  One (chunk, tap, part, half)
+    segment holds 8 channels of every row: the kernel copies 32*MT-row pieces of it straight into LDS."""
     p = pack_conv_weight(w, groups=groups, up=up)                    # [g][cin_pad][K][co_pad] f32
     g, cin_pad, k, co_pad = p.shape
-    p = p.reshape(g, cin_pad // 16, 16, k, co_pad).permute(0, 1, 3, 4, 2).contiguous()   # [g][nch][K][co][16]
+    p = p.reshape(g, cin_pad // 16, 2, 8, k, co_pad).permute(0, 1, 4, 2, 5, 3).contiguous()   # [g][nch][K][half][co][8]
     hi = p.to(torch.float16)
     lo = (p - hi.to(torch.float32)).to(torch.float16)
-    return torch.stack([hi, lo], dim=-2).contiguous()
+    return torch.stack([hi, lo], dim=3).contiguous()                 # [g][nch][K][part][half][co][8]
