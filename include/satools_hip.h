@@ -59,6 +59,7 @@ int sat_device_info(char* name, int name_len, int* cu_count);
  *   pre(v)      = in_lrelu ? (v > 0 ? v : v*in_slope) : v ;   out-of-range x reads as 0
  *   epilogue(v) : v += bias[co]; if(res) v += res_scale*res[b,co,(q*up+r)*res_tstride+res_toff];
  *                 if(ch_scale) v = v*ch_scale[co] + ch_shift[co];  if(relu) v = max(v,0);
+ *                 if(gelu) v = 0.5*v*(1+erf(v/sqrt 2));   (res_after_act moves the residual add here)
  *                 if(accum) v = y_old + v;  if(accum_div != 0) v = v / accum_div
  *
  * Weights are pre-packed by the host (sa-toolkit_amd/packing.py) as
@@ -83,6 +84,8 @@ typedef struct {
   int32_t up;                  /* 1 for a plain conv */
   int32_t in_lrelu;  float in_slope;
   int32_t relu;
+  int32_t gelu;                /* erf GELU after the affine/ReLU steps */
+  int32_t res_after_act;       /* add the residual AFTER relu/gelu (x + gelu(conv(x)), wav2vec2 pos-conv) */
   int32_t accum;     float accum_div;
   float   res_scale; int32_t res_toff, res_tstride;
   int64_t x_bstride, x_cstride;      /* element strides of x  */
@@ -214,6 +217,26 @@ size_t sat_yaapt_workspace_bytes(const sat_yaapt_plan* plan, int B);
 int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float* f0, int32_t* status,
                   const float* hann, const float* kaiser, const float* twiddle, void* workspace,
                   size_t workspace_bytes, int B, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * wav2vec2 support (torchaudio.models.wav2vec2 as configured by tdnnf_wav2vec2_vq.py:39-56; third
+ * party to the reference, restated in oracle/wav2vec2.py).  All matrix-shaped work (conv feature
+ * extractor after layer 0, Linear layers, grouped positional conv, attention products) goes through
+ * sat_conv1d_f32; these are the remaining pieces.
+ *   sat_w2v2_conv0_f32:        y[b][c][t] = bias[c] + sum_j w[c][j] x[b][t*stride + j]
+ *   sat_layernorm_channels_f32: LayerNorm over C of x[B][C][T] (eps 1e-5), optional erf-GELU; with
+ *                              split_phases the output is [B][2C][ceil(T/2)] = even | odd time phases,
+ *                              which turns the next stride-2 conv into a stride-1 conv
+ *   sat_softmax_columns_f32:   in place on S^T [G*T keys][pitch]: softmax over keys of scale*s per query
+ *   sat_transpose_heads_f32:   v [G][D][pitch] -> vt [G][jpad][D], rows >= T zero (packed-weight layout)
+ * ------------------------------------------------------------------------------------------ */
+int sat_w2v2_conv0_f32(const float* x, const float* w, const float* bias, float* y, int B, int n, int C,
+                       int k, int stride, void* stream);
+int sat_layernorm_channels_f32(const float* x, const float* gamma, const float* beta, float* y, int B,
+                               int C, int T, int64_t x_bstride, int64_t x_cstride, int64_t y_bstride,
+                               int64_t y_cstride, int gelu, int split_phases, void* stream);
+int sat_softmax_columns_f32(float* st, int G, int T, int pitch, float scale, void* stream);
+int sat_transpose_heads_f32(const float* v, float* vt, int G, int D, int T, int pitch, int jpad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -92,3 +92,22 @@ def extract_bn_fbank(sd, wav, aux=None, hook=None):
     x = x - x.mean(dim=1).unsqueeze(1)          # UttCMVN(): mean over frames
     x = pad_input(x, 19)
     return run_stack(sd, x, FBANK_KS, FBANK_SUB, aux=aux, hook=hook)
+
+
+def extract_bn_w2v2(sd, wav, aux=None, hook=None, model=None):
+    """wav2vec2-tag bottleneck extractor (tdnnf_wav2vec2_vq.py:289-314): last transformer layer output
+    [N, 249, 1024] -> replicate-pad one frame -> pad_input(3) -> tdnn1, tdnnfs[0], VQ bottleneck of
+    tdnnfs[2].  `sd` = ASR-BN state dict (keys without 'bn_extractor.'); the wav2vec2 weights are its
+    'preprocessor.*' entries (torchaudio key names)."""
+    from . import wav2vec2 as w2
+    if model is None:
+        model = w2.Wav2Vec2Restated(24)
+        model.load_state_dict({k[len("preprocessor."):]: v for k, v in sd.items() if k.startswith("preprocessor.")})
+        model.eval()
+    with torch.no_grad():
+        x = model.extract_features(wav.detach().clone())[0][-1]
+    if hook:
+        hook("w2v2", x)
+    x = F.pad(x.transpose(2, 1), (0, 1), "replicate").transpose(2, 1).to(torch.float32)
+    x = pad_input(x, 3)
+    return run_stack(sd, x, W2V2_KS, W2V2_SUB, aux=aux, hook=hook)

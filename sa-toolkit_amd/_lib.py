@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("ksize", C.c_int32), ("dilation", C.c_int32), ("stride", C.c_int32), ("pad_left", C.c_int32),
         ("mode", C.c_int32), ("groups", C.c_int32), ("up", C.c_int32),
         ("in_lrelu", C.c_int32), ("in_slope", C.c_float),
-        ("relu", C.c_int32),
+        ("relu", C.c_int32), ("gelu", C.c_int32), ("res_after_act", C.c_int32),
         ("accum", C.c_int32), ("accum_div", C.c_float),
         ("res_scale", C.c_float), ("res_toff", C.c_int32), ("res_tstride", C.c_int32),
         ("x_bstride", C.c_int64), ("x_cstride", C.c_int64),
@@ -68,6 +68,13 @@ _PROTOS = {
     "sat_yaapt_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "sat_yaapt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "sat_w2v2_conv0_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p]),
+    "sat_layernorm_channels_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                             C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "sat_softmax_columns_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "sat_transpose_heads_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p]),
     "sat_assemble_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p]),
 }
@@ -105,13 +112,17 @@ def check(status, what=""):
         raise SatError(f"{what} failed ({status}): {msg}")
 
 
-def ptr(t):
-    """device pointer of a contiguous f32/i32 CUDA(HIP) tensor, None -> NULL"""
+def ptr(t, strided=False):
+    """device pointer of a contiguous f32/i32 CUDA(HIP) tensor, None -> NULL.  `strided` accepts a view
+    whose innermost axis is contiguous (the caller passes the strides explicitly)"""
     if t is None:
         return None
     if not t.is_cuda:
         raise SatError("HIP entry points need device tensors; got a CPU tensor (no CPU fallback)")
-    if not t.is_contiguous():
+    if strided:
+        if t.stride(-1) != 1:
+            raise SatError("HIP entry points need the innermost axis contiguous")
+    elif not t.is_contiguous():
         raise SatError("HIP entry points need contiguous tensors")
     return t.data_ptr()
 

@@ -33,7 +33,7 @@ struct ConvArgs {
   int cin_g, T_in, rows_g, cout_g, T_q;
   int ksize, dil, stride, pad_left, up;
   int cin_pad, co_pad, xw, co_tiles_g;
-  int in_lrelu, relu, accum;
+  int in_lrelu, relu, accum, gelu, res_after;
   float in_slope, accum_div, res_scale;
   int res_toff, res_tstride;
   int fast_epi;  // up == 1 and every (utterance, group) slab addressable with 31-bit byte offsets
@@ -101,9 +101,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = acc[m][n][r] + bi[r];
-          if (p.res) v += p.res_scale * rv[r];
+          if (p.res && !p.res_after) v += p.res_scale * rv[r];
           if (p.ch_scale) v = v * sc[r] + sh[r];
           if (p.relu) v = v > 0.f ? v : 0.f;
+          if (p.gelu) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+          if (p.res && p.res_after) v += p.res_scale * rv[r];
           if (p.accum) v = yv[r] + v;
           if (p.accum_div != 0.f) v = v / p.accum_div;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
@@ -144,9 +146,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         if (q >= p.T_q) continue;
         const int t = q * up + ph;
         float v = acc[m][n][r] + bias;
-        if (rrow) v += p.res_scale * rrow[(long long)t * p.res_tstride + p.res_toff];
+        if (rrow && !p.res_after) v += p.res_scale * rrow[(long long)t * p.res_tstride + p.res_toff];
         if (p.ch_scale) v = v * sc + sh;
         if (p.relu) v = v > 0.f ? v : 0.f;
+        if (p.gelu) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+        if (rrow && p.res_after) v += p.res_scale * rrow[(long long)t * p.res_tstride + p.res_toff];
         if (p.accum) v = yrow[t] + v;
         if (p.accum_div != 0.f) v = v / p.accum_div;
         yrow[t] = v;
@@ -564,6 +568,7 @@ static int launch_ks(const ConvArgs& a, int B, int groups, hipStream_t s) {
   if (a.stride == 1) {
     switch (a.ksize) {
       case 1: return launch_xwi<MT, NT, WM, WN, 1>(a, B, groups, s);
+      case 2: return launch_xwi<MT, NT, WM, WN, 2>(a, B, groups, s);
       case 3: return launch_xwi<MT, NT, WM, WN, 3>(a, B, groups, s);
       case 7: return launch_xwi<MT, NT, WM, WN, 7>(a, B, groups, s);
       case 11: return launch_xwi<MT, NT, WM, WN, 11>(a, B, groups, s);
@@ -625,6 +630,8 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
   a.in_lrelu = d->in_lrelu;
   a.in_slope = d->in_slope;
   a.relu = d->relu;
+  a.gelu = d->gelu;
+  a.res_after = d->res_after_act;
   a.accum = d->accum;
   a.accum_div = d->accum_div;
   a.res_scale = d->res_scale;

@@ -1,0 +1,153 @@
+// wav2vec2 support kernels (everything matrix-shaped runs on the fused conv1d kernel):
+// first conv layer (1 -> C, k, stride), LayerNorm over channels (+GELU, + even/odd phase split for a
+// following stride-2 conv), softmax over keys of the transposed score matrix, per-head transpose of V.
+// Reference: torchaudio.models.wav2vec2 (third-party; semantics restated in oracle/wav2vec2.py) as
+// configured by egs/asr/librispeech/local/chain/tuning/tdnnf_wav2vec2_vq.py:39-56.
+#include "common.h"
+
+namespace sat {
+
+__device__ __forceinline__ float gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// y[b][c][t] = bias[c] + sum_j w[c][j] * x[b][t*stride + j]      (C <= 512, k <= 16)
+__global__ void __launch_bounds__(256) w2v2_conv0_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int n,
+                                                        int C, int k, int stride, int T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // w [C][k], bias [C]
+  float* wl = lds;
+  float* bl = lds + C * k;
+  for (int i = threadIdx.x; i < C * k; i += 256) wl[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += 256) bl[i] = bias[i];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float xv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xv[j] = (j < k) ? x[(size_t)b * n + (size_t)t * stride + j] : 0.f;
+  float* yb = y + (size_t)b * C * T + t;
+  for (int c = 0; c < C; ++c) {
+    float acc = bl[c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < k) acc = fmaf(wl[c * k + j], xv[j], acc);
+    yb[(size_t)c * T] = acc;
+  }
+}
+
+// LayerNorm over the channel axis of x [B][C][T] (eps 1e-5, biased variance, affine), optional GELU.
+// split = 0: y [B][C][T] (row pitch y_pitch);  split = 1: y [B][2C][ceil(T/2)], y[(ph*C + c)][u] = ln(x)[c][2u + ph].
+// One thread per (utterance, frame): frames of a channel are contiguous, so every pass is coalesced.
+__global__ void __launch_bounds__(256) layernorm_ch_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          int C, int T, long long x_bs, long long x_cs, long long y_bs,
+                                                          long long y_cs, int gelu, int split) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float* xb = x + (size_t)b * x_bs + t;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += xb[(size_t)c * x_cs];
+  const float mean = s / (float)C;
+  float q = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = xb[(size_t)c * x_cs] - mean;
+    q = fmaf(d, d, q);
+  }
+  const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+  float* yb = y + (size_t)b * y_bs;
+  const int ph = split ? (t & 1) : 0;
+  const int u = split ? (t >> 1) : t;
+  for (int c = 0; c < C; ++c) {
+    float v = (xb[(size_t)c * x_cs] - mean) * rstd * gamma[c] + beta[c];
+    if (gelu) v = gelu_erf(v);
+    yb[(size_t)(ph * C + c) * y_cs + u] = v;
+  }
+  if (split && (T & 1) && t == T - 1) {
+    // odd length: the odd phase is one frame shorter; its last slot reads as zero padding
+    for (int c = 0; c < C; ++c) yb[(size_t)(C + c) * y_cs + u] = 0.f;
+  }
+}
+
+// in place: st [G*T rows (key j)][pitch] -> softmax over j of scale*s, for every (group, query column)
+__global__ void __launch_bounds__(256) softmax_cols_kernel(float* __restrict__ st, int T, int pitch, float scale) {
+  const int g = blockIdx.y;
+  const int qcol = blockIdx.x * 256 + threadIdx.x;
+  if (qcol >= T) return;
+  float* base = st + (size_t)g * T * pitch + qcol;
+  float mx = -INFINITY;
+  for (int j = 0; j < T; ++j) mx = fmaxf(mx, base[(size_t)j * pitch] * scale);
+  float sum = 0.f;
+  for (int j = 0; j < T; ++j) {
+    const float e = expf(base[(size_t)j * pitch] * scale - mx);
+    base[(size_t)j * pitch] = e;
+    sum += e;
+  }
+  const float inv = 1.0f / sum;
+  for (int j = 0; j < T; ++j) base[(size_t)j * pitch] *= inv;
+}
+
+// v [B][H*D][pitch] -> vt [B*H][jpad][D] (packed-weight layout [ci = key j][co = d]); rows j >= T are zero
+__global__ void __launch_bounds__(256) transpose_heads_kernel(const float* __restrict__ v, float* __restrict__ vt, int D,
+                                                             int T, int pitch, int jpad) {
+  __shared__ float tile[64][65];
+  const int g = blockIdx.y;           // (b, h)
+  const int j0 = blockIdx.x * 64;
+  const float* src = v + (size_t)g * D * pitch;
+  float* dst = vt + (size_t)g * jpad * D;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int d = ty; d < D; d += 4) {
+    const int j = j0 + tx;
+    tile[d][tx] = (j < T) ? src[(size_t)d * pitch + j] : 0.f;
+  }
+  __syncthreads();
+  for (int jj = ty; jj < 64; jj += 4) {
+    const int j = j0 + jj;
+    if (j < jpad && tx < D) dst[(size_t)j * D + tx] = tile[tx][jj];
+  }
+}
+
+}  // namespace sat
+
+using namespace sat;
+
+extern "C" int sat_w2v2_conv0_f32(const float* x, const float* w, const float* bias, float* y, int B, int n, int C,
+                                  int k, int stride, void* stream) {
+  SAT_REQUIRE(x && w && bias && y, "w2v2_conv0: null pointer");
+  SAT_REQUIRE(B > 0 && C > 0 && C <= 1024 && k >= 1 && k <= 16 && stride >= 1 && n >= k, "w2v2_conv0: unsupported shape");
+  const int T = (n - k) / stride + 1;
+  const size_t lds = ((size_t)C * k + C) * sizeof(float);
+  dim3 grid(ceil_div(T, 256), B);
+  hipLaunchKernelGGL(w2v2_conv0_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, n, C, k, stride, T);
+  SAT_LAUNCH_CHECK("w2v2_conv0_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_layernorm_channels_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int C,
+                                          int T, int64_t x_bstride, int64_t x_cstride, int64_t y_bstride,
+                                          int64_t y_cstride, int gelu, int split_phases, void* stream) {
+  SAT_REQUIRE(x && gamma && beta && y, "layernorm_channels: null pointer");
+  SAT_REQUIRE(B > 0 && C > 0 && T > 0, "layernorm_channels: empty shape");
+  dim3 grid(ceil_div(T, 256), B);
+  hipLaunchKernelGGL(layernorm_ch_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, C, T,
+                     (long long)x_bstride, (long long)x_cstride, (long long)y_bstride, (long long)y_cstride, gelu,
+                     split_phases);
+  SAT_LAUNCH_CHECK("layernorm_ch_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_softmax_columns_f32(float* st, int G, int T, int pitch, float scale, void* stream) {
+  SAT_REQUIRE(st && G > 0 && T > 0 && pitch >= T, "softmax_columns: bad arguments");
+  dim3 grid(ceil_div(T, 256), G);
+  hipLaunchKernelGGL(softmax_cols_kernel, grid, dim3(256), 0, (hipStream_t)stream, st, T, pitch, scale);
+  SAT_LAUNCH_CHECK("softmax_cols_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_transpose_heads_f32(const float* v, float* vt, int G, int D, int T, int pitch, int jpad, void* stream) {
+  SAT_REQUIRE(v && vt && G > 0 && D > 0 && D <= 64 && T > 0 && pitch >= T && jpad >= T, "transpose_heads: bad arguments");
+  dim3 grid(ceil_div(jpad, 64), G);
+  hipLaunchKernelGGL(transpose_heads_kernel, grid, dim3(256), 0, (hipStream_t)stream, v, vt, D, T, pitch, jpad);
+  SAT_LAUNCH_CHECK("transpose_heads_kernel");
+  return SAT_OK;
+}

@@ -14,13 +14,22 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _strided3(t):
+    """[B, C, T] tensor usable by the conv kernel: f32, innermost axis contiguous (views with a row
+    pitch are fine: the kernel takes batch / channel strides)"""
+    if t.dtype != torch.float32:
+        raise _lib.SatError(f"expected float32 tensor, got {t.dtype}")
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
 def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_left=0, pad_right=None, groups=1,
            up=1, in_lrelu=None, res=None, res_scale=1.0, res_toff=0, res_tstride=1, ch_scale=None, ch_shift=None,
-           relu=False, out=None, accum=False, accum_div=0.0, mode=0):
+           relu=False, gelu=False, post_res=None, out=None, accum=False, accum_div=0.0, mode=0, t_out=None):
     """Fused conv (see include/satools_hip.h sat_conv1d_f32).  `pad_right` defaults to the
     'same'-style value implied by pad_left for stride 1; T_q is derived like torch does:
-    T_q = (T_in + pad_left + pad_right - dilation*(ksize-1) - 1)//stride + 1."""
-    x = _f32c(x)
+    T_q = (T_in + pad_left + pad_right - dilation*(ksize-1) - 1)//stride + 1 (`t_out` caps it).
+    `post_res` is a residual added AFTER the activation (y = post_res + act(conv(x)))."""
+    x = _strided3(x)
     B, c_in, t_in = x.shape
     if pad_right is None:
         pad_right = dilation * (ksize - 1) - pad_left if up == 1 and stride == 1 else 0
@@ -28,30 +37,36 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
         t_q = t_in
     else:
         t_q = (t_in + pad_left + pad_right - dilation * (ksize - 1) - 1) // stride + 1
+    if t_out is not None:
+        t_q = min(t_q, int(t_out))
     if t_q <= 0:
         raise _lib.SatError("conv1d: input too short for this kernel")
     if out is None:
         out = torch.empty(B, c_out, t_q * up, dtype=torch.float32, device=x.device)
+    if post_res is not None:
+        assert res is None
+        res = post_res
     d = ConvDesc()
     d.B, d.C_in, d.T_in, d.C_out, d.T_q = B, c_in, t_in, c_out, t_q
     d.ksize, d.dilation, d.stride, d.pad_left, d.groups, d.up = ksize, dilation, stride, pad_left, groups, up
     d.mode = int(mode)
     d.in_lrelu = 0 if in_lrelu is None else 1
     d.in_slope = 0.0 if in_lrelu is None else float(in_lrelu)
-    d.relu = int(relu)
+    d.relu, d.gelu, d.res_after_act = int(relu), int(gelu), int(post_res is not None)
     d.accum = int(accum)
     d.accum_div = float(accum_div)
     d.res_scale, d.res_toff, d.res_tstride = float(res_scale), int(res_toff), int(res_tstride)
     d.x_bstride, d.x_cstride = x.stride(0), x.stride(1)
     d.y_bstride, d.y_cstride = out.stride(0), out.stride(1)
     if res is not None:
-        res = _f32c(res)
+        res = _strided3(res)
         d.res_bstride, d.res_cstride = res.stride(0), res.stride(1)
     d.bias = ptr(bias)
-    d.res = ptr(res)
+    d.res = ptr(res, strided=True)
     d.ch_scale = ptr(ch_scale)
     d.ch_shift = ptr(ch_shift)
-    check(lib().sat_conv1d_f32(C.byref(d), ptr(x), ptr(w_packed), ptr(out), stream()), "sat_conv1d_f32")
+    check(lib().sat_conv1d_f32(C.byref(d), ptr(x, strided=True), ptr(w_packed), ptr(out, strided=True), stream()),
+          "sat_conv1d_f32")
     return out
 
 
@@ -124,3 +139,58 @@ def assemble_input(bn, f0, spk_idx, n_spk):
     check(lib().sat_assemble_input_f32(ptr(bn), ptr(f0), ptr(spk_idx), ptr(x), B, c_bn, T, t_f0, n_spk, stream()),
           "sat_assemble_input_f32")
     return x
+
+
+# ---- wav2vec2 support -------------------------------------------------------------------------------
+def w2v2_conv0(wav, w, bias, stride=5):
+    wav = _f32c(wav)
+    B, n = wav.shape
+    c, k = w.shape
+    t = (n - k) // stride + 1
+    y = torch.empty(B, c, t, dtype=torch.float32, device=wav.device)
+    check(lib().sat_w2v2_conv0_f32(ptr(wav), ptr(w), ptr(bias), ptr(y), B, n, c, k, stride, stream()), "sat_w2v2_conv0_f32")
+    return y
+
+
+def layernorm_ch(x, gamma, beta, gelu=False, split_phases=False):
+    """LayerNorm over channels of [B, C, T]; split_phases -> [B, 2C, ceil(T/2)] (even | odd frames)"""
+    x = _strided3(x)
+    B, c, t = x.shape
+    y = torch.empty((B, 2 * c, (t + 1) // 2) if split_phases else (B, c, t), dtype=torch.float32, device=x.device)
+    check(lib().sat_layernorm_channels_f32(ptr(x, strided=True), ptr(gamma), ptr(beta), ptr(y), B, c, t, x.stride(0),
+                                           x.stride(1), y.stride(0), y.stride(1), int(gelu), int(split_phases),
+                                           stream()), "sat_layernorm_channels_f32")
+    return y
+
+
+def attention_scores(q, k, st, B, heads, hd, T):
+    """st[(b,h)*T + j][q] = sum_c k[b][h*hd + c][j] * q[b][h*hd + c][q]: a grouped 1x1 conv whose packed weights
+    ARE the [hd][pitch] head slices of k (ci = c, co = j)"""
+    pitch = k.shape[2]
+    assert k.is_contiguous() and q.is_contiguous() and hd % 16 == 0
+    assert pitch == ((T + 63) // 64) * 64, "head tensors must use row pitch round_up(T, 64) (= packed co_pad)"
+    G = B * heads
+    conv1d(q.view(1, G * hd, pitch)[:, :, :T], k, G * T, 1, groups=G, out=st.view(1, G * T, st.shape[1])[:, :, :T])
+    return st
+
+
+def softmax_cols(st, G, T, scale):
+    check(lib().sat_softmax_columns_f32(ptr(st), G, T, st.shape[1], float(scale), stream()), "sat_softmax_columns_f32")
+    return st
+
+
+def transpose_heads(v, B, heads, hd, T, jpad=None):
+    pitch = v.shape[2]
+    jpad = jpad or ((T + 15) // 16) * 16
+    assert v.is_contiguous()
+    vt = torch.empty(B * heads, jpad, hd, dtype=torch.float32, device=v.device)
+    check(lib().sat_transpose_heads_f32(ptr(v), ptr(vt), B * heads, hd, T, pitch, jpad, stream()), "sat_transpose_heads_f32")
+    return vt
+
+
+def attention_apply(st, vt, B, heads, hd, T):
+    """o[b][h*hd + c][q] = sum_j vt[(b,h)][j][c] * st[(b,h)*T + j][q]: grouped 1x1 conv, packed weights = vt"""
+    G = B * heads
+    o = torch.empty(B, heads * hd, T, dtype=torch.float32, device=st.device)
+    conv1d(st.view(1, G * T, st.shape[1])[:, :, :T], vt, G * hd, 1, groups=G, out=o.view(1, G * hd, T))
+    return o

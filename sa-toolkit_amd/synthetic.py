@@ -97,6 +97,9 @@ def fill_state_dict(sd, seed=0):
     for k in list(out):
         if k.endswith("weight_g"):
             v = out[k[:-1] + "v"]
+            if tuple(sd[k].shape[:2]) == (1, 1) and v.dim() == 3 and v.shape[0] > 1:
+                out[k] = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()    # weight_norm(dim=2): wav2vec2 positional conv
+                continue
             norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(sd[k].shape)
             out[k] = norm * _generator_gain(k, v)
     # the VQ module is registered twice in the reference; both copies hold the same tensors

@@ -1,0 +1,264 @@
+"""wav2vec2-large front end + TDNNF tail + VQ bottleneck behind the reference's
+`tdnnf_wav2vec2_vq.Net.extract_bn` (egs/asr/librispeech/local/chain/tuning/tdnnf_wav2vec2_vq.py:21-345).
+
+The wav2vec2 model itself is torchaudio's (`import_fairseq_model.py:81-113`), third-party to the
+reference and absent here: its module semantics are restated from torchaudio 2.1 (SURVEY Appendix D,
+oracle/wav2vec2.py) — parity unpinned.  Parameters keep torchaudio's state-dict key names
+(`preprocessor.feature_extractor...`, `preprocessor.encoder...`) so reference checkpoints load.
+
+Everything runs on the HIP kernels with activations channel-major [B][C][T]:
+  * conv layer 0 (1 -> 512, k 10, stride 5): dedicated streaming kernel;
+  * the six stride-2 convs: the LayerNorm+GELU kernel writes its output split into even/odd time phases
+    (2C channels, T/2 frames), which turns a stride-2 conv of k taps into a stride-1 conv of ceil(k/2) taps
+    on the fused MFMA conv kernel;
+  * every Linear = 1x1 conv on the same kernel (bias / GELU / residual in the epilogue);
+  * attention: S^T = K^T Q and O = V P as GROUPED convs, one group per (utterance, head): a [64][T]
+    head slice of Q / of V^T stored with row pitch 256 is exactly the kernel's packed-weight layout, so no
+    batched-GEMM kernel is needed; softmax over keys is a column kernel in between.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops, packing
+from .asrbn import _AsrHead, _TdnnfBase, get_padding
+from .params import WeightNormConv, _p, tdnnf_stack
+
+CONV_LAYERS = [(512, 10, 5), (512, 3, 2), (512, 3, 2), (512, 3, 2), (512, 3, 2), (512, 2, 2), (512, 2, 2)]
+
+
+class _WB(nn.Module):
+    def __init__(self, *wshape, bias=None):
+        super().__init__()
+        self.weight = _p(*wshape)
+        self.bias = _p(bias if bias is not None else wshape[0])
+
+
+class _ConvBlock(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = _WB(cout, cin, k)
+        self.layer_norm = _WB(cout)
+
+
+class _FeatureExtractor(nn.Module):
+    def __init__(self):
+        super().__init__()
+        blocks, cin = [], 1
+        for cout, k, _ in CONV_LAYERS:
+            blocks.append(_ConvBlock(cin, cout, k))
+            cin = cout
+        self.conv_layers = nn.ModuleList(blocks)
+
+
+class _FeatureProjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.layer_norm = _WB(512)
+        self.projection = _WB(1024, 512)
+
+
+class _PosConvHolder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Module()
+        self.conv.bias = _p(1024)
+        self.conv.weight_g = _p(1, 1, 128)
+        self.conv.weight_v = _p(1024, 64, 128)
+
+
+class _Attention(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.k_proj = _WB(1024, 1024)
+        self.v_proj = _WB(1024, 1024)
+        self.q_proj = _WB(1024, 1024)
+        self.out_proj = _WB(1024, 1024)
+
+
+class _FeedForward(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.intermediate_dense = _WB(4096, 1024)
+        self.output_dense = _WB(1024, 4096)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.attention = _Attention()
+        self.layer_norm = _WB(1024)
+        self.feed_forward = _FeedForward()
+        self.final_layer_norm = _WB(1024)
+
+
+class _Transformer(nn.Module):
+    def __init__(self, n_layers):
+        super().__init__()
+        self.pos_conv_embed = _PosConvHolder()
+        self.layer_norm = _WB(1024)
+        self.layers = nn.ModuleList([_EncoderLayer() for _ in range(n_layers)])
+
+
+class _Encoder(nn.Module):
+    def __init__(self, n_layers):
+        super().__init__()
+        self.feature_projection = _FeatureProjection()
+        self.transformer = _Transformer(n_layers)
+
+
+class Wav2Vec2Params(nn.Module):
+    def __init__(self, n_layers=24):
+        super().__init__()
+        self.feature_extractor = _FeatureExtractor()
+        self.encoder = _Encoder(n_layers)
+
+
+def frames_out(n):
+    for _, k, s in CONV_LAYERS:
+        n = (n - k) // s + 1
+    return n
+
+
+def _polyphase_stride2_weight(w):
+    """stride-2 conv weight [Cout, Cin, k] -> stride-1 weight over [even phase | odd phase] channels:
+    out[t] = sum_j w[j] x[2t + j] = sum_m ( w[2m] x_even[t + m] + w[2m+1] x_odd[t + m] )"""
+    cout, cin, k = w.shape
+    kp = (k + 1) // 2
+    wc = torch.zeros(cout, 2 * cin, kp, dtype=w.dtype, device=w.device)
+    for j in range(k):
+        wc[:, (j % 2) * cin:(j % 2 + 1) * cin, j // 2] = w[:, :, j]
+    return wc, kp
+
+
+class TdnnfWav2vec2VqNet(_TdnnfBase):
+    def __init__(self, output_dim, hidden_dim=1024, bottleneck_dim=128, prefinal_bottleneck_dim=256,
+                 kernel_size_list=([3, 3, 3], [1, 3, 3, 3]), subsampling_factor_list=([1, 1, 1], [1.5, 1, 1, 1]),
+                 p_dropout=0.1, codebook_size=48):
+        super().__init__()
+        self.input_dim = 1024
+        self.preprocessor = Wav2Vec2Params(24)
+        self.output_dim = output_dim
+        self.padding = get_padding(kernel_size_list[0], subsampling_factor_list[0]) // 2
+        self.padding_after = get_padding(kernel_size_list[1], subsampling_factor_list[1]) // 2
+        self.tdnn1, self.tdnnfs = tdnnf_stack(self.input_dim, hidden_dim, bottleneck_dim, prefinal_bottleneck_dim,
+                                              kernel_size_list[0], subsampling_factor_list[0], codebook_size)
+        _AsrHead.attach(self, hidden_dim, bottleneck_dim, prefinal_bottleneck_dim, kernel_size_list[1],
+                        subsampling_factor_list[1], output_dim)
+        self._init_cache()
+        self._w2 = None
+        self._w2_key = None
+
+    # ---- kernel-ready weights of the wav2vec2 part -------------------------------------------
+    def _prepare_w2v2(self, device):
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.preprocessor.parameters())
+        if self._w2_key == key:
+            return self._w2
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        pre = self.preprocessor
+        W = {"fe": []}
+        for i, blk in enumerate(pre.feature_extractor.conv_layers):
+            w = f32(blk.conv.weight)
+            ent = {"b": f32(blk.conv.bias), "g": f32(blk.layer_norm.weight), "beta": f32(blk.layer_norm.bias)}
+            if i == 0:
+                ent["w"] = w.reshape(w.shape[0], w.shape[2]).contiguous()       # [512][10]
+            else:
+                wc, kp = _polyphase_stride2_weight(w)
+                ent["w"], ent["k"] = packing.pack_conv_weight(wc), kp
+            W["fe"].append(ent)
+        fp = pre.encoder.feature_projection
+        W["fp"] = {"g": f32(fp.layer_norm.weight), "beta": f32(fp.layer_norm.bias),
+                   "w": packing.pack_conv_weight(f32(fp.projection.weight).unsqueeze(-1)), "b": f32(fp.projection.bias)}
+        tr = pre.encoder.transformer
+        pc = tr.pos_conv_embed.conv
+        wv, wg = f32(pc.weight_v), f32(pc.weight_g)
+        wpos = torch._weight_norm(wv, wg, 2)                                      # weight_norm(dim=2)
+        W["pos"] = {"w": packing.pack_conv_weight(wpos, groups=16), "b": f32(pc.bias)}
+        W["ln"] = {"g": f32(tr.layer_norm.weight), "beta": f32(tr.layer_norm.bias)}
+        W["layers"] = []
+        for lay in tr.layers:
+            at = lay.attention
+            W["layers"].append({
+                "ln1": (f32(lay.layer_norm.weight), f32(lay.layer_norm.bias)),
+                "q_w": packing.pack_conv_weight(f32(at.q_proj.weight).unsqueeze(-1)), "q_b": f32(at.q_proj.bias),
+                "k_w": packing.pack_conv_weight(f32(at.k_proj.weight).unsqueeze(-1)), "k_b": f32(at.k_proj.bias),
+                "v_w": packing.pack_conv_weight(f32(at.v_proj.weight).unsqueeze(-1)), "v_b": f32(at.v_proj.bias),
+                "o_w": packing.pack_conv_weight(f32(at.out_proj.weight).unsqueeze(-1)), "o_b": f32(at.out_proj.bias),
+                "ln2": (f32(lay.final_layer_norm.weight), f32(lay.final_layer_norm.bias)),
+                "f1_w": packing.pack_conv_weight(f32(lay.feed_forward.intermediate_dense.weight).unsqueeze(-1)),
+                "f1_b": f32(lay.feed_forward.intermediate_dense.bias),
+                "f2_w": packing.pack_conv_weight(f32(lay.feed_forward.output_dense.weight).unsqueeze(-1)),
+                "f2_b": f32(lay.feed_forward.output_dense.bias),
+            })
+        self._w2, self._w2_key = W, key
+        return W
+
+    # ---- wav2vec2 forward: [B, n] -> last layer output [B, 1024, frames] ------------------------
+    def w2v2_features(self, wav):
+        W = self._prepare_w2v2(wav.device)
+        B, n = wav.shape
+        heads, hd = 16, 64
+        # conv feature extractor
+        x = ops.w2v2_conv0(wav, W["fe"][0]["w"], W["fe"][0]["b"])                   # [B, 512, T0]
+        for i in range(7):
+            e = W["fe"][i]
+            last = i == 6
+            # LayerNorm over channels + GELU; for a following stride-2 conv the output is phase-split
+            x = ops.layernorm_ch(x, e["g"], e["beta"], gelu=True, split_phases=not last)
+            if not last:
+                nxt = W["fe"][i + 1]
+                x = ops.conv1d(x, nxt["w"], 512, nxt["k"], bias=nxt["b"], pad_left=0, pad_right=0, t_out=self._fe_len[i + 1])
+        T = x.shape[2]
+        # feature projection
+        x = ops.layernorm_ch(x, W["fp"]["g"], W["fp"]["beta"])
+        x = ops.conv1d(x, W["fp"]["w"], 1024, 1, bias=W["fp"]["b"])
+        # positional conv (grouped, k = 128, pad 64, last sample dropped) + GELU, added to x
+        x = ops.conv1d(x, W["pos"]["w"], 1024, 128, bias=W["pos"]["b"], pad_left=64, pad_right=63, groups=16,
+                       gelu=True, post_res=x)
+        x = ops.layernorm_ch(x, W["ln"]["g"], W["ln"]["beta"])
+        G = B * heads
+        tp = ((T + 63) // 64) * 64   # row pitch of the per-head tensors = the packed-weight co_pad for T rows
+        for L in W["layers"]:
+            h = ops.layernorm_ch(x, *L["ln1"])
+            q = torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device)
+            k = torch.empty_like(q)
+            v = torch.empty_like(q)
+            ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], out=q[:, :, :T])
+            ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], out=k[:, :, :T])
+            ops.conv1d(h, L["v_w"], 1024, 1, bias=L["v_b"], out=v[:, :, :T])
+            # S^T[j][q] = sum_c K[c][j] Q[c][q]  per (utterance, head): K as packed weights, Q as input
+            st = torch.empty(G * T, tp, dtype=torch.float32, device=x.device)
+            ops.attention_scores(q, k, st, B, heads, hd, T)
+            ops.softmax_cols(st, G, T, scale=hd ** -0.5)
+            vt = ops.transpose_heads(v, B, heads, hd, T)                           # [G][jpad][64]
+            o = ops.attention_apply(st, vt, B, heads, hd, T)                        # [B, 1024, T]
+            x = ops.conv1d(o, L["o_w"], 1024, 1, bias=L["o_b"], res=x)
+            h = ops.layernorm_ch(x, *L["ln2"])
+            h = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True)
+            x = ops.conv1d(h, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x)
+        return x
+
+    def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
+        """inputs [N, n] in [-1, 1] (no 32768 scaling on this tag) -> [N, T, 256]
+        (tdnnf_wav2vec2_vq.py:289-314)"""
+        if not x.is_cuda:
+            raise _lib.SatError("extract_bn runs on the HIP device only (no CPU fallback); move the input to 'cuda'")
+        if x.dim() != 2:
+            raise _lib.SatError("extract_bn expects a 2-dimensional tensor [N, samples]")
+        n = x.shape[1]
+        lens, t = [], n
+        for _, k, s in CONV_LAYERS:
+            t = (t - k) // s + 1
+            lens.append(t)
+        if t < 1:
+            raise _lib.SatError("input too short for the wav2vec2 feature extractor")
+        self._fe_len = lens
+        feats = self.w2v2_features(x.to(torch.float32).contiguous())                # [N, 1024, 249]
+        feats = ops.pad_replicate(feats, 0, 1)                                      # F.pad(.., (0, 1), "replicate")
+        feats = ops.pad_replicate(feats, self.padding, self.padding, interleave_right=True)   # pad_input
+        out = self._run_stack(feats, want_aux=want_aux)
+        if want_aux:
+            return out[0].permute(0, 2, 1), out[1]
+        return out.permute(0, 2, 1)
+
+    def forward(self, x):
+        raise NotImplementedError("the ASR output head is outside the anonymization hot path (SURVEY §8 f4)")

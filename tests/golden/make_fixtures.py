@@ -282,6 +282,49 @@ def main():
             out["harm01_16000_quant16_awgn2_seed1234"] = net2.convert(w, target=[spk[3], spk[10]]).numpy()
         np.savez_compressed(os.path.join(GOLD, "fx_e2e.npz"), **out)
         json.dump(shapes, open(os.path.join(GOLD, "fx_shapes.json"), "w"))
+    if want("w2v2"):
+        # wav2vec2 tag: the reference's own tdnnf_wav2vec2_vq.Net / hifigan Net with the torchaudio stand-in's
+        # wav2vec2 factory (= oracle/wav2vec2.py).  Pins the plumbing around the third-party model
+        # (extract_features(x)[0][-1], replicate pad, pad_input(3), TDNNF tail, VQ), not torchaudio's arithmetic.
+        import torchaudio
+        from oracle import wav2vec2 as ow
+        torchaudio.models.wav2vec2.model._factory = ow.build_wav2vec2
+        name2 = "bn_tdnnf_wav2vec2_vq_48"
+        tag2 = "hifigan_" + name2 + "_v1"
+        net2 = build_reference_model(ref, name2)
+        st2, mine2 = synthetic.checkpoint(tag2, conditioning=None)
+        res = net2.load_state_dict(st2["base_model_state_dict"], strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert list(net2.state_dict()) == list(mine2.state_dict())
+        net2.eval()
+        json.dump([[k, list(v.shape), str(v.dtype)] for k, v in net2.state_dict().items()],
+                  open(os.path.join(GOLD, "state_dict_keys_w2v2.json"), "w"))
+        calib = torch.cat([synthetic.harm_batch(range(100, 104), 32000), synthetic.rand_batch(5, 1, 32000) * 2 - 1], 0)
+        calibrate(net2, name2, calib, vq_layer=2)
+        st2, _ = synthetic.checkpoint(tag2)
+        net2.load_state_dict(st2["base_model_state_dict"], strict=True)
+        net2.eval()
+        out = {}
+        acts = {}
+        h = net2.bn_extractor.tdnnfs[2].bottleneck_func.quant.register_forward_hook(
+            lambda m, i, o: acts.update(idx=o[5].detach(), dist=o[4].detach()))
+        with torch.no_grad():
+            w = synthetic.harm_batch([0, 1], 16000)
+            bn = net2.get_bn(w)
+            out["harm01_16000/bn"] = bn.numpy()
+            out["harm01_16000/idx"] = acts["idx"].reshape(2, -1).numpy()
+            srt = acts["dist"].sort(1)[0]
+            out["harm01_16000/margin"] = (srt[:, 1] - srt[:, 0]).reshape(2, -1).numpy()
+            feats = net2.bn_extractor.preprocessor.extract_features(w)[0][-1]
+            out["harm01_16000/w2v2_last_sub"] = feats[:, :, ::16].numpy()
+            out["harm0_16000/convert"] = net2.convert(synthetic.harm_batch([0], 16000), target=net2.spk[3]).numpy()
+            shapes2 = {}
+            for n in (16000, 32000, 80000):
+                ww = synthetic.harm_batch([2], n)
+                shapes2[str(n)] = [list(net2.get_bn(ww).shape), list(net2.get_f0(ww).shape)]
+        h.remove()
+        np.savez_compressed(os.path.join(GOLD, "fx_w2v2.npz"), **out)
+        json.dump(shapes2, open(os.path.join(GOLD, "fx_shapes_w2v2.json"), "w"))
     print("fixtures written to", GOLD)
 
 

@@ -1,0 +1,132 @@
+"""wav2vec2 tag on the HIP path: support kernels against torch, extract_bn / convert against the
+reference-generated fixtures.  Needs a real MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rms
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def test_conv0_and_layernorm_phase_split():
+    from satools_amd import ops
+    x = _rand(2, 4005, seed=1, scale=0.3)
+    w, b = _rand(512, 1, 10, seed=2, scale=0.3), _rand(512, seed=3, scale=0.1)
+    g, beta = 1 + _rand(512, seed=4, scale=0.1), _rand(512, seed=5, scale=0.1)
+    ref = F.conv1d(x.unsqueeze(1), w, b, stride=5)
+    y = ops.w2v2_conv0(x.to(DEV), w.reshape(512, 10).contiguous().to(DEV), b.to(DEV))
+    assert y.shape == ref.shape and (y.cpu() - ref).abs().max() < 1e-5
+    ln = F.gelu(F.layer_norm(ref.transpose(1, 2), (512,), g, beta)).transpose(1, 2)
+    z = ops.layernorm_ch(y, g.to(DEV), beta.to(DEV), gelu=True)
+    assert (z.cpu() - ln).abs().max() < 2e-5
+    zs = ops.layernorm_ch(y, g.to(DEV), beta.to(DEV), gelu=True, split_phases=True).cpu()
+    T = ln.shape[2]
+    assert zs.shape == (2, 1024, (T + 1) // 2)
+    assert (zs[:, :512, :] - ln[:, :, 0::2]).abs().max() < 2e-5
+    assert (zs[:, 512:, :T // 2] - ln[:, :, 1::2]).abs().max() < 2e-5
+    if T % 2:
+        assert not zs[:, 512:, -1].any()
+
+
+@pytest.mark.parametrize("k", [3, 2])
+def test_stride2_conv_as_polyphase(k):
+    from satools_amd import ops, packing
+    from satools_amd.wav2vec2 import _polyphase_stride2_weight
+    for T in (801, 800):
+        x, w, b = _rand(2, 64, T, seed=1), _rand(96, 64, k, seed=2, scale=0.1), _rand(96, seed=3)
+        ref = F.conv1d(x, w, b, stride=2)
+        g, beta = torch.ones(64), torch.zeros(64)
+        xs = torch.zeros(2, 128, (T + 1) // 2)
+        xs[:, :64] = x[:, :, 0::2]
+        xs[:, 64:, :T // 2] = x[:, :, 1::2]
+        wc, kp = _polyphase_stride2_weight(w)
+        y = ops.conv1d(xs.to(DEV), packing.pack_conv_weight(wc.to(DEV)), 96, kp, bias=b.to(DEV), pad_left=0, pad_right=0,
+                       t_out=ref.shape[2])
+        assert y.shape == ref.shape and (y.cpu() - ref).abs().max() < 3e-5
+
+
+def test_attention_as_grouped_convs():
+    from satools_amd import ops
+    B, H, D, T, P = 2, 4, 64, 249, 256
+    q, k, v = (_rand(B, H * D, T, seed=s) for s in (1, 2, 3))
+    pad = lambda t: F.pad(t, (0, P - T)).contiguous().to(DEV)
+    sh = lambda t: t.view(B, H, D, T)
+    s = torch.einsum("bhcq,bhcj->bhqj", sh(q), sh(k)) * D ** -0.5
+    ref = torch.einsum("bhqj,bhcj->bhcq", torch.softmax(s, -1), sh(v)).reshape(B, H * D, T)
+    st = torch.empty(B * H * T, P, device=DEV)
+    ops.attention_scores(pad(q), pad(k), st, B, H, D, T)
+    ops.softmax_cols(st, B * H, T, scale=D ** -0.5)
+    vt = ops.transpose_heads(pad(v), B, H, D, T)
+    o = ops.attention_apply(st, vt, B, H, D, T)
+    assert o.shape == ref.shape and (o.cpu() - ref).abs().max() < 2e-5
+
+
+def test_gelu_and_post_residual_epilogue():
+    from satools_amd import ops, packing
+    x, w, b = _rand(2, 64, 100, seed=1), _rand(64, 4, 128, seed=2, scale=0.05), _rand(64, seed=3)
+    ref = x + F.gelu(F.conv1d(x, w, b, padding=64, groups=16)[..., :-1])
+    y = ops.conv1d(x.to(DEV), packing.pack_conv_weight(w.to(DEV), groups=16), 64, 128, bias=b.to(DEV), pad_left=64,
+                   pad_right=63, groups=16, gelu=True, post_res=x.to(DEV))
+    assert y.shape == ref.shape and (y.cpu() - ref).abs().max() < 3e-5
+
+
+@pytest.fixture(scope="module")
+def model():
+    import satools_amd
+    m = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_wav2vec2_vq_48_v1")
+    m.to(DEV)
+    m.eval()
+    return m
+
+
+def test_extract_bn_matches_reference_fixture(model, gold):
+    from satools_amd import synthetic
+    fx = gold.npz("fx_w2v2.npz")
+    wav = synthetic.harm_batch([0, 1], 16000)
+    feats = model.bn_extractor
+    feats._fe_len = []
+    bn, (z, idx, dist) = model.bn_extractor.extract_bn(wav.clone().to(DEV), want_aux=True)
+    assert bn.shape == (2, 50, 256)
+    margin = torch.from_numpy(fx["harm01_16000/margin"])
+    agree = idx.cpu().long() == torch.from_numpy(fx["harm01_16000/idx"]).long()
+    print("wav2vec2-tag VQ index agreement with the reference run:", agree.float().mean().item())
+    assert agree[margin > 5e-3].all() and agree.float().mean() > 0.97
+    ref = torch.from_numpy(fx["harm01_16000/bn"]).permute(0, 2, 1)
+    assert (bn.cpu() - ref)[agree].abs().max() < 5e-4
+    out = model.get_bn(wav.to(DEV))
+    assert out.shape == (2, 256, 50)
+
+
+def test_w2v2_last_layer_matches_oracle(model, gold):
+    from satools_amd import synthetic
+    fx = gold.npz("fx_w2v2.npz")
+    wav = synthetic.harm_batch([0, 1], 16000).to(DEV)
+    ext = model.bn_extractor
+    lens, t = [], 16000
+    from satools_amd.wav2vec2 import CONV_LAYERS
+    for _, k, s in CONV_LAYERS:
+        t = (t - k) // s + 1
+        lens.append(t)
+    ext._fe_len = lens
+    y = ext.w2v2_features(wav).cpu()                      # [2, 1024, 49]
+    ref = torch.from_numpy(fx["harm01_16000/w2v2_last_sub"])   # [2, 49, 64] (every 16th channel)
+    err = (y.permute(0, 2, 1)[:, :, ::16] - ref).abs().max().item()
+    print("wav2vec2 last-layer max abs error vs the restated CPU model:", err, "(values up to", ref.abs().max().item(), ")")
+    assert err < 2e-3
+
+
+def test_convert_w2v2_tag_matches_fixture(model, gold):
+    from satools_amd import synthetic
+    fx = gold.npz("fx_w2v2.npz")
+    y = model.convert(synthetic.harm_batch([0], 16000).to(DEV), target=model.spk[3])
+    assert y.shape == fx["harm0_16000/convert"].shape == (1, 16001)
+    err = rms(y.cpu().numpy() - fx["harm0_16000/convert"])
+    print("wav2vec2-tag convert RMS error vs reference run:", err)
+    assert err < 1e-4
