@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tag", default=TAG, help="model tag (default: the headline config; the wav2vec2 tag is BASELINE configs[2])")
+    ap.add_argument("--f0-transformation", default="", help="e.g. quant_16_awgn_2 (BASELINE configs[3])")
     a = ap.parse_args()
 
     import torch
@@ -93,7 +95,8 @@ def main():
     import satools_amd
     from satools_amd import synthetic
 
-    model = satools_amd.load_model("synthetic:" + TAG)
+    tag = a.tag
+    model = satools_amd.load_model("synthetic:" + tag, option_args={"f0_transformation": a.f0_transformation} if a.f0_transformation else None)
     model.to(dev)
     model.eval()
     seeds = [rank * BATCH + i for i in range(BATCH)]
@@ -176,13 +179,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (generator matrix products as split-f16 x3 with f32 accumulate)" if model.hifigan.precision == "f16x3" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"{TAG} model.convert, batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
+            "config": {"workload": f"{tag}{'+f0-transformation=' + a.f0_transformation if a.f0_transformation else ''} model.convert, batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
                        "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
                        "f0": "YAAPT computed on-path on the GPU inside convert()",
                        "parallelism": f"dp{world}" + (" + RCCL all_gather of waveforms per step" if world > 1 else "")},
             "roofline": roofline,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and tag == TAG:
             state, _ = synthetic.checkpoint(TAG)
             sample = list(range(4))
             out["cpu_baseline"] = cpu_baseline(state, model.spk, sample)

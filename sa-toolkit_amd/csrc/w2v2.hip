@@ -37,54 +37,105 @@ __global__ void __launch_bounds__(256) w2v2_conv0_kernel(const float* __restrict
 
 // LayerNorm over the channel axis of x [B][C][T] (eps 1e-5, biased variance, affine), optional GELU.
 // split = 0: y [B][C][T] (row pitch y_pitch);  split = 1: y [B][2C][ceil(T/2)], y[(ph*C + c)][u] = ln(x)[c][2u + ph].
-// One thread per (utterance, frame): frames of a channel are contiguous, so every pass is coalesced.
-__global__ void __launch_bounds__(256) layernorm_ch_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ y,
-                                                          int C, int T, long long x_bs, long long x_cs, long long y_bs,
-                                                          long long y_cs, int gelu, int split) {
+// A block owns 64 consecutive frames of one utterance; its 16 waves each reduce a 1/16 slice of the
+// channels (frames of a channel are contiguous, so every access is a coalesced 256-B row piece) and the
+// partial sums meet in LDS.  Two-pass mean / variance like torch's CPU kernel.
+constexpr int LN_SLICES = 16;
+__global__ void __launch_bounds__(64 * LN_SLICES) layernorm_ch_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+    int C, int T, long long x_bs, long long x_cs, long long y_bs, long long y_cs, int gelu, int split) {
+  __shared__ float part[LN_SLICES][64];
+  __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
-  const float* xb = x + (size_t)b * x_bs + t;
+  const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tx;
+  const bool ok = t < T;
+  const float* xb = x + (size_t)b * x_bs + (ok ? t : 0);
   float s = 0.f;
-  for (int c = 0; c < C; ++c) s += xb[(size_t)c * x_cs];
-  const float mean = s / (float)C;
-  float q = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float d = xb[(size_t)c * x_cs] - mean;
-    q = fmaf(d, d, q);
+  if (ok)
+    for (int c = sl; c < C; c += LN_SLICES) s += xb[(size_t)c * x_cs];
+  part[sl][tx] = s;
+  __syncthreads();
+  if (sl == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_SLICES; ++i) tot += part[i][tx];
+    s_mean[tx] = tot / (float)C;
   }
-  const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+  __syncthreads();
+  const float mean = s_mean[tx];
+  float q = 0.f;
+  if (ok)
+    for (int c = sl; c < C; c += LN_SLICES) {
+      const float d = xb[(size_t)c * x_cs] - mean;
+      q = fmaf(d, d, q);
+    }
+  part[sl][tx] = q;
+  __syncthreads();
+  if (sl == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_SLICES; ++i) tot += part[i][tx];
+    s_rstd[tx] = 1.0f / sqrtf(tot / (float)C + 1e-5f);
+  }
+  __syncthreads();
+  if (!ok) return;
+  const float rstd = s_rstd[tx];
   float* yb = y + (size_t)b * y_bs;
   const int ph = split ? (t & 1) : 0;
   const int u = split ? (t >> 1) : t;
-  for (int c = 0; c < C; ++c) {
+  const bool tail = split && (T & 1) && t == T - 1;   // odd length: the odd phase's last slot is zero padding
+  for (int c = sl; c < C; c += LN_SLICES) {
     float v = (xb[(size_t)c * x_cs] - mean) * rstd * gamma[c] + beta[c];
     if (gelu) v = gelu_erf(v);
     yb[(size_t)(ph * C + c) * y_cs + u] = v;
-  }
-  if (split && (T & 1) && t == T - 1) {
-    // odd length: the odd phase is one frame shorter; its last slot reads as zero padding
-    for (int c = 0; c < C; ++c) yb[(size_t)(C + c) * y_cs + u] = 0.f;
+    if (tail) yb[(size_t)(C + c) * y_cs + u] = 0.f;
   }
 }
 
-// in place: st [G*T rows (key j)][pitch] -> softmax over j of scale*s, for every (group, query column)
-__global__ void __launch_bounds__(256) softmax_cols_kernel(float* __restrict__ st, int T, int pitch, float scale) {
+// in place: st [G*T rows (key j)][pitch] -> softmax over j of scale*s, for every (group, query column).
+// Block = 64 query columns x 16 row slices; a column's max and sum meet in LDS.
+__global__ void __launch_bounds__(1024) softmax_cols_kernel(float* __restrict__ st, int T, int pitch, float scale) {
+  __shared__ float part[16][64];
+  __shared__ float s_a[64];
   const int g = blockIdx.y;
-  const int qcol = blockIdx.x * 256 + threadIdx.x;
-  if (qcol >= T) return;
-  float* base = st + (size_t)g * T * pitch + qcol;
+  const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int qcol = blockIdx.x * 64 + tx;
+  const bool ok = qcol < T;
+  float* base = st + (size_t)g * T * pitch + (ok ? qcol : 0);
   float mx = -INFINITY;
-  for (int j = 0; j < T; ++j) mx = fmaxf(mx, base[(size_t)j * pitch] * scale);
-  float sum = 0.f;
-  for (int j = 0; j < T; ++j) {
-    const float e = expf(base[(size_t)j * pitch] * scale - mx);
-    base[(size_t)j * pitch] = e;
-    sum += e;
+  if (ok)
+    for (int j = sl; j < T; j += 16) mx = fmaxf(mx, base[(size_t)j * pitch] * scale);
+  part[sl][tx] = mx;
+  __syncthreads();
+  if (sl == 0) {
+    float m = part[0][tx];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, part[i][tx]);
+    s_a[tx] = m;
   }
-  const float inv = 1.0f / sum;
-  for (int j = 0; j < T; ++j) base[(size_t)j * pitch] *= inv;
+  __syncthreads();
+  mx = s_a[tx];
+  float sum = 0.f;
+  if (ok)
+    for (int j = sl; j < T; j += 16) {
+      const float e = expf(base[(size_t)j * pitch] * scale - mx);
+      base[(size_t)j * pitch] = e;
+      sum += e;
+    }
+  __syncthreads();
+  part[sl][tx] = sum;
+  __syncthreads();
+  if (sl == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += part[i][tx];
+    s_a[tx] = 1.0f / tot;
+  }
+  __syncthreads();
+  if (!ok) return;
+  const float inv = s_a[tx];
+  for (int j = sl; j < T; j += 16) base[(size_t)j * pitch] *= inv;
 }
 
 // v [B][H*D][pitch] -> vt [B*H][jpad][D] (packed-weight layout [ci = key j][co = d]); rows j >= T are zero
@@ -128,8 +179,8 @@ extern "C" int sat_layernorm_channels_f32(const float* x, const float* gamma, co
                                           int64_t y_cstride, int gelu, int split_phases, void* stream) {
   SAT_REQUIRE(x && gamma && beta && y, "layernorm_channels: null pointer");
   SAT_REQUIRE(B > 0 && C > 0 && T > 0, "layernorm_channels: empty shape");
-  dim3 grid(ceil_div(T, 256), B);
-  hipLaunchKernelGGL(layernorm_ch_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, C, T,
+  dim3 grid(ceil_div(T, 64), B);
+  hipLaunchKernelGGL(layernorm_ch_kernel, grid, dim3(64 * LN_SLICES), 0, (hipStream_t)stream, x, gamma, beta, y, C, T,
                      (long long)x_bstride, (long long)x_cstride, (long long)y_bstride, (long long)y_cstride, gelu,
                      split_phases);
   SAT_LAUNCH_CHECK("layernorm_ch_kernel");
@@ -138,8 +189,8 @@ extern "C" int sat_layernorm_channels_f32(const float* x, const float* gamma, co
 
 extern "C" int sat_softmax_columns_f32(float* st, int G, int T, int pitch, float scale, void* stream) {
   SAT_REQUIRE(st && G > 0 && T > 0 && pitch >= T, "softmax_columns: bad arguments");
-  dim3 grid(ceil_div(T, 256), G);
-  hipLaunchKernelGGL(softmax_cols_kernel, grid, dim3(256), 0, (hipStream_t)stream, st, T, pitch, scale);
+  dim3 grid(ceil_div(T, 64), G);
+  hipLaunchKernelGGL(softmax_cols_kernel, grid, dim3(1024), 0, (hipStream_t)stream, st, T, pitch, scale);
   SAT_LAUNCH_CHECK("softmax_cols_kernel");
   return SAT_OK;
 }
