@@ -99,6 +99,13 @@ typedef struct {
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
                    void* stream);
+/* One fused ResBlock1 step of the thin generator stages (C = 16 or 32), split-f16 arithmetic:
+ *   y = conv2(lrelu(conv1(lrelu(x)) + bias1)) + d->bias + x      (hifigan/nn.py:179-186)
+ * conv1 = (ksize, d->dilation), conv2 = (ksize, 1), both 'same' padded, slope d->in_slope; the
+ * intermediate never leaves LDS.  d->res must be x; d->accum / accum_div as in sat_conv1d_f32
+ * (MRF sum).  Weights: SAT_CONV_F16X3 packing. */
+int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
+                            const float* bias1, const void* w2_packed, float* y, void* stream);
 /* cin_pad / co_pad the packed layout must use for this shape (host-side helper, no GPU needed) */
 int sat_conv1d_packed_dims(int C_in, int C_out, int up, int groups, int* cin_pad, int* co_pad);
 /* Polyphase view of ConvTranspose1d(k, stride u, padding pad): output t = q*u + r reads input
@@ -125,6 +132,8 @@ size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T);
 int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, float* y, void* workspace,
                             size_t workspace_bytes, int B, int T, void* stream);
 void sat_hifigan_destroy(sat_hifigan* h);
+/* options: "fuse_pairs" (default 1): run the conv pairs of stages with C <= 32 as one fused kernel */
+int sat_hifigan_set_option(sat_hifigan* h, const char* name, int value);
 
 /* final stage alone: leaky_relu(0.01) -> ReflectionPad1d((1,0)) -> Conv1d(C,1,7,pad 3) -> tanh
  * (archi.py:87-90).  x [B][C][T] -> y [B][1][T+1];  w [C][7], bias [1]. */

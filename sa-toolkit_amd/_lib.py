@@ -53,6 +53,9 @@ _PROTOS = {
     "sat_hifigan_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                           C.c_int, C.c_void_p]),
     "sat_hifigan_destroy": (None, [C.c_void_p]),
+    "sat_hifigan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "sat_resblock_pair_f16x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
     "sat_hifigan_convpost_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]),
     "sat_fbank_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

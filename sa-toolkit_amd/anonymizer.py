@@ -108,8 +108,10 @@ def build(args):
                 xd = self._to_device(x.detach())
                 cur = torch.cuda.current_stream(xd.device)
                 if self._f0_stream is None:
-                    self._f0_stream = torch.cuda.Stream(device=xd.device)
-                side = self._f0_stream
+                    self._f0_stream = {}
+                side = self._f0_stream.get(cur.cuda_stream)
+                if side is None:    # one F0 side stream per launch stream
+                    side = self._f0_stream[cur.cuda_stream] = torch.cuda.Stream(device=xd.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     f0, self._f0_status = f0_hip.yaapt(xd, self.f0_yaapt_opts, defer_status=True)
@@ -144,7 +146,8 @@ def build(args):
             quant = f0_transforms.parse_quant_bins(spec) if spec and "quant" in spec else 0
             noise = None
             if spec and "awgn" in spec:
-                noise = f0_transforms.draw_awgn(f0.shape, f0_transforms.parse_awgn_db(spec)).to(f0.dtype).to(f0.device)
+                noise = f0_transforms.draw_awgn(f0.shape, f0_transforms.parse_awgn_db(spec)).to(f0.dtype)
+                noise = noise.pin_memory().to(f0.device, non_blocking=True) if f0.is_cuda else noise
             if spec and "mean-reverv" in spec:
                 raise NotImplementedError("f0 transformation 'mean-reverv' is not part of the accelerated path")
             if quant or noise is not None:
@@ -180,7 +183,12 @@ def build(args):
             B, c_bn, T = bn.shape
             if f0_d.shape[0] != B:
                 raise AssertionError("f0 and bn batch sizes differ")
-            spk = spk_id.to(device=dev, dtype=torch.float32).contiguous()
+            if spk_id.is_cuda:
+                spk = spk_id.to(device=dev, dtype=torch.float32).contiguous()
+            else:
+                # pinned + non_blocking: a pageable host-to-device copy would block the host until every
+                # kernel already queued on this stream has finished and serialise successive convert() calls
+                spk = spk_id.to(torch.float32).contiguous().pin_memory().to(dev, non_blocking=True)
             assert B == spk.shape[0], \
                 "len(target) != len(input_wav), check if the waveform batch size == target=len(['6081','4214'])"
             x = ops.assemble_input(bn, f0_d.reshape(B, -1), spk, spk.shape[1])

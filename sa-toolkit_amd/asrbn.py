@@ -11,6 +11,7 @@ BatchNorm1d(affine=False) and the ReLU (chain/nn.py:338-347).  Both run on the f
 kernel; the VQ bottleneck (chain/nn.py:402-476) has its own kernel.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -56,11 +57,15 @@ def mel_banks(num_bins=80, n_fft=512, sample_freq=16000.0, low_freq=20.0, high_f
 
 class _LayerCache:
     """device-side, kernel-ready form of one TDNNFBatchNorm layer"""
-    __slots__ = ("wB", "bB", "wA", "bA", "scale", "shift", "codebook")
+    __slots__ = ("wB", "bB", "wA", "bA", "scale", "shift", "codebook", "modeA", "modeB")
 
 
 class _TdnnfBase(nn.Module):
     """shared machinery of the two ASR-BN nets: TDNNF stack forward on the HIP kernels"""
+
+    #: arithmetic of the TDNNF matrix products: "f32" (exact f32 MFMA, default: the VQ arg-min behind this
+    #: stack is decision-critical) or "f16x3" (split-f16, ~2^-21 relative per product, about 2x faster)
+    precision = os.environ.get("SATOOLS_AMD_TDNNF_PRECISION", "f32")
 
     def _init_cache(self):
         self._cache = None
@@ -73,10 +78,12 @@ class _TdnnfBase(nn.Module):
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in list(self.parameters()) + list(self.buffers()))
 
     def _prepare(self, device):
-        key = self._param_key()
+        key = (self.precision,) + self._param_key()
         if self._cache_key == key:
             return
         cache = []
+        split = self.precision == "f16x3"
+        pack = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight
         for lay in self._stack_layers():
             c = _LayerCache()
             wB = lay.tdnn.linearB.inner_nat.weight.detach().to(device=device, dtype=torch.float32)
@@ -84,10 +91,13 @@ class _TdnnfBase(nn.Module):
             ctx, feat = lay.context_len, lay.feat_dim
             assert kin == ctx * feat
             # unfold window = ctx consecutive frames of `feat` values: column j*feat + c
-            c.wB = packing.pack_conv_weight(wB.reshape(bott, ctx, feat).permute(0, 2, 1).contiguous())
+            sub = int(lay.subsampling_factor)
+            c.modeB = 1 if (split and sub == 1 and ctx in (1, 2, 3)) else 0
+            c.wB = (pack if c.modeB else packing.pack_conv_weight)(wB.reshape(bott, ctx, feat).permute(0, 2, 1).contiguous())
             c.bB = lay.tdnn.linearB.inner_nat.bias.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
             wA = lay.tdnn.linearA.weight.detach().to(device=device, dtype=torch.float32)
-            c.wA = packing.pack_conv_weight(wA.unsqueeze(-1).contiguous())
+            c.modeA = 1 if split else 0
+            c.wA = pack(wA.unsqueeze(-1).contiguous())
             c.bA = lay.tdnn.linearA.bias.detach().to(device=device, dtype=torch.float32).contiguous()
             mean = lay.bn.running_mean.detach().to(device=device, dtype=torch.float32)
             var = lay.bn.running_var.detach().to(device=device, dtype=torch.float32)
@@ -105,7 +115,7 @@ class _TdnnfBase(nn.Module):
     def _tdnnf_layer(self, lay, c, x, return_bottleneck=False, want_aux=False):
         """x [B, feat, T] -> [B, out, T'] (or the bottleneck [B, bott, T'])"""
         ctx, sub = lay.context_len, int(lay.subsampling_factor)
-        z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, stride=sub, pad_left=0, pad_right=0)
+        z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, stride=sub, pad_left=0, pad_right=0, mode=c.modeB)
         aux = None
         if c.codebook is not None:
             zq, idx, dist = ops.vq(z, c.codebook, want_dist=want_aux)
@@ -119,7 +129,7 @@ class _TdnnfBase(nn.Module):
             if ctx == 2:
                 lidx = 1
             kw = dict(res=x, res_scale=lay.bypass_scale, res_toff=lidx, res_tstride=sub)
-        return ops.conv1d(z, c.wA, lay.out_dim, 1, bias=c.bA, ch_scale=c.scale, ch_shift=c.shift, relu=True, **kw)
+        return ops.conv1d(z, c.wA, lay.out_dim, 1, bias=c.bA, ch_scale=c.scale, ch_shift=c.shift, relu=True, mode=c.modeA, **kw)
 
     def _run_stack(self, x, want_aux=False):
         """x [B, C, T] (already padded) through tdnn1, tdnnfs[:-2], and the bottleneck of tdnnfs[-2]"""

@@ -36,6 +36,8 @@ struct ConvArgs {
   int in_lrelu, relu, accum, gelu, res_after;
   float in_slope, accum_div, res_scale;
   int res_toff, res_tstride;
+  const void* w2;        // fused pair: packed split-f16 weights of the second conv
+  const float* bias1;    // fused pair: bias of the first conv
   int fast_epi;  // up == 1 and every (utterance, group) slab addressable with 31-bit byte offsets
 };
 
@@ -43,7 +45,7 @@ struct ConvArgs {
 // BatchNorm, ReLU, MRF accumulation, (polyphase) store ----
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NT], int b, int g, int co_w,
-                                              int q_w, int l31, int lh) {
+                                              int q_w, int l31, int lh, int q_step = 32, int q_end = 0x7fffffff) {
   const int up = p.up;
   if (p.fast_epi) {
     // plain conv (up == 1): every row of this (utterance, group) sits behind one buffer descriptor
@@ -81,8 +83,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
       }
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int q = q_w + n * 32 + l31;
-        const bool qok = q < p.T_q;
+        const int q = q_w + n * q_step + l31;
+        const bool qok = q < p.T_q && q < q_end;
         const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
         const unsigned roff = qok ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : OOB;
         float rv[16], yv[16];
@@ -142,8 +144,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
           p.res ? p.res + (long long)b * p.r_bs + (long long)co * p.r_cs : nullptr;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int q = q_w + n * 32 + l31;
-        if (q >= p.T_q) continue;
+        const int q = q_w + n * q_step + l31;
+        if (q >= p.T_q || q >= q_end) continue;
         const int t = q * up + ph;
         float v = acc[m][n][r] + bias;
         if (rrow && !p.res_after) v += p.res_scale * rrow[(long long)t * p.res_tstride + p.res_toff];
@@ -518,13 +520,221 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
 template <int MT, int NT>
 static int launch_f16x3_ks(const ConvArgs& a, int B, int groups, hipStream_t s) {
   switch (a.ksize) {
+    case 1: return launch_f16x3<MT, NT, 1>(a, B, groups, s);
+    case 2: return launch_f16x3<MT, NT, 2>(a, B, groups, s);
     case 3: return launch_f16x3<MT, NT, 3>(a, B, groups, s);
     case 7: return launch_f16x3<MT, NT, 7>(a, B, groups, s);
     case 11: return launch_f16x3<MT, NT, 11>(a, B, groups, s);
     default:
-      set_error("conv1d(f16x3): kernel size %d not instantiated (3, 7, 11)", a.ksize);
+      set_error("conv1d(f16x3): kernel size %d not instantiated (1, 2, 3, 7, 11)", a.ksize);
       return SAT_ERR_INVALID;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused ResBlock1 step for the thin generator stages (C <= 32), split-f16 arithmetic:
+//     out = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x        (hifigan/nn.py:179-186)
+// Unfused, a step moves five stage-sized tensors through HBM (x, t1 out, t1 in, residual, out) and the
+// thin stages sit on the HBM roofline; fused, the intermediate t1 lives only in LDS (already split into
+// hi|lo f16 planes, ready to be the B operand of conv2) and the step reads x once and writes out once.
+// A block produces 224 output positions: conv1 is evaluated on the 256-position window that conv2
+// needs (t1 positions outside the utterance are zero, they are conv2's zero padding), 8 sub-tiles of
+// 32 over 4 waves; conv2 on 7 sub-tiles.  One 32-row weight tile (C = 16 is padded to 32 rows).
+// ------------------------------------------------------------------------------------------------
+constexpr int FP_TO = 224;    // output positions per block
+constexpr int FP_W1 = 256;    // t1 window: [t0 - 16, t0 + 240)
+constexpr int FP_OFF = 16;
+
+template <int KS, int XWI>
+__global__ void __launch_bounds__(256, 2) resblock_pair_f16x3_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  constexpr int CO_B = 32;
+  constexpr int XWP = 64 * XWI;
+  constexpr int NIT = (XWI + 1) / 2;
+  constexpr int W_UNITS = KS * 4 * CO_B;
+  constexpr int W_IT = (W_UNITS + 255) / 256;
+  uint4* ldsx = lds4;                       // [4][XWP]            input chunk, hi|lo x half
+  uint4* ldsw = lds4 + 4 * XWP;             // [KS][2][2][32]      weight chunk
+  uint4* ldst = ldsw + W_UNITS;             // [nchunk][4][FP_W1]  t1, all channels
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * FP_TO;
+  const int h2 = (KS - 1) / 2;
+  const int xi0 = t0 - FP_OFF - p.pad_left;   // first input position of the staged tile (pad_left = conv1 halo)
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (long long)b * p.x_bs), 0, (unsigned)((long long)p.cin_g * p.x_cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)p.w_gs, 0x00020000);
+  const int sh = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int sp = __builtin_amdgcn_readfirstlane(wave >> 1);
+  const int x_row_bytes = (int)p.x_cs * 4;
+  const int seg_bytes = p.co_pad * 16;
+  const int nchunk = p.cin_pad / CI_CHUNK;
+
+  auto stage_w = [&](const __amdgpu_buffer_rsrc_t& rs, int chunk) {
+    uint4 wst[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + 256 * i;
+      wst[i] = make_uint4(0, 0, 0, 0);
+      if (u < W_UNITS)
+        wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rs, (u % CO_B) * 16 + (u / CO_B) * seg_bytes, chunk * (KS * 4) * seg_bytes, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + 256 * i;
+      if (u < W_UNITS) ldsw[u] = wst[i];
+    }
+  };
+
+  // ================= phase 1: t1 = lrelu(conv1(lrelu(x)) + b1) on the 256-position window =================
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const int c0 = chunk * CI_CHUNK;
+    __syncthreads();
+    {
+      float stg[NIT][8];
+#pragma unroll
+      for (int ii = 0; ii < NIT; ++ii) {
+        const int it = 2 * ii + sp;
+        const int xi = xi0 + lane + 64 * it;
+        const unsigned voff = (it < XWI && xi >= 0 && xi < p.T_in) ? (unsigned)(xi * 4) : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ci = c0 + 8 * sh + j;
+          float v = 0.f;
+          if (ci < p.cin_g) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, ci * x_row_bytes, 0));
+          stg[ii][j] = v;
+        }
+      }
+      stage_w(w1rs, chunk);
+#pragma unroll
+      for (int ii = 0; ii < NIT; ++ii) {
+        const int it = 2 * ii + sp;
+        if (it < XWI) {
+          unsigned hi[4], lo[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x0 = stg[ii][2 * j], x1 = stg[ii][2 * j + 1];
+            x0 = x0 > 0.f ? x0 : x0 * p.in_slope;
+            x1 = x1 > 0.f ? x1 : x1 * p.in_slope;
+            const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+            const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+            hi[j] = __builtin_bit_cast(unsigned, h);
+            lo[j] = __builtin_bit_cast(unsigned, l);
+          }
+          const int col = lane + 64 * it;
+          ldsx[(0 * 2 + sh) * XWP + col] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+          ldsx[(1 * 2 + sh) * XWP + col] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+      }
+    }
+    __syncthreads();
+    const uint4* wb = ldsw + lh * CO_B + l31;
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      const h8 a_hi = __builtin_bit_cast(h8, wb[(t * 4 + 0) * CO_B]);
+      const h8 a_lo = __builtin_bit_cast(h8, wb[(t * 4 + 2) * CO_B]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const uint4* xt = ldsx + lh * XWP + (wave + 4 * n) * 32 + l31 + t * p.dil;
+        const h8 b_hi = __builtin_bit_cast(h8, xt[0]);
+        const h8 b_lo = __builtin_bit_cast(h8, xt[2 * XWP]);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[n], 0, 0, 0);
+      }
+    }
+  }
+  // t1 -> LDS as conv2's B operand.  D layout: lane (col = l31, lh) holds rows 8*rg + 4*lh + (r&3), rg = r>>2:
+  // four consecutive channels = 8 bytes of the 16-byte unit (chunk' = rg>>1, half' = rg&1) of its column.
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = (wave + 4 * n) * 32 + l31;
+    const int pos = t0 - FP_OFF + col;
+    const bool inside = pos >= 0 && pos < p.T_in;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      if ((rg >> 1) >= nchunk) continue;   // C = 16: rows 16..31 are padding, no t1 plane for them
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 8 * rg + 4 * lh + k;
+        float t = acc[n][4 * rg + k] + (row < p.rows_g ? p.bias1[row] : 0.f);
+        t = t > 0.f ? t : t * p.in_slope;
+        v[k] = inside ? t : 0.f;
+      }
+      const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+      const auto h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+      const auto l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
+      const auto l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+      uint2* dh = (uint2*)(ldst + (((rg >> 1) * 4 + 0 * 2 + (rg & 1)) * FP_W1 + col)) + lh;
+      uint2* dl = (uint2*)(ldst + (((rg >> 1) * 4 + 1 * 2 + (rg & 1)) * FP_W1 + col)) + lh;
+      *dh = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+      *dl = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    }
+  }
+
+  // ================= phase 2: out = conv2(t1) + b2 + x =================
+  f32x16 acc2[1][2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[0][n][r] = 0.f;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();
+    stage_w(w2rs, chunk);
+    __syncthreads();
+    const uint4* wb = ldsw + lh * CO_B + l31;
+    const uint4* tb = ldst + (chunk * 4 + lh) * FP_W1 + FP_OFF - h2 + l31;
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      const h8 a_hi = __builtin_bit_cast(h8, wb[(t * 4 + 0) * CO_B]);
+      const h8 a_lo = __builtin_bit_cast(h8, wb[(t * 4 + 2) * CO_B]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        if (wave + 4 * n < FP_TO / 32) {   // wave-uniform: 7 output sub-tiles over 4 waves
+          const uint4* xt = tb + (wave + 4 * n) * 32 + t;
+          const h8 b_hi = __builtin_bit_cast(h8, xt[0]);
+          const h8 b_lo = __builtin_bit_cast(h8, xt[2 * FP_W1]);
+          acc2[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc2[0][n], 0, 0, 0);
+          acc2[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc2[0][n], 0, 0, 0);
+          acc2[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc2[0][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  conv_epilogue<1, 2>(p, acc2, b, 0, 0, t0 + wave * 32, l31, lh, 128, t0 + FP_TO);
+}
+
+template <int KS>
+static int launch_pair(const ConvArgs& a, int B, hipStream_t s) {
+  constexpr int XWI = (FP_W1 + (KS - 1) * 5 + 63) / 64;
+  ConvArgs p = a;
+  if (FP_W1 + (p.ksize - 1) * p.dil > 64 * XWI) {
+    set_error("resblock_pair: dilation %d too large", p.dil);
+    return SAT_ERR_INVALID;
+  }
+  p.co_tiles_g = 1;
+  const size_t lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * 32 + (size_t)(p.cin_pad / CI_CHUNK) * 4 * FP_W1) * 16;
+  auto kern = resblock_pair_f16x3_kernel<KS, XWI>;
+  if (lds_bytes > 64 * 1024)
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  dim3 grid(ceil_div(p.T_q, FP_TO), 1, B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
+  SAT_LAUNCH_CHECK("resblock_pair_f16x3_kernel");
+  return SAT_OK;
 }
 
 template <int MT, int NT, int WM, int WN, int KS, bool S1, int XWI>
@@ -661,4 +871,45 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
   }
   if (a.rows_g > 32) return launch_ks<2, 2, 1, 4>(a, d->B, d->groups, s);   //  64 rows x 256 positions
   return launch_ks<1, 4, 1, 4>(a, d->B, d->groups, s);                       //  32 rows x 512 positions
+}
+
+
+extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
+                                       const float* bias1, const void* w2_packed, float* y, void* stream) {
+  SAT_REQUIRE(d && x && w1_packed && w2_packed && bias1 && y && d->bias, "resblock_pair: null pointer");
+  SAT_REQUIRE(d->C_in == d->C_out && d->C_in <= 32 && d->C_in % 16 == 0, "resblock_pair: C must be 16 or 32");
+  SAT_REQUIRE(d->groups == 1 && d->up == 1 && d->stride == 1 && d->T_q == d->T_in, "resblock_pair: same-length conv pair only");
+  SAT_REQUIRE(d->ksize == 3 || d->ksize == 7 || d->ksize == 11, "resblock_pair: kernel size %d not instantiated", d->ksize);
+  SAT_REQUIRE(d->in_lrelu, "resblock_pair: both convs take a leaky-relu input");
+  SAT_REQUIRE(d->res == x, "resblock_pair: the residual is the block input");
+  ConvArgs a{};
+  a.x = x;
+  a.w = (const float*)w1_packed;
+  a.w2 = w2_packed;
+  a.bias1 = bias1;
+  a.y = y;
+  a.bias = d->bias;                 // bias of the second conv (the epilogue's)
+  a.res = d->res;
+  a.x_bs = d->x_bstride; a.x_cs = d->x_cstride;
+  a.y_bs = d->y_bstride; a.y_cs = d->y_cstride;
+  a.r_bs = d->res_bstride; a.r_cs = d->res_cstride;
+  a.cin_g = d->C_in; a.cout_g = d->C_out; a.rows_g = d->C_out;
+  a.T_in = d->T_in; a.T_q = d->T_q;
+  a.ksize = d->ksize; a.dil = d->dilation; a.stride = 1; a.up = 1;
+  a.pad_left = (d->ksize * d->dilation - d->dilation) / 2;   // 'same' padding of the dilated first conv
+  a.cin_pad = round_up(a.cin_g, CI_CHUNK);
+  a.co_pad = 64;
+  a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;
+  a.in_lrelu = 1; a.in_slope = d->in_slope;
+  a.accum = d->accum; a.accum_div = d->accum_div;
+  a.res_scale = 1.f; a.res_toff = 0; a.res_tstride = 1;
+  SAT_REQUIRE((long long)a.cin_g * a.x_cs * 4 < (1LL << 31) && (long long)a.rows_g * a.y_cs * 4 < (1LL << 31),
+              "resblock_pair: slab too large for 31-bit offsets");
+  a.fast_epi = 1;
+  hipStream_t s = (hipStream_t)stream;
+  switch (a.ksize) {
+    case 3: return launch_pair<3>(a, d->B, s);
+    case 7: return launch_pair<7>(a, d->B, s);
+    default: return launch_pair<11>(a, d->B, s);
+  }
 }

@@ -1,6 +1,7 @@
 // HiFi-GAN generator forward on gfx950: orchestration over the fused conv1d kernel plus the
 // streaming output stage.  Reference: CoreHifiGan.forward_resnet, satools/satools/hifigan/
 // archi.py:77-91; ResBlock1.forward, satools/satools/hifigan/nn.py:179-186.
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -87,6 +88,7 @@ struct sat_hifigan {
     int mode = SAT_CONV_F32;
   };
   std::vector<Conv> convs;
+  int fuse_pairs = 1;
   int n_ups() const { return (int)up_rates.size(); }
   int n_rbk() const { return (int)rb_kernels.size(); }
   int id_up(int i) const { return 1 + i; }
@@ -161,6 +163,13 @@ extern "C" size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T
 }
 
 extern "C" void sat_hifigan_destroy(sat_hifigan* h) { delete h; }
+
+extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int value) {
+  SAT_REQUIRE(h && name, "hifigan_set_option: null pointer");
+  if (std::string(name) == "fuse_pairs") { h->fuse_pairs = value; return SAT_OK; }
+  set_error("hifigan_set_option: unknown option %s", name);
+  return SAT_ERR_INVALID;
+}
 
 extern "C" int sat_hifigan_convpost_f32(const float* x, const float* w, const float* bias, float* y, int B,
                                         int C, int T, void* stream) {
@@ -249,31 +258,22 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
       const float* r = H;
       for (int pair = 0; pair < 3; ++pair) {
         const int dil = h->rb_dil[j * 3 + pair];
-        // xt = c1(leaky_relu(x, 0.1))
-        sat_conv1d_desc d1 = base_desc(Cn, Cn, Tn, Tn, 1);
-        d1.ksize = rk;
-        d1.dilation = dil;
-        d1.pad_left = (rk * dil - dil) / 2;
-        d1.in_lrelu = 1;
-        d1.in_slope = 0.1f;
-        d1.bias = h->convs[h->id_rb(i, j, pair, 0)].bias;
-        d1.mode = h->convs[h->id_rb(i, j, pair, 0)].mode;
-        int s = sat_conv1d_f32(&d1, r, h->convs[h->id_rb(i, j, pair, 0)].w, T1, stream);
-        if (s != SAT_OK) return s;
-        // x = c2(leaky_relu(xt, 0.1)) + x
+        const auto& cv1 = h->convs[h->id_rb(i, j, pair, 0)];
+        const auto& cv2 = h->convs[h->id_rb(i, j, pair, 1)];
+        float* dst;
+        // x = c2(leaky_relu(xt, 0.1)) + x with xt = c1(leaky_relu(x, 0.1))
         sat_conv1d_desc d2 = base_desc(Cn, Cn, Tn, Tn, 1);
         d2.ksize = rk;
         d2.dilation = 1;
         d2.pad_left = (rk - 1) / 2;
         d2.in_lrelu = 1;
         d2.in_slope = 0.1f;
-        d2.bias = h->convs[h->id_rb(i, j, pair, 1)].bias;
-        d2.mode = h->convs[h->id_rb(i, j, pair, 1)].mode;
+        d2.bias = cv2.bias;
+        d2.mode = cv2.mode;
         d2.res = r;
         d2.res_scale = 1.f;
         d2.res_cstride = Tn;
         d2.res_bstride = (int64_t)Cn * Tn;
-        float* dst;
         if (pair < 2) {
           dst = (r == RA) ? RB : RA;
         } else {
@@ -281,8 +281,27 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
           d2.accum = j > 0;
           d2.accum_div = (j == nk - 1) ? (float)nk : 0.f;
         }
-        s = sat_conv1d_f32(&d2, T1, h->convs[h->id_rb(i, j, pair, 1)].w, dst, stream);
-        if (s != SAT_OK) return s;
+        int s;
+        if (Cn <= 32 && Cn % 16 == 0 && cv1.mode == SAT_CONV_F16X3 && cv2.mode == SAT_CONV_F16X3 && h->fuse_pairs) {
+          // thin stages sit on the HBM roofline: one fused kernel, the intermediate stays in LDS
+          sat_conv1d_desc df = d2;
+          df.dilation = dil;
+          s = sat_resblock_pair_f16x3(&df, r, cv1.w, cv1.bias, cv2.w, dst, stream);
+          if (s != SAT_OK) return s;
+        } else {
+          sat_conv1d_desc d1 = base_desc(Cn, Cn, Tn, Tn, 1);
+          d1.ksize = rk;
+          d1.dilation = dil;
+          d1.pad_left = (rk * dil - dil) / 2;
+          d1.in_lrelu = 1;
+          d1.in_slope = 0.1f;
+          d1.bias = cv1.bias;
+          d1.mode = cv1.mode;
+          s = sat_conv1d_f32(&d1, r, cv1.w, T1, stream);
+          if (s != SAT_OK) return s;
+          s = sat_conv1d_f32(&d2, T1, cv2.w, dst, stream);
+          if (s != SAT_OK) return s;
+        }
         r = dst;
       }
     }

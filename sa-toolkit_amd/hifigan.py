@@ -77,10 +77,17 @@ class CoreHifiGan(CoreHifiGanParams):
         self._packed_key = key
 
     def _workspace(self, B, T, device):
+        # one workspace per launch stream: concurrent convert() calls on different streams (the
+        # reference's `jobs_per_compute_device`, bin/anonymize:85-93) must not share scratch buffers
         need = lib().sat_hifigan_workspace_bytes(self._handle, B, T)
-        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != device:
-            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
-        return self._ws, need
+        key = torch.cuda.current_stream(device).cuda_stream
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 4 < need or ws.device != device:
+            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+            self._ws[key] = ws
+        return ws, need
 
     # -- reference interface ----------------------------------------------------------------
     def forward_resnet(self, x):

@@ -194,3 +194,24 @@ def attention_apply(st, vt, B, heads, hd, T):
     o = torch.empty(B, heads * hd, T, dtype=torch.float32, device=st.device)
     conv1d(st.view(1, G * T, st.shape[1])[:, :, :T], vt, G * hd, 1, groups=G, out=o.view(1, G * hd, T))
     return o
+
+
+def resblock_pair(x, w1, b1, w2, b2, ksize, dilation, slope=0.1, out=None, accum=False, accum_div=0.0):
+    """fused ResBlock1 step (C = 16 / 32, split-f16): out = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x"""
+    x = _f32c(x)
+    B, c, t = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    d = ConvDesc()
+    d.B, d.C_in, d.T_in, d.C_out, d.T_q = B, c, t, c, t
+    d.ksize, d.dilation, d.stride, d.pad_left, d.groups, d.up, d.mode = ksize, dilation, 1, 0, 1, 1, 1
+    d.in_lrelu, d.in_slope = 1, float(slope)
+    d.accum, d.accum_div = int(accum), float(accum_div)
+    d.res_scale, d.res_toff, d.res_tstride = 1.0, 0, 1
+    d.x_bstride, d.x_cstride = x.stride(0), x.stride(1)
+    d.y_bstride, d.y_cstride = out.stride(0), out.stride(1)
+    d.res_bstride, d.res_cstride = x.stride(0), x.stride(1)
+    d.bias, d.res = ptr(b2), ptr(x)
+    check(lib().sat_resblock_pair_f16x3(C.byref(d), ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(out), stream()),
+          "sat_resblock_pair_f16x3")
+    return out

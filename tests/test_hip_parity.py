@@ -82,6 +82,29 @@ def test_conv1d_split_f16_matches_torch(case):
     assert e16 < 2.5 * e32 + 1e-8
 
 
+@pytest.mark.parametrize("case", [(16, 3, 1, 1000), (16, 7, 3, 700), (16, 11, 5, 2500), (32, 3, 5, 449), (32, 7, 1, 224), (32, 11, 3, 1500)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_fused_resblock_pair_matches_torch(case):
+    """out = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x in one kernel (thin generator stages)"""
+    ops, packing = _ops()
+    C, k, d, T = case
+    x = _rand(2, C, T, seed=1)
+    w1, w2 = _rand(C, C, k, seed=2, scale=0.6 / np.sqrt(C * k)), _rand(C, C, k, seed=3, scale=0.6 / np.sqrt(C * k))
+    b1, b2 = _rand(C, seed=4, scale=0.1), _rand(C, seed=5, scale=0.1)
+    xd = x.double()
+    t1 = F.conv1d(F.leaky_relu(xd, 0.1), w1.double(), b1.double(), dilation=d, padding=(k * d - d) // 2)
+    ref = F.conv1d(F.leaky_relu(t1, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2) + xd
+    pk = packing.pack_conv_weight_f16x3
+    y = ops.resblock_pair(x.to(DEV), pk(w1.to(DEV)), b1.to(DEV), pk(w2.to(DEV)), b2.to(DEV), k, d)
+    err = (y.cpu().double() - ref).abs().max().item()
+    print("max abs err vs f64:", err)
+    assert err < 2e-5
+    acc0 = _rand(2, C, T, seed=6).to(DEV)
+    out = acc0.clone()
+    ops.resblock_pair(x.to(DEV), pk(w1.to(DEV)), b1.to(DEV), pk(w2.to(DEV)), b2.to(DEV), k, d, out=out, accum=True, accum_div=3.0)
+    assert (out.cpu().double() - (acc0.cpu().double() + ref) / 3).abs().max() < 2e-5
+
+
 def test_conv1d_fused_prologue_epilogue():
     ops, packing = _ops()
     B, C, T, k, d = 2, 64, 333, 7, 3
