@@ -170,8 +170,17 @@ def main():
         split = model.hifigan.precision == "f16x3"
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
         hbm = GEN_BYTES_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_generator_traffic.json")
+        if os.path.exists(tpath) and tag == TAG:
+            tj = json.load(open(tpath))["per_forward"]
+            traffic = tj["traffic_GB_raw"] * 1e9
+            traffic_note = (f"HBM bytes per generator forward (batch 32) from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                            f"passes (profiles/r01_generator_traffic.json): fetch {tj['fetch_GB_raw']} GB as counted "
+                            f"({tj['fetch_GB_doubled']} GB with the gfx950 wide-load x2 correction as upper bound) + write "
+                            f"{tj['write_GB']} GB; per-layer streaming model {tj['algorithmic_GB_per_layer_model']} GB")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": ("conv1d_f16x3_kernel" if split else "conv1d_mfma_kernel") + " family: the 96 MFMA conv "
                               f"launches of one generator forward (+ output stage), {gen_ms:.3f} ms per batch of {BATCH}",
                     "arithmetic": ("f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = "

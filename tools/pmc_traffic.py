@@ -1,0 +1,47 @@
+"""Summarise the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 2 --warmup 1 --jobs 1`
+into HBM traffic per generator forward (batch of 32).  Units and corrections per MI355X_MICROARCH.md §HBM:
+counters are KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced streaming reads, so
+the read side is reported raw and doubled (upper bound).  Usage: python tools/pmc_traffic.py FETCH.csv WRITE.csv"""
+import csv
+import json
+import re
+import sys
+
+
+def load(path, counter):
+    per = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"^void ", "", r["Kernel_Name"])
+        name = re.sub(r"\(.*", "", name)
+        d = per.setdefault(name, [0, 0.0])
+        d[0] += 1
+        d[1] += float(r["Counter_Value"])
+    return per
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    gen = lambda n: ("conv1d_f16x3" in n or "resblock_pair" in n or "convpost" in n)
+    # generator forwards in that run: 3 convert() steps + 1 warm + 3 timed forwards of the roofline probe
+    n_post = fetch.get("sat::convpost_kernel", [1])[0]
+    out = {"generator_forwards_in_run": n_post, "kernels": {}}
+    tot_f = tot_w = 0.0
+    for name in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(name, [0, 0.0]), write.get(name, [0, 0.0])
+        if not gen(name):
+            continue
+        out["kernels"][name] = {"launches": f[0], "fetch_GB": round(f[1] * 1024 / 1e9, 3), "write_GB": round(w[1] * 1024 / 1e9, 3)}
+        tot_f += f[1] * 1024
+        tot_w += w[1] * 1024
+    out["per_forward"] = {"fetch_GB_raw": round(tot_f / n_post / 1e9, 3), "fetch_GB_doubled": round(2 * tot_f / n_post / 1e9, 3),
+                          "write_GB": round(tot_w / n_post / 1e9, 3),
+                          "traffic_GB_raw": round((tot_f + tot_w) / n_post / 1e9, 3),
+                          "traffic_GB_fetch_doubled": round((2 * tot_f + tot_w) / n_post / 1e9, 3),
+                          "algorithmic_GB_per_layer_model": 23.405}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
