@@ -74,6 +74,19 @@ int sat_device_info(char* name, int name_len, int* cu_count);
  *                  ksize in {3, 7, 11}; operands must lie inside the f16 range (|x| < 65504). */
 #define SAT_CONV_F32 0
 #define SAT_CONV_F16X3 1
+/*   SAT_CONV_F16F8 hi*hi on the f16 MFMA; the two cross terms hi*lo + lo*hi (2^-11 of the product) on the
+ *                  block-scaled e4m3 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the f16 rate per K) with
+ *                  exact power-of-two scales: ~2^-15 relative per product, measured 3e-6 RMS on the
+ *                  generator's waveform against 1.5e-7 for SAT_CONV_F16X3 (bar 1e-4).  Input must be split
+ *                  planes in SAT_SPLIT_F8 format; weights |w| < 7 packed by pack_conv_weight_f16f8:
+ *                  w[g][cin_pad/16][ksize][4][co_pad][16 B], segments hi f16 ch 0-7 | hi f16 ch 8-15 |
+ *                  e4m3(lo * 2^16) 16 ch | e4m3(hi * 2^6) 16 ch. */
+#define SAT_CONV_F16F8 2
+/* split-plane formats: per 16-channel chunk and position four 16-byte units
+ *   SAT_SPLIT_F16: hi f16 ch 0-7 | hi f16 ch 8-15 | lo f16 ch 0-7 | lo f16 ch 8-15
+ *   SAT_SPLIT_F8 : hi f16 ch 0-7 | hi f16 ch 8-15 | e4m3(hi) 16 ch | e4m3(lo * 2^10) 16 ch */
+#define SAT_SPLIT_F16 0
+#define SAT_SPLIT_F8 1
 
 typedef struct {
   int32_t B, C_in, T_in;       /* input  [B][C_in][T_in]  */
@@ -95,6 +108,17 @@ typedef struct {
   const float* res;        /* residual source or NULL */
   const float* ch_scale;   /* [C_out] or NULL (BatchNorm1d eval folded: 1/sqrt(var+eps)) */
   const float* ch_shift;   /* [C_out] or NULL (-mean/sqrt(var+eps)) */
+  /* split-plane activations (SAT_CONV_F16X3, groups 1, up 1, channel counts multiples of 16): a
+   * tensor [B][C][T] stored as S[b][c/16][4 units][t][16 B] (SAT_SPLIT_F16: [hi|lo][(c/8)&1][t][c%8] f16)
+   * — the exact B-operand layout of the split-f16 kernels, same number of bytes as the f32 tensor.  A producer writes
+   * split(lrelu(y, y_split_slope)) next to (or instead of) y; the consumer then stages its input
+   * with one 16-byte load per 8 channels and no conversion (`x` and in_lrelu are ignored). */
+  const void* x_split;     /* input as split planes of pre(x), or NULL */
+  void* y_split;           /* also write the output as split planes, or NULL */
+  float y_split_slope;     /* leaky-relu slope applied before splitting; 1 = none */
+  int32_t no_y;            /* skip the f32 store of y (y may be NULL) */
+  int32_t y_split_format;  /* 0 = the format this mode reads (F16X3: SAT_SPLIT_F16, F16F8: SAT_SPLIT_F8),
+                              1 = SAT_SPLIT_F16, 2 = SAT_SPLIT_F8 */
 } sat_conv1d_desc;
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
@@ -106,6 +130,8 @@ int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packe
  * (MRF sum).  Weights: SAT_CONV_F16X3 packing. */
 int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
                             const float* bias1, const void* w2_packed, float* y, void* stream);
+/* f32 [B][C][T] -> split planes of lrelu(x, slope) in `format` (SAT_SPLIT_*); C % 16 == 0 */
+int sat_act_split_f32(const float* x, void* x_split, int B, int C, int T, float slope, int format, void* stream);
 /* cin_pad / co_pad the packed layout must use for this shape (host-side helper, no GPU needed) */
 int sat_conv1d_packed_dims(int C_in, int C_out, int up, int groups, int* cin_pad, int* co_pad);
 /* Polyphase view of ConvTranspose1d(k, stride u, padding pad): output t = q*u + r reads input

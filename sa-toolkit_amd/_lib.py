@@ -17,7 +17,8 @@ class SatError(RuntimeError):
     pass
 
 
-CONV_F32, CONV_F16X3 = 0, 1
+CONV_F32, CONV_F16X3, CONV_F16F8 = 0, 1, 2
+SPLIT_F16, SPLIT_F8 = 0, 1
 
 
 class ConvDesc(C.Structure):
@@ -35,6 +36,8 @@ class ConvDesc(C.Structure):
         ("y_bstride", C.c_int64), ("y_cstride", C.c_int64),
         ("res_bstride", C.c_int64), ("res_cstride", C.c_int64),
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ch_scale", C.c_void_p), ("ch_shift", C.c_void_p),
+        ("x_split", C.c_void_p), ("y_split", C.c_void_p), ("y_split_slope", C.c_float), ("no_y", C.c_int32),
+        ("y_split_format", C.c_int32),
     ]
 
 
@@ -56,6 +59,7 @@ _PROTOS = {
     "sat_hifigan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "sat_resblock_pair_f16x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "sat_act_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "sat_hifigan_convpost_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]),
     "sat_fbank_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -18,6 +18,25 @@ namespace sat {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// power-of-two scales of the e4m3 cross-term operands (exact): x_lo * 2^10, W_hi * 2^6, W_lo * 2^16;
+// E8M0 scale bytes of v_mfma_scale (value 2^(e - 127)) undo them: lanes 0-31 carry the K block
+// "W_lo8 . x_hi8", lanes 32-63 the block "W_hi8 . x_lo8"
+constexpr float F8_XLO_SCALE = 1024.f;
+constexpr int F8_E_XHI = 127, F8_E_XLO = 127 - 10, F8_E_WHI = 127 - 6, F8_E_WLO = 127 - 16;
+
+__device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
+  // OCP e4m3 saturates at 448; clamp first so an out-of-range activation degrades gracefully
+  a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
+  b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+  c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f);
+  d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+
 constexpr int CI_CHUNK = 16;  // input channels staged per K-chunk (8 MFMA k-pairs)
 
 struct ConvArgs {
@@ -39,13 +58,65 @@ struct ConvArgs {
   const void* w2;        // fused pair: packed split-f16 weights of the second conv
   const float* bias1;    // fused pair: bias of the first conv
   int fast_epi;  // up == 1 and every (utterance, group) slab addressable with 31-bit byte offsets
+  const void* x16;       // input as split planes (see satools_hip.h), or null
+  void* y16;             // output as split planes, or null
+  float y16_slope;
+  int no_y;
+  int f8;                // planes kernels: cross terms hi*lo + lo*hi on the block-scaled e4m3 MFMA
+  int y16_f8;            // output planes carry (hi f16 | e4m3(hi) | e4m3(lo * 2^10)) instead of (hi f16 | lo f16)
+#ifdef SAT_STAMPS
+  long long* dbg;        // diagnostic build (tools/stamp_conv.hip): per-block, per-chunk phase time stamps
+#endif
 };
+#ifdef SAT_STAMPS
+long long* g_stamp_buffer = nullptr;
+#define SAT_STAMP(i) do { \
+    __builtin_amdgcn_sched_barrier(0); \
+    unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); \
+    if (p.dbg && tid == 0) p.dbg[((long long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (p.cin_pad / CI_CHUNK) + chunk) * 8 + (i)] = (long long)t_; \
+  } while (0)
+// block-level record in the slots 6/7 of chunk 0 and 1: 100 MHz wall clock at start/end, HW_ID, XCC_ID
+#define SAT_STAMP_BLOCK(i, expr) do { \
+    if (p.dbg && tid == 0) p.dbg[((long long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (p.cin_pad / CI_CHUNK)) * 8 + (i)] = (long long)(expr); \
+  } while (0)
+#else
+#define SAT_STAMP(i)
+#define SAT_STAMP_BLOCK(i, expr)
+#endif
 
 // ---- epilogue shared by the exact-f32 and the split-f16 kernels: bias, residual / bypass, folded
 // BatchNorm, ReLU, MRF accumulation, (polyphase) store ----
+// residual of the whole wave tile fetched ahead of the epilogue (fast path only): issued before the last
+// K-chunk's MFMA phase, the HBM round trip hides under the matrix work instead of stalling the epilogue
 template <int MT, int NT>
+__device__ __forceinline__ void epilogue_prefetch_res(const ConvArgs& p, float (&rpre)[MT][NT][16], int b, int g, int co_w,
+                                                      int q_w, int l31, int lh, int q_step = 32, int q_end = 0x7fffffff) {
+  const long long rb = (long long)b * p.r_bs + (long long)(g * p.cout_g) * p.r_cs;
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res ? p.res + rb : p.y), 0, p.res ? (unsigned)(p.rows_g * p.r_cs * 4) : 0u, 0x00020000);
+  const int r_rb = (int)p.r_cs * 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row0 = co_w + m * 32 + 4 * lh;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int q = q_w + n * q_step + l31;
+      const bool qok = q < p.T_q && q < q_end;
+      const unsigned roff = qok ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : 0x80000000u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        rpre[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rrs, roff + ((r & 3) + 8 * (r >> 2)) * r_rb, 0, 0));
+    }
+  }
+}
+
+template <int MT, int NT, bool RPRE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NT], int b, int g, int co_w,
-                                              int q_w, int l31, int lh, int q_step = 32, int q_end = 0x7fffffff) {
+                                              int q_w, int l31, int lh, int q_step = 32, int q_end = 0x7fffffff,
+                                              float (*rpre)[NT][16] = nullptr) {
   const int up = p.up;
   if (p.fast_epi) {
     // plain conv (up == 1): every row of this (utterance, group) sits behind one buffer descriptor
@@ -68,15 +139,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
     const __amdgpu_buffer_rsrc_t shs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.ch_shift ? p.ch_shift + chb : p.y), 0, p.ch_shift ? chn : 0u, 0x00020000);
     const int y_rb = (int)p.y_cs * 4, r_rb = (int)p.r_cs * 4;  // bytes per row
+    const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.y16 ? (char*)p.y16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
+        p.y16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int row0 = co_w + m * 32 + 4 * lh;
       float bi[16], sc[16], sh[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = ((r & 3) + 8 * (r >> 2)) * 4;
-        bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, row0 * 4 + ro, 0, 0));
-        if (p.ch_scale) {
+      for (int r = 0; r < 16; ++r)
+        bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, row0 * 4 + ((r & 3) + 8 * (r >> 2)) * 4, 0, 0));
+      if (p.ch_scale) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = ((r & 3) + 8 * (r >> 2)) * 4;
           sc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scs, row0 * 4 + ro, 0, 0));
           sh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shs, row0 * 4 + ro, 0, 0));
         }
@@ -90,9 +166,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         float rv[16], yv[16];
         if (p.res) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                  rrs, roff + ((r & 3) + 8 * (r >> 2)) * r_rb, 0, 0));
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (RPRE)
+              rv[r] = rpre[m][n][r];
+            else
+              rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                    rrs, roff + ((r & 3) + 8 * (r >> 2)) * r_rb, 0, 0));
+          }
         }
         if (p.accum) {
 #pragma unroll
@@ -100,18 +180,84 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
             yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                   yrs, yoff + ((r & 3) + 8 * (r >> 2)) * y_rb, 0, 0));
         }
+        // one wave-uniform branch per option around a 16-element pass (not per element: the per-element
+        // form cost ~20k cycles of scalar branching per block); the order of operations is the desc's
+        float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[m][n][r] + bi[r];
-          if (p.res && !p.res_after) v += p.res_scale * rv[r];
-          if (p.ch_scale) v = v * sc[r] + sh[r];
-          if (p.relu) v = v > 0.f ? v : 0.f;
-          if (p.gelu) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-          if (p.res && p.res_after) v += p.res_scale * rv[r];
-          if (p.accum) v = yv[r] + v;
-          if (p.accum_div != 0.f) v = v / p.accum_div;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
-                                                yoff + ((r & 3) + 8 * (r >> 2)) * y_rb, 0, 0);
+        for (int r = 0; r < 16; ++r) v[r] = acc[m][n][r] + bi[r];
+        if (p.res && !p.res_after) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += p.res_scale * rv[r];
+        }
+        if (p.ch_scale) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = v[r] * sc[r] + sh[r];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
+        if (p.gelu) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            v[r] = v[r] * 0.5f * (1.0f + erff(v[r] * 0.70710678118654752440f));
+          }
+        }
+        if (p.res && p.res_after) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += p.res_scale * rv[r];
+        }
+        if (p.accum) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = yv[r] + v[r];
+        }
+        if (p.accum_div != 0.f) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = v[r] / p.accum_div;
+        }
+        if (!p.no_y) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs,
+                                                  yoff + ((r & 3) + 8 * (r >> 2)) * y_rb, 0, 0);
+        }
+        if (p.y16) {
+          // D layout: rows 8*rg + 4*lh + k (k < 4) of this lane = 8 bytes of the 16-byte unit
+          // (chunk = row/16, half = rg & 1) at its column
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int chunk = ((co_w + m * 32) >> 4) + (rg >> 1);
+            if (chunk * 16 >= p.rows_g) continue;   // wave-uniform: padding rows of a 32-row tile
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float t = v[4 * rg + k];
+              u[k] = t > 0.f ? t : t * p.y16_slope;
+            }
+            const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+            const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+            const unsigned off = qok ? (unsigned)(((chunk * 4 + (rg & 1)) * p.T_q + q) * 16 + 8 * lh) : OOB;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 hv;
+            hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
+            __builtin_amdgcn_raw_buffer_store_b64(hv, y16rs, off, 0, 0);
+            if (p.y16_f8) {
+              // planes 2 / 3 of the chunk: one byte per channel, these four channels = bytes 8*(rg&1) + 4*lh ..
+              const float hf0 = (float)h01[0], hf1 = (float)h01[1], hf2 = (float)h23[0], hf3 = (float)h23[1];
+              const unsigned x8h = pack_e4m3x4(hf0, hf1, hf2, hf3);
+              const unsigned x8l = pack_e4m3x4((u[0] - hf0) * F8_XLO_SCALE, (u[1] - hf1) * F8_XLO_SCALE,
+                                               (u[2] - hf2) * F8_XLO_SCALE, (u[3] - hf3) * F8_XLO_SCALE);
+              const unsigned off8 = qok ? (unsigned)(((chunk * 4 + 2) * p.T_q + q) * 16 + 8 * (rg & 1) + 4 * lh) : OOB;
+              __builtin_amdgcn_raw_buffer_store_b32(x8h, y16rs, off8, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(x8l, y16rs, off8, p.T_q * 16, 0);
+            } else {
+              const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+              const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+              u32x2 lv;
+              lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
+              __builtin_amdgcn_raw_buffer_store_b64(lv, y16rs, off, 2 * p.T_q * 16, 0);
+            }
+          }
         }
       }
     }
@@ -422,45 +568,47 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) 
           wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                                                  wrs, (co_w + r) * 16 + seg * seg_bytes, chunk * (KS * 4) * seg_bytes, 0));
       }
-      float stg[NIT][8];
+      {
+        float stg[NIT][8];
 #pragma unroll
-      for (int ii = 0; ii < NIT; ++ii) {
-        const int it = 2 * ii + sp;
-        const int xi = xi0 + lane + 64 * it;
-        const unsigned voff = (it < XWI && xi >= 0 && xi < p.T_in) ? (unsigned)(xi * 4) : 0x80000000u;
+        for (int ii = 0; ii < NIT; ++ii) {
+          const int it = 2 * ii + sp;
+          const int xi = xi0 + lane + 64 * it;
+          const unsigned voff = (it < XWI && xi >= 0 && xi < p.T_in) ? (unsigned)(xi * 4) : 0x80000000u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int ci = c0 + 8 * sh + j;
-          float v = 0.f;
-          if (ci < p.cin_g) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, ci * x_row_bytes, 0));
-          stg[ii][j] = v;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < W_IT; ++i) {
-        const int u = tid + 256 * i;
-        if (u < W_UNITS) ldsw[u] = wst[i];
-      }
-#pragma unroll
-      for (int ii = 0; ii < NIT; ++ii) {
-        const int it = 2 * ii + sp;
-        if (it < XWI) {
-          unsigned hi[4], lo[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float x0 = stg[ii][2 * j], x1 = stg[ii][2 * j + 1];
-            if (p.in_lrelu) {
-              x0 = x0 > 0.f ? x0 : x0 * p.in_slope;
-              x1 = x1 > 0.f ? x1 : x1 * p.in_slope;
-            }
-            const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-            const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
-            hi[j] = __builtin_bit_cast(unsigned, h);
-            lo[j] = __builtin_bit_cast(unsigned, l);
+          for (int j = 0; j < 8; ++j) {
+            const int ci = c0 + 8 * sh + j;
+            float v = 0.f;
+            if (ci < p.cin_g) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, ci * x_row_bytes, 0));
+            stg[ii][j] = v;
           }
-          const int col = lane + 64 * it;
-          ldsx[(0 * 2 + sh) * XWP + col] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-          ldsx[(1 * 2 + sh) * XWP + col] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+          const int u = tid + 256 * i;
+          if (u < W_UNITS) ldsw[u] = wst[i];
+        }
+#pragma unroll
+        for (int ii = 0; ii < NIT; ++ii) {
+          const int it = 2 * ii + sp;
+          if (it < XWI) {
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float x0 = stg[ii][2 * j], x1 = stg[ii][2 * j + 1];
+              if (p.in_lrelu) {
+                x0 = x0 > 0.f ? x0 : x0 * p.in_slope;
+                x1 = x1 > 0.f ? x1 : x1 * p.in_slope;
+              }
+              const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+              const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+              hi[j] = __builtin_bit_cast(unsigned, h);
+              lo[j] = __builtin_bit_cast(unsigned, l);
+            }
+            const int col = lane + 64 * it;
+            ldsx[(0 * 2 + sh) * XWP + col] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            ldsx[(1 * 2 + sh) * XWP + col] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+          }
         }
       }
     }
@@ -493,6 +641,192 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) 
     }
   }
   conv_epilogue<MT, NT>(p, acc, b, g, co_w, q_w, l31, lh);
+
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-plane input (x16): the B operand arrives as ready hi|lo f16 planes, staging is a 16-byte copy.
+// Software-pipelined over K-chunks through registers: chunk c+1's global loads (weights + planes,
+// W_IT + XWI 16-byte loads per lane) are issued right after chunk c's tile is published in LDS and
+// stay in flight during its MFMA phase; during the LAST chunk's MFMA phase the same registers
+// prefetch the residual the epilogue adds.  Measured with s_memtime stamps (tools/stamp_conv.hip) the
+// un-pipelined form spent 1.7-2.7k cycles per chunk waiting on loads and 22-32k cycles in the epilogue
+// against a 4.2k-cycle MFMA phase (k = 11).
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, int KS, int XWI, bool F8>
+__global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  constexpr int CO_B = 32 * MT;
+  constexpr int T_B = 128 * NT;
+  constexpr int XWP = 64 * XWI;
+  constexpr int W_UNITS = KS * 4 * CO_B;
+  constexpr int W_IT = (W_UNITS + 255) / 256;
+  uint4* ldsx = lds4;                     // [4][XWP]
+  uint4* ldsw = lds4 + 4 * XWP;           // [KS][2][2][CO_B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+  const int b = blockIdx.z;
+  const int co_w = blockIdx.y * CO_B;
+  const int q_b = blockIdx.x * T_B;
+  const int q_w = q_b + wave * (32 * NT);
+  const int xi0 = q_b - p.pad_left;
+  const int nch = p.cin_pad / CI_CHUNK;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.x16 + (long long)b * p.cin_g * p.T_in * 4), 0, (unsigned)(p.cin_g * p.T_in * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
+  const int seg_bytes = p.co_pad * 16;
+  const int pl = __builtin_amdgcn_readfirstlane(wave);    // plane (part*2 + half) this wave copies
+  const int x_chunk_bytes = 4 * p.T_in * 16;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  uint4 wst[W_IT], xst[XWI];
+  auto issue_loads = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + 256 * i;
+      const int seg = u / CO_B, r = u % CO_B;
+      wst[i] = make_uint4(0, 0, 0, 0);
+      if (u < W_UNITS)
+        wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               wrs, (co_w + r) * 16 + seg * seg_bytes, chunk * (KS * 4) * seg_bytes, 0));
+    }
+#pragma unroll
+    for (int it = 0; it < XWI; ++it) {
+      const int xi = xi0 + lane + 64 * it;
+      const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((pl * p.T_in + xi) * 16) : 0x80000000u;
+      xst[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, chunk * x_chunk_bytes, 0));
+    }
+  };
+  auto publish = [&]() {
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + 256 * i;
+      if (u < W_UNITS) ldsw[u] = wst[i];
+    }
+#pragma unroll
+    for (int it = 0; it < XWI; ++it) ldsx[pl * XWP + lane + 64 * it] = xst[it];
+  };
+  const uint4* xb = ldsx + lh * XWP + wave * (32 * NT) + l31;
+  const uint4* wb = ldsw + lh * CO_B + l31;
+  // F8: per-lane E8M0 scale bytes of the cross-term MFMA (lanes 0-31: W_lo8 . x_hi8, lanes 32-63: W_hi8 . x_lo8)
+  const int sc_a = lh ? F8_E_WHI : F8_E_WLO;
+  const int sc_b = lh ? F8_E_XLO : F8_E_XHI;
+  auto mfma_phase = [&]() {
+    if constexpr (F8) {
+      // hi*hi on the f16 MFMA per tap; both cross terms of a PAIR of taps in one block-scaled e4m3
+      // MFMA (K = 64 = 2 terms x 2 taps x 16 channels) at twice the f16 rate per K
+#pragma unroll
+      for (int tp = 0; tp < (KS + 1) / 2; ++tp) {
+        const int t0 = 2 * tp, t1 = 2 * tp + 1;
+        const bool two = t1 < KS;
+        h8 a_h0[MT], a_h1[MT], b_h0[NT], b_h1[NT];
+        uint4 a8_0[MT], a8_1[MT], b8_0[NT], b8_1[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          a_h0[m] = __builtin_bit_cast(h8, wb[(t0 * 4 + 0) * CO_B + m * 32]);
+          a8_0[m] = wb[(t0 * 4 + 2) * CO_B + m * 32];
+          if (two) {
+            a_h1[m] = __builtin_bit_cast(h8, wb[(t1 * 4 + 0) * CO_B + m * 32]);
+            a8_1[m] = wb[(t1 * 4 + 2) * CO_B + m * 32];
+          } else {
+            a8_1[m] = make_uint4(0, 0, 0, 0);   // phantom tap: zero weights
+          }
+        }
+        const uint4* x0 = xb + t0 * p.dil;
+        const uint4* x1 = xb + t1 * p.dil;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          b_h0[n] = __builtin_bit_cast(h8, x0[n * 32]);
+          b8_0[n] = x0[2 * XWP + n * 32];
+          if (two) {
+            b_h1[n] = __builtin_bit_cast(h8, x1[n * 32]);
+            b8_1[n] = x1[2 * XWP + n * 32];
+          } else {
+            b8_1[n] = b8_0[n];                  // finite bytes against the zero weights
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h0[m], b_h0[n], acc[m][n], 0, 0, 0);
+            if (two) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h1[m], b_h1[n], acc[m][n], 0, 0, 0);
+            const i32x8 a8 = {(int)a8_0[m].x, (int)a8_0[m].y, (int)a8_0[m].z, (int)a8_0[m].w,
+                              (int)a8_1[m].x, (int)a8_1[m].y, (int)a8_1[m].z, (int)a8_1[m].w};
+            const i32x8 b8 = {(int)b8_0[n].x, (int)b8_0[n].y, (int)b8_0[n].z, (int)b8_0[n].w,
+                              (int)b8_1[n].x, (int)b8_1[n].y, (int)b8_1[n].z, (int)b8_1[n].w};
+            acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[m][n], 0, 0, 0, sc_a, 0, sc_b);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        h8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          a_hi[m] = __builtin_bit_cast(h8, wb[(t * 4 + 0) * CO_B + m * 32]);
+          a_lo[m] = __builtin_bit_cast(h8, wb[(t * 4 + 2) * CO_B + m * 32]);
+        }
+        const uint4* xt = xb + t * p.dil;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          b_hi[n] = __builtin_bit_cast(h8, xt[n * 32]);
+          b_lo[n] = __builtin_bit_cast(h8, xt[2 * XWP + n * 32]);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[m], b_hi[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[m], b_lo[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[m], b_hi[n], acc[m][n], 0, 0, 0);
+          }
+      }
+    }
+  };
+
+  int chunk = 0;
+  SAT_STAMP_BLOCK(6, __builtin_amdgcn_s_memrealtime());
+  SAT_STAMP_BLOCK(7, ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492));
+  issue_loads(0);
+  for (; chunk < nch - 1; ++chunk) {
+    __syncthreads();   // every wave is done reading the previous tile
+    SAT_STAMP(0);
+    publish();
+    SAT_STAMP(2);
+    __syncthreads();
+    SAT_STAMP(3);
+    issue_loads(chunk + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_phase();
+    SAT_STAMP(4);
+  }
+  __syncthreads();
+  SAT_STAMP(0);
+  publish();
+  SAT_STAMP(2);
+  __syncthreads();
+  SAT_STAMP(3);
+  float rpre[MT][NT][16];
+  if (p.res) epilogue_prefetch_res<MT, NT>(p, rpre, b, 0, co_w, q_w, l31, lh);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_phase();
+  SAT_STAMP(4);
+  conv_epilogue<MT, NT, true>(p, acc, b, 0, co_w, q_w, l31, lh, 32, 0x7fffffff, rpre);
+  SAT_STAMP(5);
+  SAT_STAMP_BLOCK(14, __builtin_amdgcn_s_memrealtime());
 }
 
 template <int MT, int NT, int KS>
@@ -501,6 +835,9 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
   constexpr int T_B = 128 * NT;
   constexpr int XWI = (T_B + (KS - 1) * 5 + 63) / 64;
   ConvArgs p = a;
+#ifdef SAT_STAMPS
+  p.dbg = g_stamp_buffer;
+#endif
   p.xw = T_B + (p.ksize - 1) * p.dil;
   if (p.xw > 64 * XWI) {
     set_error("conv1d(f16x3): dilation %d too large for the %d-tap kernel", p.dil, p.ksize);
@@ -508,7 +845,8 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
   }
   p.co_tiles_g = ceil_div(p.rows_g, CO_B);
   const size_t lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * CO_B) * 16;
-  auto kern = conv1d_f16x3_kernel<MT, NT, KS, XWI>;
+  auto kern = !p.x16 ? conv1d_f16x3_kernel<MT, NT, KS, XWI>
+              : p.f8 ? conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, true> : conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false>;
   if (lds_bytes > 64 * 1024)
     SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   dim3 grid(ceil_div(p.T_q, T_B), p.co_tiles_g * groups, B);
@@ -545,7 +883,7 @@ constexpr int FP_TO = 224;    // output positions per block
 constexpr int FP_W1 = 256;    // t1 window: [t0 - 16, t0 + 240)
 constexpr int FP_OFF = 16;
 
-template <int KS, int XWI>
+template <int KS, int XWI, bool X16IN>
 __global__ void __launch_bounds__(256, 2) resblock_pair_f16x3_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   constexpr int CO_B = 32;
@@ -567,8 +905,11 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_f16x3_kernel(const ConvA
   const int h2 = (KS - 1) / 2;
   const int xi0 = t0 - FP_OFF - p.pad_left;   // first input position of the staged tile (pad_left = conv1 halo)
 
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.x + (long long)b * p.x_bs), 0, (unsigned)((long long)p.cin_g * p.x_cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = X16IN
+      ? __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x16 + (long long)b * p.cin_g * p.T_in * 4), 0,
+                                          (unsigned)(p.cin_g * p.T_in * 4), 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.x + (long long)b * p.x_bs), 0, (unsigned)((long long)p.cin_g * p.x_cs * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
   const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)p.w_gs, 0x00020000);
   const int sh = __builtin_amdgcn_readfirstlane(wave & 1);
@@ -603,6 +944,19 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_f16x3_kernel(const ConvA
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int c0 = chunk * CI_CHUNK;
     __syncthreads();
+    if constexpr (X16IN) {
+      uint4 xst[XWI];
+      const int pl = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+      for (int it = 0; it < XWI; ++it) {
+        const int xi = xi0 + lane + 64 * it;
+        const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((pl * p.T_in + xi) * 16) : 0x80000000u;
+        xst[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, chunk * 4 * p.T_in * 16, 0));
+      }
+      stage_w(w1rs, chunk);
+#pragma unroll
+      for (int it = 0; it < XWI; ++it) ldsx[pl * XWP + lane + 64 * it] = xst[it];
+    } else
     {
       float stg[NIT][8];
 #pragma unroll
@@ -728,13 +1082,58 @@ static int launch_pair(const ConvArgs& a, int B, hipStream_t s) {
   }
   p.co_tiles_g = 1;
   const size_t lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * 32 + (size_t)(p.cin_pad / CI_CHUNK) * 4 * FP_W1) * 16;
-  auto kern = resblock_pair_f16x3_kernel<KS, XWI>;
+  auto kern = p.x16 ? resblock_pair_f16x3_kernel<KS, XWI, true> : resblock_pair_f16x3_kernel<KS, XWI, false>;
   if (lds_bytes > 64 * 1024)
     SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   dim3 grid(ceil_div(p.T_q, FP_TO), 1, B);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
   SAT_LAUNCH_CHECK("resblock_pair_f16x3_kernel");
   return SAT_OK;
+}
+
+// f32 [B][C][T] -> split planes of lrelu(x, slope): thread = (utterance, 8-channel group, position);
+// 8 coalesced dword loads, two coalesced 16-byte stores (HBM-streaming)
+__global__ void __launch_bounds__(256) act_split_kernel(const float* __restrict__ x, uint4* __restrict__ y,
+                                                        int C, int T, float slope, int f8) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int cg = blockIdx.y;            // 8-channel group: chunk = cg >> 1, half = cg & 1
+  const int b = blockIdx.z;
+  if (t >= T) return;
+  const float* xr = x + ((long long)b * C + cg * 8) * T + t;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = xr[(long long)j * T];
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x0 = v[2 * j], x1 = v[2 * j + 1];
+    x0 = x0 > 0.f ? x0 : x0 * slope;
+    x1 = x1 > 0.f ? x1 : x1 * slope;
+    const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+    hi[j] = __builtin_bit_cast(unsigned, h);
+    lo[j] = __builtin_bit_cast(unsigned, l);
+  }
+  uint4* yb = y + (long long)b * (C / 4) * T;                     // C*T*4 bytes per utterance
+  const long long u = ((long long)((cg >> 1) * 4 + (cg & 1))) * T + t;
+  yb[u] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  if (!f8) {
+    yb[u + 2LL * T] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    return;
+  }
+  // planes 2 / 3: e4m3(hi) and e4m3(lo * 2^10), one byte per channel; this thread owns 8 of the 16 bytes
+  float hf[8], lf[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float xv = v[j];
+    xv = xv > 0.f ? xv : xv * slope;
+    const auto hh = __builtin_bit_cast(decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)), hi[j >> 1]);
+    hf[j] = (float)hh[j & 1];
+    lf[j] = (xv - hf[j]) * F8_XLO_SCALE;
+  }
+  uint2* y8 = (uint2*)(yb + ((long long)((cg >> 1) * 4 + 2)) * T + t) + (cg & 1);
+  *y8 = make_uint2(pack_e4m3x4(hf[0], hf[1], hf[2], hf[3]), pack_e4m3x4(hf[4], hf[5], hf[6], hf[7]));
+  y8[2LL * T] = make_uint2(pack_e4m3x4(lf[0], lf[1], lf[2], lf[3]), pack_e4m3x4(lf[4], lf[5], lf[6], lf[7]));
 }
 
 template <int MT, int NT, int WM, int WN, int KS, bool S1, int XWI>
@@ -803,7 +1202,7 @@ extern "C" int sat_conv1d_packed_dims(int C_in, int C_out, int up, int groups, i
 
 extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed,
                               float* y, void* stream) {
-  SAT_REQUIRE(d && x && w_packed && y, "conv1d: null pointer");
+  SAT_REQUIRE(d && w_packed && (x || d->x_split) && (y || (d->no_y && d->y_split)), "conv1d: null pointer");
   SAT_REQUIRE(d->B > 0 && d->C_in > 0 && d->C_out > 0 && d->T_in > 0 && d->T_q > 0, "conv1d: empty shape");
   SAT_REQUIRE(d->ksize >= 1 && d->dilation >= 1 && d->stride >= 1 && d->up >= 1 && d->groups >= 1,
               "conv1d: bad ksize/dilation/stride/up/groups");
@@ -853,9 +1252,27 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     a.fast_epi = d->up == 1 && ylim < (1LL << 31) && rlim < (1LL << 31) && ylim > 0;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (d->mode == SAT_CONV_F16X3) {
+  SAT_REQUIRE(d->mode != SAT_CONV_F32 || (!d->x_split && !d->y_split && !d->no_y), "conv1d: split planes need a split-f16 mode");
+  if (d->mode == SAT_CONV_F16X3 || d->mode == SAT_CONV_F16F8) {
+    a.f8 = d->mode == SAT_CONV_F16F8;
+    SAT_REQUIRE(!a.f8 || d->x_split, "conv1d(f16f8): the input must be split planes (SAT_SPLIT_F8)");
+    SAT_REQUIRE(d->y_split_format >= 0 && d->y_split_format <= 2, "conv1d: unknown y_split_format");
+    a.y16_f8 = d->y_split_format == 0 ? a.f8 : d->y_split_format == 2;
     SAT_REQUIRE(d->stride == 1, "conv1d(f16x3): stride 1 only");
     SAT_REQUIRE((long long)a.cin_g * a.x_cs * 4 < (1LL << 31), "conv1d(f16x3): input slab too large for 31-bit offsets");
+    a.x16 = d->x_split;
+    a.y16 = d->y_split;
+    a.y16_slope = d->y_split_slope;
+    a.no_y = d->no_y;
+    if (a.x16)
+      SAT_REQUIRE(d->groups == 1 && a.cin_g % 16 == 0 && (long long)a.cin_g * a.T_in * 4 < (1LL << 31),
+                  "conv1d(f16x3): x_split needs groups 1, C_in %% 16 == 0 and a slab below 2 GiB");
+    if (a.y16 || a.no_y) {
+      SAT_REQUIRE(a.fast_epi && d->groups == 1 && a.rows_g % 16 == 0 && (long long)a.rows_g * a.T_q * 4 < (1LL << 31),
+                  "conv1d(f16x3): y_split / no_y need up 1, groups 1, C_out %% 16 == 0 and a slab below 2 GiB");
+      if (a.no_y) a.y = (float*)a.y16, a.accum = 0;   // descriptor base only; nothing is loaded or stored through it
+      SAT_REQUIRE(!(d->no_y && d->accum), "conv1d: no_y with accum");
+    }
     a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;   // bytes per group
     if (a.rows_g > 32) return launch_f16x3_ks<2, 2>(a, d->B, d->groups, s);   // 64 rows x 256 positions
     return launch_f16x3_ks<1, 4>(a, d->B, d->groups, s);                       // 32 rows x 512 positions
@@ -877,6 +1294,7 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
 extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
                                        const float* bias1, const void* w2_packed, float* y, void* stream) {
   SAT_REQUIRE(d && x && w1_packed && w2_packed && bias1 && y && d->bias, "resblock_pair: null pointer");
+  SAT_REQUIRE(!d->no_y, "resblock_pair: the f32 output is the next step's residual");
   SAT_REQUIRE(d->C_in == d->C_out && d->C_in <= 32 && d->C_in % 16 == 0, "resblock_pair: C must be 16 or 32");
   SAT_REQUIRE(d->groups == 1 && d->up == 1 && d->stride == 1 && d->T_q == d->T_in, "resblock_pair: same-length conv pair only");
   SAT_REQUIRE(d->ksize == 3 || d->ksize == 7 || d->ksize == 11, "resblock_pair: kernel size %d not instantiated", d->ksize);
@@ -906,10 +1324,23 @@ extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x,
   SAT_REQUIRE((long long)a.cin_g * a.x_cs * 4 < (1LL << 31) && (long long)a.rows_g * a.y_cs * 4 < (1LL << 31),
               "resblock_pair: slab too large for 31-bit offsets");
   a.fast_epi = 1;
+  a.x16 = d->x_split;
+  a.y16 = d->y_split;
+  a.y16_slope = d->y_split_slope;
   hipStream_t s = (hipStream_t)stream;
   switch (a.ksize) {
     case 3: return launch_pair<3>(a, d->B, s);
     case 7: return launch_pair<7>(a, d->B, s);
     default: return launch_pair<11>(a, d->B, s);
   }
+}
+
+extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, int T, float slope, int format, void* stream) {
+  SAT_REQUIRE(x && x_split, "act_split: null pointer");
+  SAT_REQUIRE(format == SAT_SPLIT_F16 || format == SAT_SPLIT_F8, "act_split: unknown format");
+  SAT_REQUIRE(B > 0 && C > 0 && T > 0 && C % 16 == 0 && B < 65536, "act_split: unsupported shape B=%d C=%d T=%d", B, C, T);
+  dim3 grid(ceil_div(T, 256), C / 8, B);
+  hipLaunchKernelGGL(act_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (uint4*)x_split, C, T, slope, format == SAT_SPLIT_F8);
+  SAT_LAUNCH_CHECK("act_split_kernel");
+  return SAT_OK;
 }

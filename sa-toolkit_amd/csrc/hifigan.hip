@@ -89,6 +89,7 @@ struct sat_hifigan {
   };
   std::vector<Conv> convs;
   int fuse_pairs = 1;
+  int split_acts = 1;
   int n_ups() const { return (int)up_rates.size(); }
   int n_rbk() const { return (int)rb_kernels.size(); }
   int id_up(int i) const { return 1 + i; }
@@ -137,7 +138,7 @@ extern "C" int sat_hifigan_num_convs(const sat_hifigan* h) { return h ? (int)h->
 
 extern "C" int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const void* w_packed, const float* bias, int mode) {
   SAT_REQUIRE(h && conv_id >= 0 && conv_id < (int)h->convs.size() && w_packed && bias, "hifigan_set_conv: bad arguments");
-  SAT_REQUIRE(mode == SAT_CONV_F32 || mode == SAT_CONV_F16X3, "hifigan_set_conv: unknown mode");
+  SAT_REQUIRE(mode == SAT_CONV_F32 || mode == SAT_CONV_F16X3 || mode == SAT_CONV_F16F8, "hifigan_set_conv: unknown mode");
   SAT_REQUIRE(conv_id != h->id_post() || mode == SAT_CONV_F32, "hifigan_set_conv: the output stage is f32 only");
   h->convs[conv_id].w = w_packed;
   h->convs[conv_id].bias = bias;
@@ -157,9 +158,23 @@ static size_t hifigan_max_elems(const sat_hifigan* h, int B, int T) {
   return mx * B;
 }
 
+// every conv but the output stage on the split-f16 kernel: activations travel as split planes
+static bool hifigan_split_acts(const sat_hifigan* h) {
+  if (!h->split_acts) return false;
+  // conv_pre stages f32 input itself (split-f16 kernel); every later conv reads split planes, all in one mode
+  if (h->convs[0].mode != SAT_CONV_F16X3) return false;
+  for (int i = 1; i < h->id_post(); ++i)
+    if (h->convs[i].mode != h->convs[1].mode || h->convs[i].mode == SAT_CONV_F32) return false;
+  int C = h->c0;
+  for (int i = 0; i < h->n_ups(); ++i) C /= 2;
+  return C % 16 == 0 && h->c0 % 16 == 0;
+}
+
+constexpr int WS_SLOTS = 10;
+
 extern "C" size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
-  return 6 * align_up(hifigan_max_elems(h, B, T) * sizeof(float), 256);
+  return WS_SLOTS * align_up(hifigan_max_elems(h, B, T) * sizeof(float), 256);
 }
 
 extern "C" void sat_hifigan_destroy(sat_hifigan* h) { delete h; }
@@ -167,6 +182,7 @@ extern "C" void sat_hifigan_destroy(sat_hifigan* h) { delete h; }
 extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int value) {
   SAT_REQUIRE(h && name, "hifigan_set_option: null pointer");
   if (std::string(name) == "fuse_pairs") { h->fuse_pairs = value; return SAT_OK; }
+  if (std::string(name) == "split_acts") { h->split_acts = value; return SAT_OK; }
   set_error("hifigan_set_option: unknown option %s", name);
   return SAT_ERR_INVALID;
 }
@@ -221,6 +237,123 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
     d.res_tstride = 1;
     return d;
   };
+
+  if (hifigan_split_acts(h)) {
+    // ---- split-plane pipeline: every producer writes the hi|lo f16 planes of leaky_relu(y, 0.1) the
+    // consumer will multiply with, so inputs are staged with 16-byte copies and converted once ----
+    const int cmode = h->convs[1].mode;                                // SAT_CONV_F16X3 or SAT_CONV_F16F8
+    const int yfmt = cmode == SAT_CONV_F16F8 ? 2 : 1;                  // plane format every consumer reads
+    char* ws = (char*)workspace;
+    float* Hf = (float*)(ws + 0 * slot);   void* Hs = ws + 1 * slot;    // upsampled x (residual + planes)
+    void* T1s = ws + 2 * slot;                                         // inner activation of a pair
+    float* RAf = (float*)(ws + 3 * slot);  void* RAs = ws + 4 * slot;
+    float* RBf = (float*)(ws + 5 * slot);  void* RBs = ws + 6 * slot;
+    float* ACCf = (float*)(ws + 7 * slot);                             // MRF sum
+    void* XS = ws + 8 * slot;                                          // stage input planes
+    void* XSn = ws + 9 * slot;
+    {
+      sat_conv1d_desc d = base_desc(h->in_ch, h->c0, T, T, 1);
+      d.ksize = 7;
+      d.pad_left = 3;
+      d.bias = h->convs[0].bias;
+      d.mode = SAT_CONV_F16X3;
+      d.y_split = XS;
+      d.y_split_slope = 0.1f;
+      d.y_split_format = yfmt;
+      d.no_y = 1;
+      int s = sat_conv1d_f32(&d, x, h->convs[0].w, nullptr, stream);
+      if (s != SAT_OK) return s;
+    }
+    int C = h->c0, Tc = T;
+    const int nk = h->n_rbk();
+    for (int i = 0; i < h->n_ups(); ++i) {
+      const int u = h->up_rates[i], k = h->up_kernels[i];
+      const int Cn = C / 2, Tn = Tc * u;
+      const bool last_stage = i == h->n_ups() - 1;
+      {
+        int lo, hi;
+        phase_window(k, u, (k - u) / 2, &lo, &hi);
+        sat_conv1d_desc d = base_desc(C, Cn, Tc, Tc, u);
+        d.ksize = hi - lo + 1;
+        d.pad_left = -lo;
+        d.bias = h->convs[h->id_up(i)].bias;
+        d.mode = cmode;
+        d.x_split = XS;
+        int s = sat_conv1d_f32(&d, nullptr, h->convs[h->id_up(i)].w, Hf, stream);
+        if (s != SAT_OK) return s;
+        // the polyphase epilogue scatters rows over time phases: split in a streaming pass
+        s = sat_act_split_f32(Hf, Hs, B, Cn, Tn, 0.1f, cmode == SAT_CONV_F16F8 ? SAT_SPLIT_F8 : SAT_SPLIT_F16, stream);
+        if (s != SAT_OK) return s;
+      }
+      for (int j = 0; j < nk; ++j) {
+        const int rk = h->rb_kernels[j];
+        const float* rf = Hf;
+        const void* rs = Hs;
+        for (int pair = 0; pair < 3; ++pair) {
+          const int dil = h->rb_dil[j * 3 + pair];
+          const auto& cv1 = h->convs[h->id_rb(i, j, pair, 0)];
+          const auto& cv2 = h->convs[h->id_rb(i, j, pair, 1)];
+          sat_conv1d_desc d2 = base_desc(Cn, Cn, Tn, Tn, 1);
+          d2.ksize = rk;
+          d2.dilation = 1;
+          d2.pad_left = (rk - 1) / 2;
+          d2.in_lrelu = 1;
+          d2.in_slope = 0.1f;
+          d2.bias = cv2.bias;
+          d2.mode = cmode;
+          d2.res = rf;
+          d2.res_scale = 1.f;
+          d2.res_cstride = Tn;
+          d2.res_bstride = (int64_t)Cn * Tn;
+          d2.y_split_slope = 0.1f;
+          float* dstf;
+          void* dsts;
+          if (pair < 2) {
+            dstf = (rf == RAf) ? RBf : RAf;
+            dsts = (rf == RAf) ? RBs : RAs;
+          } else {
+            dstf = ACCf;
+            d2.accum = j > 0;
+            d2.accum_div = (j == nk - 1) ? (float)nk : 0.f;
+            dsts = (j == nk - 1 && !last_stage) ? XSn : nullptr;   // the next stage's input planes
+          }
+          d2.y_split = dsts;
+          int s;
+          if (Cn <= 32 && h->fuse_pairs && cmode == SAT_CONV_F16X3) {
+            sat_conv1d_desc df = d2;
+            df.dilation = dil;
+            df.x_split = rs;
+            s = sat_resblock_pair_f16x3(&df, rf, cv1.w, cv1.bias, cv2.w, dstf, stream);
+            if (s != SAT_OK) return s;
+          } else {
+            sat_conv1d_desc d1 = base_desc(Cn, Cn, Tn, Tn, 1);
+            d1.ksize = rk;
+            d1.dilation = dil;
+            d1.pad_left = (rk * dil - dil) / 2;
+            d1.bias = cv1.bias;
+            d1.mode = cmode;
+            d1.x_split = rs;
+            d1.y_split = T1s;
+            d1.y_split_slope = 0.1f;
+            d1.no_y = 1;
+            s = sat_conv1d_f32(&d1, nullptr, cv1.w, nullptr, stream);
+            if (s != SAT_OK) return s;
+            d2.x_split = T1s;
+            s = sat_conv1d_f32(&d2, nullptr, cv2.w, dstf, stream);
+            if (s != SAT_OK) return s;
+          }
+          rf = dstf;
+          rs = dsts;
+        }
+      }
+      void* t = XS;
+      XS = XSn;
+      XSn = t;
+      C = Cn;
+      Tc = Tn;
+    }
+    return sat_hifigan_convpost_f32(ACCf, (const float*)h->convs[h->id_post()].w, h->convs[h->id_post()].bias, y, B, C, Tc, stream);
+  }
 
   // conv_pre (archi.py:78)
   {

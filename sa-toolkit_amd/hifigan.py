@@ -15,8 +15,12 @@ from .params import CoreHifiGanParams
 
 class CoreHifiGan(CoreHifiGanParams):
     #: matrix-product arithmetic of the generator convs: "f16x3" (split-f16 on the f16 matrix cores,
-    #: ~2^-21 relative per product) or "f32" (exact f32 MFMA).  The output stage is always f32.
+    #: ~2^-21 relative per product), "f16f8" (hi*hi in f16, the cross terms on the block-scaled e4m3
+    #: MFMA, ~2^-15 per product: 3e-6 RMS on the waveform against 1.5e-7) or "f32" (exact f32 MFMA).
+    #: The output stage is always f32.
     precision = os.environ.get("SATOOLS_AMD_GEN_PRECISION", "f16x3")
+    #: hand activations between layers as split planes (csrc/hifigan.hip); 0 = f32 tensors
+    split_acts = int(os.environ.get("SATOOLS_AMD_GEN_SPLIT_ACTS", "1"))
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -27,7 +31,7 @@ class CoreHifiGan(CoreHifiGanParams):
 
     # -- device-side weight cache ---------------------------------------------------------
     def _param_key(self):
-        return (self.precision,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        return (self.precision, self.split_acts) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
 
     def invalidate(self):
         self._packed_key = None
@@ -59,9 +63,13 @@ class CoreHifiGan(CoreHifiGanParams):
         for i, m in enumerate(mods):
             w = m.folded_weight().to(device=device, dtype=torch.float32)
             b = m.bias.detach().to(device=device, dtype=torch.float32).contiguous()
-            split = self.precision == "f16x3"
+            if self.precision not in ("f16x3", "f16f8", "f32"):
+                raise _lib.SatError(f"unknown generator precision {self.precision!r}")
+            split = self.precision != "f32"
             mode = _lib.CONV_F16X3 if split else _lib.CONV_F32
             pack = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight
+            if self.precision == "f16f8" and i >= 1:      # conv_pre stages the f32 input itself: split-f16
+                mode, pack = _lib.CONV_F16F8, packing.pack_conv_weight_f16f8
             if i == len(mods) - 1:
                 wp = w.reshape(w.shape[1], w.shape[2]).contiguous()  # conv_post: [C][7], f32 streaming kernel
                 mode = _lib.CONV_F32
@@ -73,6 +81,7 @@ class CoreHifiGan(CoreHifiGanParams):
                 wp = pack(w)
             packed.append((wp, b))
             check(l.sat_hifigan_set_conv(self._handle, i, ptr(wp), ptr(b), mode), "sat_hifigan_set_conv")
+        check(l.sat_hifigan_set_option(self._handle, b"split_acts", int(self.split_acts)), "sat_hifigan_set_option")
         self._packed = packed  # keeps the device buffers alive
         self._packed_key = key
 

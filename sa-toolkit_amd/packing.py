@@ -64,3 +64,31 @@ def pack_conv_weight_f16x3(w: torch.Tensor, groups: int = 1, up: int = 1) -> tor
     hi = p.to(torch.float16)
     lo = (p - hi.to(torch.float32)).to(torch.float16)
     return torch.stack([hi, lo], dim=3).contiguous()                 # [g][nch][K][part][half][co][8]
+
+
+F8_W_HI_EXP, F8_W_LO_EXP, F8_X_LO_EXP = 6, 16, 10      # power-of-two scales of the e4m3 operands (csrc/conv1d_mfma.hip)
+
+
+def pack_conv_weight_f16f8(w: torch.Tensor, groups: int = 1, up: int = 1) -> torch.Tensor:
+    """packing for SAT_CONV_F16F8: w [rows, C_in/groups, K] f32 -> uint8
+    [g][cin_pad/16][K][4][co_pad][16 B] with the segments  hi f16 ch 0-7 | hi f16 ch 8-15 |
+    e4m3(lo * 2^16), 16 channels | e4m3(hi * 2^6), 16 channels   (hi = f16(w), lo = w - hi).
+    The fixed scales need |w| < 7 (448 / 2^6); larger weights are refused so the caller can fall back
+    to SAT_CONV_F16X3."""
+    if float(w.abs().max()) >= 7.0:
+        raise ValueError("pack_conv_weight_f16f8: |w| >= 7 does not fit the fixed e4m3 scale")
+    p = pack_conv_weight(w, groups=groups, up=up).cpu()             # [g][cin_pad][K][co_pad] f32
+    g, cin_pad, k, co_pad = p.shape
+    nch = cin_pad // 16
+    hi = p.to(torch.float16)
+    lo = p - hi.to(torch.float32)
+    hi16 = hi.reshape(g, nch, 2, 8, k, co_pad).permute(0, 1, 4, 2, 5, 3).contiguous()       # [g][nch][K][half][co][8] f16
+    seg01 = hi16.view(torch.uint8).reshape(g, nch, k, 2, co_pad, 16)
+
+    def e4m3(t, exp):                                                # [g][cin_pad][K][co] -> [g][nch][K][co][16] bytes
+        q = (t * float(2 ** exp)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        return q.reshape(g, nch, 16, k, co_pad).permute(0, 1, 3, 4, 2).contiguous()
+
+    seg2 = e4m3(lo, F8_W_LO_EXP).unsqueeze(3)
+    seg3 = e4m3(hi.to(torch.float32), F8_W_HI_EXP).unsqueeze(3)
+    return torch.cat([seg01, seg2, seg3], dim=3).contiguous().to(w.device)

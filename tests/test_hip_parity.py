@@ -253,6 +253,135 @@ def test_f0_norm_transform_matches_golden(gold):
     assert np.abs(x.cpu().numpy() - fx["quant16_awgn2_seed1234"][:, 0]).max() < 1e-6
 
 
+def test_act_split_planes():
+    """split planes: hi = f16(x) (round toward zero), lo = f16(x - hi); hi + lo reproduces lrelu(x) to 2^-21"""
+    ops, _ = _ops()
+    x = _rand(3, 32, 333, seed=7, scale=2.0)
+    s = ops.act_split(x.to(DEV), 0.1)
+    assert s.shape == (3, 2, 2, 2, 333, 8) and s.dtype == torch.float16
+    ref = F.leaky_relu(x, 0.1)
+    back = ops.unsplit(s).cpu()
+    assert (back - ref).abs().max() <= 2.0 ** -20 * ref.abs().max()
+    hi = ops.unsplit(torch.stack([s[:, :, 0], torch.zeros_like(s[:, :, 0])], 2)).cpu()
+    assert (hi.abs() <= ref.abs()).all()          # truncation toward zero
+
+
+@pytest.mark.parametrize("case", [(16, 16, 3, 1, 700), (32, 32, 7, 3, 600), (64, 64, 11, 1, 257), (256, 256, 11, 5, 250), (512, 256, 3, 1, 130)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv1d_split_planes_in_out(case):
+    """the split-plane hand-over is the same arithmetic as splitting inside the kernel: a conv fed with
+    act_split(lrelu(x)) is bit-identical to the conv that stages the f32 x itself, and the planes it
+    writes are bit-identical to act_split of its own f32 output"""
+    ops, packing = _ops()
+    cin, cout, k, d, T = case
+    x = _rand(2, cin, T, seed=1).to(DEV)
+    w = packing.pack_conv_weight_f16x3(_rand(cout, cin, k, seed=2, scale=1.0 / np.sqrt(cin * k)).to(DEV))
+    b = _rand(cout, seed=3).to(DEV)
+    res = _rand(2, cout, T, seed=4).to(DEV)
+    pl = (k * d - d) // 2
+    y0 = ops.conv1d(x, w, cout, k, bias=b, dilation=d, pad_left=pl, in_lrelu=0.1, res=res, mode=1)
+    ys = ops.split_like(2, cout, T, DEV)
+    y1 = ops.conv1d(x, w, cout, k, bias=b, dilation=d, pad_left=pl, res=res, mode=1,
+                    x_split=ops.act_split(x, 0.1), y_split=ys, y_split_slope=0.1)
+    assert torch.equal(y0, y1)
+    assert torch.equal(ys, ops.act_split(y0, 0.1))
+    # planes only (no f32 store): y untouched
+    y2 = torch.full_like(y0, 7.0)
+    ys2 = torch.zeros_like(ys)
+    ops.conv1d(x, w, cout, k, bias=b, dilation=d, pad_left=pl, res=res, mode=1, x_split=ops.act_split(x, 0.1),
+               y_split=ys2, y_split_slope=0.1, no_y=True, out=y2)
+    assert torch.equal(ys2, ys) and (y2 == 7.0).all()
+
+
+def _e4m3(t, exp=0):
+    return (t * 2.0 ** exp).clamp(-448, 448).to(torch.float32).to(torch.float8_e4m3fn)
+
+
+def test_act_split_f8_planes():
+    """SAT_SPLIT_F8: hi planes as in SAT_SPLIT_F16; unit 2 = e4m3(hi), unit 3 = e4m3(lo * 2^10), one byte per
+    channel, OCP e4m3 round-to-nearest-even like torch.float8_e4m3fn"""
+    ops, _ = _ops()
+    x = _rand(2, 32, 301, seed=11, scale=3.0)
+    s16 = ops.act_split(x.to(DEV), 0.1)
+    s8 = ops.act_split(x.to(DEV), 0.1, fmt=1)
+    assert torch.equal(s8[:, :, 0], s16[:, :, 0])
+    hi = ops.unsplit(torch.stack([s16[:, :, 0], torch.zeros_like(s16[:, :, 0])], 2)).cpu()      # [B][C][T]
+    lo = F.leaky_relu(x, 0.1) - hi
+    raw = s8.cpu().view(torch.uint8).reshape(2, 2, 2, 2, 301, 16)
+    got_h = raw[:, :, 1, 0].permute(0, 1, 3, 2).reshape(2, 32, 301)          # [B][chunk][T][16] -> [B][C][T]
+    got_l = raw[:, :, 1, 1].permute(0, 1, 3, 2).reshape(2, 32, 301)
+    assert torch.equal(got_h, _e4m3(hi).view(torch.uint8))
+    assert torch.equal(got_l, _e4m3(lo, 10).view(torch.uint8))
+
+
+@pytest.mark.parametrize("case", [(16, 16, 3, 1, 700), (32, 32, 7, 3, 600), (64, 64, 11, 1, 257), (128, 128, 3, 5, 260),
+                                  (256, 256, 7, 5, 125), (256, 256, 11, 3, 250), (512, 256, 3, 1, 130)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv1d_f16f8_matches_its_decomposition(case):
+    """SAT_CONV_F16F8 = hi*hi (f16 MFMA) + e4m3(W_lo 2^16) e4m3(x_hi) 2^-16 + e4m3(W_hi 2^6) e4m3(x_lo 2^10) 2^-16
+    (block-scaled e4m3 MFMA), f32 accumulation.  Tight: against that decomposition evaluated in f64
+    from the kernel's own input planes (pins operand order, scales and rounding).  Loose: against the
+    exact product, where the e4m3 cross terms leave ~2^-15 per product"""
+    ops, packing = _ops()
+    cin, cout, k, d, T = case
+    x = _rand(2, cin, T, seed=1)
+    w = _rand(cout, cin, k, seed=2, scale=1.0 / np.sqrt(cin * k))
+    b = _rand(cout, seed=3)
+    res = _rand(2, cout, T, seed=4)
+    pl = (k * d - d) // 2
+    xs = ops.act_split(x.to(DEV), 0.1, fmt=1)
+    ys = ops.split_like(2, cout, T, DEV)
+    y = ops.conv1d(x.to(DEV), packing.pack_conv_weight_f16f8(w.to(DEV)), cout, k, bias=b.to(DEV), dilation=d, pad_left=pl,
+                   res=res.to(DEV), mode=2, x_split=xs, y_split=ys, y_split_slope=0.1).cpu().double()
+    xa = F.leaky_relu(x, 0.1)
+    xh = ops.unsplit(torch.stack([xs[:, :, 0], torch.zeros_like(xs[:, :, 0])], 2)).cpu()        # the kernel's hi (toward zero)
+    xl = xa - xh
+    wh = w.to(torch.float16).float()
+    wl = w - wh
+    conv = lambda a, ww: F.conv1d(a.double(), ww.double(), None, dilation=d, padding=pl)
+    emu = (conv(xh, wh) + conv(_e4m3(xh).float(), _e4m3(wl, 16).float() / 2 ** 16)
+           + conv(_e4m3(xl, 10).float() / 2 ** 10, _e4m3(wh, 6).float() / 2 ** 6) + b.double()[None, :, None] + res.double())
+    ref = conv(xa, w) + b.double()[None, :, None] + res.double()
+    e_emu, e_ref = (y - emu).abs().max().item(), (y - ref).abs().max().item()
+    print(f"max abs: vs decomposition {e_emu:.2e}, vs exact {e_ref:.2e} (rms {rms(y - ref):.2e})")
+    assert e_emu < 1e-5
+    assert e_ref < 1e-4 and rms(y - ref) < 2e-5
+    assert torch.equal(ys, ops.act_split(y.float().to(DEV), 0.1, fmt=1))        # output planes in the format it reads
+
+
+@pytest.mark.parametrize("case", [(16, 11, 5, 2500), (32, 3, 5, 449), (32, 7, 1, 224)], ids=lambda c: "x".join(map(str, c)))
+def test_fused_pair_split_planes(case):
+    ops, packing = _ops()
+    C, k, d, T = case
+    x = _rand(2, C, T, seed=1).to(DEV)
+    pk = packing.pack_conv_weight_f16x3
+    w1, w2 = pk(_rand(C, C, k, seed=2, scale=0.6 / np.sqrt(C * k)).to(DEV)), pk(_rand(C, C, k, seed=3, scale=0.6 / np.sqrt(C * k)).to(DEV))
+    b1, b2 = _rand(C, seed=4, scale=0.1).to(DEV), _rand(C, seed=5, scale=0.1).to(DEV)
+    y0 = ops.resblock_pair(x, w1, b1, w2, b2, k, d)
+    ys = ops.split_like(2, C, T, DEV)
+    y1 = ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=ops.act_split(x, 0.1), y_split=ys, y_split_slope=0.1)
+    assert torch.equal(y0, y1)
+    assert torch.equal(ys, ops.act_split(y0, 0.1))
+
+
+def test_generator_split_plane_pipeline_equals_f32_handover(model, gold):
+    """the generator with split-plane activations between layers vs the same kernels fed with f32
+    activations: same arithmetic, different staging"""
+    from satools_amd._lib import lib, check
+    fx = gold.npz("fx_gen.npz")
+    g = model.hifigan
+    if g.precision != "f16x3":
+        pytest.skip("split planes belong to the split-f16 generator")
+    x = torch.randn(2, g.imput_dim, 25, generator=torch.Generator().manual_seed(3)).to(DEV)
+    y1 = g(x)[0].clone()
+    check(lib().sat_hifigan_set_option(g._handle, b"split_acts", 0), "set_option")
+    try:
+        y0 = g(x)[0].clone()
+    finally:
+        check(lib().sat_hifigan_set_option(g._handle, b"split_acts", 1), "set_option")
+    assert torch.equal(y0, y1)
+
+
 # ---------------------------------------------------------------------------------------------
 # generator and end to end
 # ---------------------------------------------------------------------------------------------
@@ -268,6 +397,25 @@ def test_generator_matches_golden_teacher_forced(model, gold):
     err = rms(y.cpu().numpy() - fx["y"])
     print("generator RMS error vs reference:", err, "signal RMS", rms(fx["y"]))
     assert err < 1e-5
+
+
+def test_generator_f16f8_precision(model, gold):
+    """opt-in SAT_CONV_F16F8 generator (cross terms on the e4m3 MFMA): waveform within 2e-5 RMS of the
+    reference's on its teacher-forced input (measured ~3e-6; the path's bar is 1e-4)"""
+    fx = gold.npz("fx_gen.npz")
+    g = model.hifigan
+    old = g.precision
+    g.precision = "f16f8"
+    g.invalidate()
+    try:
+        spk = F.one_hot(torch.from_numpy(fx["spk_argmax"]), len(model.spk))
+        y = model._forward(torch.from_numpy(fx["f0_raw"].copy()), torch.from_numpy(fx["bn"]), spk)
+    finally:
+        g.precision = old
+        g.invalidate()
+    err = rms(y.cpu().numpy() - fx["y"])
+    print("f16f8 generator RMS error vs reference:", err)
+    assert err < 2e-5
 
 
 def test_convert_matches_golden(model, gold):

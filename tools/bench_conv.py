@@ -9,7 +9,8 @@ from satools_amd import ops, packing
 B = 32
 SHAPES = [  # (C, T) per stage
     (256, 1250), (128, 5000), (64, 20000), (32, 40000), (16, 80000)]
-MODE = 1 if 'f16' in sys.argv else 0
+MODE = 1 if ('f16' in sys.argv or 'split' in sys.argv) else 0
+SPLIT = 'split' in sys.argv      # split-plane input and output (conv2 of a pair: residual + both outputs)
 only = [int(a) for a in sys.argv[1:] if a.isdigit()] or list(range(5))
 dev = "cuda"
 rows = []
@@ -24,6 +25,11 @@ for si in only:
             b = torch.randn(C, device=dev)
             pl = (k * d - d) // 2
             f = lambda: ops.conv1d(x, w, C, k, bias=b, dilation=d, pad_left=pl, in_lrelu=0.1, res=res, out=out, mode=MODE)
+            if SPLIT:
+                xs = ops.act_split(x, 0.1)
+                ys = ops.split_like(B, C, T, dev)
+                f = lambda: ops.conv1d(x, w, C, k, bias=b, dilation=d, pad_left=pl, res=res, out=out, mode=1,
+                                       x_split=xs, y_split=ys, y_split_slope=0.1)
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
