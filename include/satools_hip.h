@@ -117,6 +117,10 @@ typedef struct {
   void* y_split;           /* also write the output as split planes, or NULL */
   float y_split_slope;     /* leaky-relu slope applied before splitting; 1 = none */
   int32_t no_y;            /* skip the f32 store of y (y may be NULL) */
+  const void* res_split;   /* residual taken from SAT_SPLIT_F16 planes of lrelu(r, res_split_slope) instead of `res`
+                              (r = hi + lo, the leaky-relu undone on the fly: 22 significand bits of r); with it
+                              a chain of layers needs no f32 copy of its activations.  up 1, groups 1 */
+  float res_split_slope;
   int32_t y_split_format;  /* 0 = the format this mode reads (F16X3: SAT_SPLIT_F16, F16F8: SAT_SPLIT_F8),
                               1 = SAT_SPLIT_F16, 2 = SAT_SPLIT_F8 */
 } sat_conv1d_desc;
@@ -126,8 +130,9 @@ int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packe
 /* One fused ResBlock1 step of the thin generator stages (C = 16 or 32), split-f16 arithmetic:
  *   y = conv2(lrelu(conv1(lrelu(x)) + bias1)) + d->bias + x      (hifigan/nn.py:179-186)
  * conv1 = (ksize, d->dilation), conv2 = (ksize, 1), both 'same' padded, slope d->in_slope; the
- * intermediate never leaves LDS.  d->res must be x; d->accum / accum_div as in sat_conv1d_f32
- * (MRF sum).  Weights: SAT_CONV_F16X3 packing. */
+ * intermediate never leaves LDS.  d->res must be x (or d->res_split == d->x_split); d->accum /
+ * accum_div as in sat_conv1d_f32 (MRF sum); x_split / y_split / no_y as in sat_conv1d_f32.
+ * Weights: SAT_CONV_F16X3 packing. */
 int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
                             const float* bias1, const void* w2_packed, float* y, void* stream);
 /* f32 [B][C][T] -> split planes of lrelu(x, slope) in `format` (SAT_SPLIT_*); C % 16 == 0 */

@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
         ("res_bstride", C.c_int64), ("res_cstride", C.c_int64),
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ch_scale", C.c_void_p), ("ch_shift", C.c_void_p),
         ("x_split", C.c_void_p), ("y_split", C.c_void_p), ("y_split_slope", C.c_float), ("no_y", C.c_int32),
-        ("y_split_format", C.c_int32),
+        ("res_split", C.c_void_p), ("res_split_slope", C.c_float), ("y_split_format", C.c_int32),
     ]
 
 

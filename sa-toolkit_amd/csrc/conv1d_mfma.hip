@@ -62,6 +62,8 @@ struct ConvArgs {
   void* y16;             // output as split planes, or null
   float y16_slope;
   int no_y;
+  const void* res16;     // residual as SAT_SPLIT_F16 planes of lrelu(r, res16_slope) (inverted on the fly), or null
+  float res16_inv;       // 1 / slope
   int f8;                // planes kernels: cross terms hi*lo + lo*hi on the block-scaled e4m3 MFMA
   int y16_f8;            // output planes carry (hi f16 | e4m3(hi) | e4m3(lo * 2^10)) instead of (hi f16 | lo f16)
 #ifdef SAT_STAMPS
@@ -97,6 +99,32 @@ __device__ __forceinline__ void epilogue_prefetch_res(const ConvArgs& p, float (
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.res ? p.res + rb : p.y), 0, p.res ? (unsigned)(p.rows_g * p.r_cs * 4) : 0u, 0x00020000);
   const int r_rb = (int)p.r_cs * 4;
+  if (p.res16) {
+    // residual from the split planes: per 4 consecutive rows the 8-byte hi and lo words of this column (raw)
+    const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.res16 + (long long)b * p.rows_g * p.T_q * 4), 0, (unsigned)(p.rows_g * p.T_q * 4), 0x00020000);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int q = q_w + n * q_step + l31;
+        const bool qok = q < p.T_q && q < q_end;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int chunk = ((co_w + m * 32) >> 4) + (rg >> 1);
+          const unsigned off = (qok && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (rg & 1)) * p.T_q + q) * 16 + 8 * lh) : 0x80000000u;
+          const uint4 hv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 0, 0));   // narrowed to 8 bytes (the b64 builtin of this hipcc loads one dword)
+          const unsigned hv[2] = {hv4.x, hv4.y};
+          const uint4 lv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * p.T_q * 16, 0));
+          const unsigned lv[2] = {lv4.x, lv4.y};
+          rpre[m][n][4 * rg + 0] = __builtin_bit_cast(float, hv[0]);
+          rpre[m][n][4 * rg + 1] = __builtin_bit_cast(float, hv[1]);
+          rpre[m][n][4 * rg + 2] = __builtin_bit_cast(float, lv[0]);
+          rpre[m][n][4 * rg + 3] = __builtin_bit_cast(float, lv[1]);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int row0 = co_w + m * 32 + 4 * lh;
@@ -111,6 +139,19 @@ __device__ __forceinline__ void epilogue_prefetch_res(const ConvArgs& p, float (
                                                       rrs, roff + ((r & 3) + 8 * (r >> 2)) * r_rb, 0, 0));
     }
   }
+}
+
+// raw plane words (hi01, hi23, lo01, lo23 of four consecutive rows) -> the four residual values
+__device__ __forceinline__ void decode_res16(float w0, float w1, float w2, float w3, float inv_slope, float (&out)[4]) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 h01 = __builtin_bit_cast(h2, w0), h23 = __builtin_bit_cast(h2, w1);
+  const h2 l01 = __builtin_bit_cast(h2, w2), l23 = __builtin_bit_cast(h2, w3);
+  out[0] = (float)h01[0] + (float)l01[0];
+  out[1] = (float)h01[1] + (float)l01[1];
+  out[2] = (float)h23[0] + (float)l23[0];
+  out[3] = (float)h23[1] + (float)l23[1];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = out[k] > 0.f ? out[k] : out[k] * inv_slope;
 }
 
 template <int MT, int NT, bool RPRE = false>
@@ -139,6 +180,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
     const __amdgpu_buffer_rsrc_t shs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.ch_shift ? p.ch_shift + chb : p.y), 0, p.ch_shift ? chn : 0u, 0x00020000);
     const int y_rb = (int)p.y_cs * 4, r_rb = (int)p.r_cs * 4;  // bytes per row
+    const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.res16 ? (char*)p.res16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
+        p.res16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
+    const bool has_res = p.res != nullptr || p.res16 != nullptr;
     const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.y16 ? (char*)p.y16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
         p.y16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
@@ -164,7 +209,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
         const unsigned roff = qok ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : OOB;
         float rv[16], yv[16];
-        if (p.res) {
+        if (p.res16) {
+          float raw[16];
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            if constexpr (RPRE) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) raw[4 * rg + k] = rpre[m][n][4 * rg + k];
+            } else {
+              const int chunk = ((co_w + m * 32) >> 4) + (rg >> 1);
+              const unsigned off = (qok && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (rg & 1)) * p.T_q + q) * 16 + 8 * lh) : OOB;
+              const uint4 hv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 0, 0));   // narrowed to 8 bytes (the b64 builtin of this hipcc loads one dword)
+          const unsigned hv[2] = {hv4.x, hv4.y};
+              const uint4 lv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * p.T_q * 16, 0));
+          const unsigned lv[2] = {lv4.x, lv4.y};
+              raw[4 * rg + 0] = __builtin_bit_cast(float, hv[0]);
+              raw[4 * rg + 1] = __builtin_bit_cast(float, hv[1]);
+              raw[4 * rg + 2] = __builtin_bit_cast(float, lv[0]);
+              raw[4 * rg + 3] = __builtin_bit_cast(float, lv[1]);
+            }
+          }
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            float o[4];
+            decode_res16(raw[4 * rg], raw[4 * rg + 1], raw[4 * rg + 2], raw[4 * rg + 3], p.res16_inv, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rv[4 * rg + k] = o[k];
+          }
+        } else if (p.res) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             if constexpr (RPRE)
@@ -185,7 +257,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[m][n][r] + bi[r];
-        if (p.res && !p.res_after) {
+        if (has_res && !p.res_after) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] += p.res_scale * rv[r];
         }
@@ -203,7 +275,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
             v[r] = v[r] * 0.5f * (1.0f + erff(v[r] * 0.70710678118654752440f));
           }
         }
-        if (p.res && p.res_after) {
+        if (has_res && p.res_after) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] += p.res_scale * rv[r];
         }
@@ -820,7 +892,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvA
   __syncthreads();
   SAT_STAMP(3);
   float rpre[MT][NT][16];
-  if (p.res) epilogue_prefetch_res<MT, NT>(p, rpre, b, 0, co_w, q_w, l31, lh);
+  if (p.res || p.res16) epilogue_prefetch_res<MT, NT>(p, rpre, b, 0, co_w, q_w, l31, lh);
   __builtin_amdgcn_sched_barrier(0);
   mfma_phase();
   SAT_STAMP(4);
@@ -1267,6 +1339,12 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     if (a.x16)
       SAT_REQUIRE(d->groups == 1 && a.cin_g % 16 == 0 && (long long)a.cin_g * a.T_in * 4 < (1LL << 31),
                   "conv1d(f16x3): x_split needs groups 1, C_in %% 16 == 0 and a slab below 2 GiB");
+    if (d->res_split) {
+      SAT_REQUIRE(!d->res && a.fast_epi && d->groups == 1 && a.rows_g % 16 == 0 && d->res_split_slope > 0.f &&
+                  (long long)a.rows_g * a.T_q * 4 < (1LL << 31), "conv1d(f16x3): res_split needs up 1, groups 1, C_out %% 16 == 0, no f32 res");
+      a.res16 = d->res_split;
+      a.res16_inv = 1.0f / d->res_split_slope;
+    }
     if (a.y16 || a.no_y) {
       SAT_REQUIRE(a.fast_epi && d->groups == 1 && a.rows_g % 16 == 0 && (long long)a.rows_g * a.T_q * 4 < (1LL << 31),
                   "conv1d(f16x3): y_split / no_y need up 1, groups 1, C_out %% 16 == 0 and a slab below 2 GiB");
@@ -1293,13 +1371,14 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
 
 extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
                                        const float* bias1, const void* w2_packed, float* y, void* stream) {
-  SAT_REQUIRE(d && x && w1_packed && w2_packed && bias1 && y && d->bias, "resblock_pair: null pointer");
-  SAT_REQUIRE(!d->no_y, "resblock_pair: the f32 output is the next step's residual");
+  SAT_REQUIRE(d && w1_packed && w2_packed && bias1 && d->bias && (x || d->x_split) && (y || (d->no_y && d->y_split)),
+              "resblock_pair: null pointer");
   SAT_REQUIRE(d->C_in == d->C_out && d->C_in <= 32 && d->C_in % 16 == 0, "resblock_pair: C must be 16 or 32");
   SAT_REQUIRE(d->groups == 1 && d->up == 1 && d->stride == 1 && d->T_q == d->T_in, "resblock_pair: same-length conv pair only");
   SAT_REQUIRE(d->ksize == 3 || d->ksize == 7 || d->ksize == 11, "resblock_pair: kernel size %d not instantiated", d->ksize);
   SAT_REQUIRE(d->in_lrelu, "resblock_pair: both convs take a leaky-relu input");
-  SAT_REQUIRE(d->res == x, "resblock_pair: the residual is the block input");
+  SAT_REQUIRE((d->res && d->res == x && !d->res_split) || (!d->res && d->res_split && d->res_split == d->x_split),
+              "resblock_pair: the residual is the block input (res == x, or res_split == x_split)");
   ConvArgs a{};
   a.x = x;
   a.w = (const float*)w1_packed;
@@ -1327,6 +1406,15 @@ extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x,
   a.x16 = d->x_split;
   a.y16 = d->y_split;
   a.y16_slope = d->y_split_slope;
+  a.no_y = d->no_y;
+  SAT_REQUIRE(!(d->no_y && d->accum), "resblock_pair: no_y with accum");
+  if (a.no_y) a.y = (float*)a.y16;
+  if (d->res_split) {
+    SAT_REQUIRE(d->res_split_slope > 0.f, "resblock_pair: res_split_slope");
+    a.res16 = d->res_split;
+    a.res16_inv = 1.0f / d->res_split_slope;
+  }
+  SAT_REQUIRE((long long)a.rows_g * a.T_q * 4 < (1LL << 31), "resblock_pair: slab too large");
   hipStream_t s = (hipStream_t)stream;
   switch (a.ksize) {
     case 3: return launch_pair<3>(a, d->B, s);

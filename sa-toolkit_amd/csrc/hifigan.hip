@@ -90,6 +90,7 @@ struct sat_hifigan {
   std::vector<Conv> convs;
   int fuse_pairs = 1;
   int split_acts = 1;
+  int planes_residual = 1;
   int n_ups() const { return (int)up_rates.size(); }
   int n_rbk() const { return (int)rb_kernels.size(); }
   int id_up(int i) const { return 1 + i; }
@@ -183,6 +184,7 @@ extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int valu
   SAT_REQUIRE(h && name, "hifigan_set_option: null pointer");
   if (std::string(name) == "fuse_pairs") { h->fuse_pairs = value; return SAT_OK; }
   if (std::string(name) == "split_acts") { h->split_acts = value; return SAT_OK; }
+  if (std::string(name) == "planes_residual") { h->planes_residual = value; return SAT_OK; }
   set_error("hifigan_set_option: unknown option %s", name);
   return SAT_ERR_INVALID;
 }
@@ -301,16 +303,25 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
           d2.in_slope = 0.1f;
           d2.bias = cv2.bias;
           d2.mode = cmode;
-          d2.res = rf;
+          // the residual is the pair's input: from its split planes (hi + lo, leaky-relu undone) when the
+          // format carries both halves, so no f32 copy of the activations is written inside a resblock
+          const bool planes_res = cmode == SAT_CONV_F16X3 && h->planes_residual;
+          if (planes_res) {
+            d2.res_split = rs;
+            d2.res_split_slope = 0.1f;
+          } else {
+            d2.res = rf;
+            d2.res_cstride = Tn;
+            d2.res_bstride = (int64_t)Cn * Tn;
+          }
           d2.res_scale = 1.f;
-          d2.res_cstride = Tn;
-          d2.res_bstride = (int64_t)Cn * Tn;
           d2.y_split_slope = 0.1f;
           float* dstf;
           void* dsts;
           if (pair < 2) {
             dstf = (rf == RAf) ? RBf : RAf;
-            dsts = (rf == RAf) ? RBs : RAs;
+            dsts = (rs == RAs) ? RBs : RAs;
+            d2.no_y = planes_res;
           } else {
             dstf = ACCf;
             d2.accum = j > 0;
@@ -323,7 +334,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             sat_conv1d_desc df = d2;
             df.dilation = dil;
             df.x_split = rs;
-            s = sat_resblock_pair_f16x3(&df, rf, cv1.w, cv1.bias, cv2.w, dstf, stream);
+            s = sat_resblock_pair_f16x3(&df, planes_res ? nullptr : rf, cv1.w, cv1.bias, cv2.w, dstf, stream);
             if (s != SAT_OK) return s;
           } else {
             sat_conv1d_desc d1 = base_desc(Cn, Cn, Tn, Tn, 1);

@@ -25,14 +25,15 @@ def _strided3(t):
 def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_left=0, pad_right=None, groups=1,
            up=1, in_lrelu=None, res=None, res_scale=1.0, res_toff=0, res_tstride=1, ch_scale=None, ch_shift=None,
            relu=False, gelu=False, post_res=None, out=None, accum=False, accum_div=0.0, mode=0, t_out=None,
-           x_split=None, y_split=None, y_split_slope=1.0, no_y=False, y_split_format=0):
+           x_split=None, y_split=None, y_split_slope=1.0, no_y=False, y_split_format=0, res_split=None,
+           res_split_slope=1.0):
     """Fused conv (see include/satools_hip.h sat_conv1d_f32).  `pad_right` defaults to the
     'same'-style value implied by pad_left for stride 1; T_q is derived like torch does:
     T_q = (T_in + pad_left + pad_right - dilation*(ksize-1) - 1)//stride + 1 (`t_out` caps it).
     `post_res` is a residual added AFTER the activation (y = post_res + act(conv(x))).
     Split planes (mode=CONV_F16X3): `x_split` = act_split(pre(x)) replaces the staging of x (x then only
     gives the shape); `y_split` (a split_like buffer) also receives split(lrelu(y, y_split_slope));
-    `no_y` skips the f32 store."""
+    `no_y` skips the f32 store; `res_split` takes the residual from SPLIT_F16 planes of lrelu(r, res_split_slope)."""
     x = _strided3(x)
     B, c_in, t_in = x.shape
     if pad_right is None:
@@ -71,6 +72,7 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
     d.ch_shift = ptr(ch_shift)
     d.x_split, d.y_split = ptr(x_split), ptr(y_split)
     d.y_split_slope, d.no_y, d.y_split_format = float(y_split_slope), int(no_y), int(y_split_format)
+    d.res_split, d.res_split_slope = ptr(res_split), float(res_split_slope)
     check(lib().sat_conv1d_f32(C.byref(d), ptr(x, strided=True), ptr(w_packed), ptr(out, strided=True), stream()),
           "sat_conv1d_f32")
     return out
@@ -226,7 +228,7 @@ def unsplit(s):
 
 
 def resblock_pair(x, w1, b1, w2, b2, ksize, dilation, slope=0.1, out=None, accum=False, accum_div=0.0,
-                  x_split=None, y_split=None, y_split_slope=1.0):
+                  x_split=None, y_split=None, y_split_slope=1.0, planes_residual=False, no_y=False):
     """fused ResBlock1 step (C = 16 / 32, split-f16): out = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x"""
     x = _f32c(x)
     B, c, t = x.shape
@@ -241,8 +243,11 @@ def resblock_pair(x, w1, b1, w2, b2, ksize, dilation, slope=0.1, out=None, accum
     d.x_bstride, d.x_cstride = x.stride(0), x.stride(1)
     d.y_bstride, d.y_cstride = out.stride(0), out.stride(1)
     d.res_bstride, d.res_cstride = x.stride(0), x.stride(1)
-    d.bias, d.res = ptr(b2), ptr(x)
+    d.bias, d.res = ptr(b2), (None if planes_residual else ptr(x))
     d.x_split, d.y_split, d.y_split_slope = ptr(x_split), ptr(y_split), float(y_split_slope)
-    check(lib().sat_resblock_pair_f16x3(C.byref(d), ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(out), stream()),
+    if planes_residual:
+        d.res_split, d.res_split_slope = ptr(x_split), float(slope)
+    d.no_y = int(no_y)
+    check(lib().sat_resblock_pair_f16x3(C.byref(d), None if planes_residual else ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(out), stream()),
           "sat_resblock_pair_f16x3")
     return out

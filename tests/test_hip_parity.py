@@ -291,6 +291,10 @@ def test_conv1d_split_planes_in_out(case):
     ops.conv1d(x, w, cout, k, bias=b, dilation=d, pad_left=pl, res=res, mode=1, x_split=ops.act_split(x, 0.1),
                y_split=ys2, y_split_slope=0.1, no_y=True, out=y2)
     assert torch.equal(ys2, ys) and (y2 == 7.0).all()
+    # residual rebuilt from split planes (hi + lo, leaky-relu undone): 2^-21 of the residual
+    y3 = ops.conv1d(x, w, cout, k, bias=b, dilation=d, pad_left=pl, mode=1, x_split=ops.act_split(x, 0.1),
+                    res_split=ops.act_split(res, 0.1), res_split_slope=0.1)
+    assert (y3 - y0).abs().max() <= 2.0 ** -20 * res.abs().max()
 
 
 def _e4m3(t, exp=0):
@@ -362,6 +366,12 @@ def test_fused_pair_split_planes(case):
     y1 = ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=ops.act_split(x, 0.1), y_split=ys, y_split_slope=0.1)
     assert torch.equal(y0, y1)
     assert torch.equal(ys, ops.act_split(y0, 0.1))
+    ys2 = torch.zeros_like(ys)
+    y2 = torch.full_like(y0, 7.0)
+    ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=ops.act_split(x, 0.1), y_split=ys2, y_split_slope=0.1,
+                      planes_residual=True, no_y=True, out=y2)
+    assert (y2 == 7.0).all()
+    assert (ops.unsplit(ys2) - ops.unsplit(ys)).abs().max() <= 2.0 ** -19 * x.abs().max()
 
 
 def test_generator_split_plane_pipeline_equals_f32_handover(model, gold):
@@ -373,13 +383,18 @@ def test_generator_split_plane_pipeline_equals_f32_handover(model, gold):
     if g.precision != "f16x3":
         pytest.skip("split planes belong to the split-f16 generator")
     x = torch.randn(2, g.imput_dim, 25, generator=torch.Generator().manual_seed(3)).to(DEV)
-    y1 = g(x)[0].clone()
-    check(lib().sat_hifigan_set_option(g._handle, b"split_acts", 0), "set_option")
+    y2 = g(x)[0].clone()                     # default: planes only, residuals rebuilt from hi + lo (22 bits)
+    check(lib().sat_hifigan_set_option(g._handle, b"planes_residual", 0), "set_option")
     try:
-        y0 = g(x)[0].clone()
+        y1 = g(x)[0].clone()                 # planes + f32 copies for the residuals
+        check(lib().sat_hifigan_set_option(g._handle, b"split_acts", 0), "set_option")
+        y0 = g(x)[0].clone()                 # f32 activations, split inside every kernel
     finally:
         check(lib().sat_hifigan_set_option(g._handle, b"split_acts", 1), "set_option")
+        check(lib().sat_hifigan_set_option(g._handle, b"planes_residual", 1), "set_option")
     assert torch.equal(y0, y1)
+    print("planes-only residuals vs f32 residuals: rms", rms((y2 - y1).cpu().numpy()))
+    assert rms((y2 - y1).cpu().numpy()) < 5e-7
 
 
 # ---------------------------------------------------------------------------------------------
