@@ -1,6 +1,8 @@
 // HiFi-GAN generator forward on gfx950: orchestration over the fused conv1d kernel plus the
 // streaming output stage.  Reference: CoreHifiGan.forward_resnet, satools/satools/hifigan/
 // archi.py:77-91; ResBlock1.forward, satools/satools/hifigan/nn.py:179-186.
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -79,7 +81,18 @@ __global__ void __launch_bounds__(256) convpost_kernel(const float* __restrict__
 
 using namespace sat;
 
+// side streams of one caller stream: the resblock branches of a stage (kernel sizes 3 / 7 / 11) are
+// independent until the MRF sum, so they run on separate HIP streams and fill each other's tails
+// (a C=256 conv is 640 blocks on 512 block slots); events keep the order of the sum
+struct hifigan_side {
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t fork = nullptr, acc[3] = {nullptr, nullptr, nullptr};
+};
+
 struct sat_hifigan {
+  std::mutex mu;
+  std::map<void*, hifigan_side> sides;   // keyed by the caller's stream
+  int branch_streams = 0;   // leading stages whose three resblock branches run on separate streams (single-job latency)
   int in_ch = 0, c0 = 0;
   std::vector<int> up_rates, up_kernels, rb_kernels, rb_dil;
   struct Conv {
@@ -171,20 +184,43 @@ static bool hifigan_split_acts(const sat_hifigan* h) {
   return C % 16 == 0 && h->c0 % 16 == 0;
 }
 
-constexpr int WS_SLOTS = 10;
+constexpr int WS_SLOTS = 20;   // H (f32 + planes), MRF sum, 2 stage-input planes, 3 branches x (T1, RA, RB) x (f32 + planes)
 
 extern "C" size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
   return WS_SLOTS * align_up(hifigan_max_elems(h, B, T) * sizeof(float), 256);
 }
 
-extern "C" void sat_hifigan_destroy(sat_hifigan* h) { delete h; }
+extern "C" void sat_hifigan_destroy(sat_hifigan* h) {
+  if (!h) return;
+  for (auto& kv : h->sides) {
+    for (auto st : kv.second.s) if (st) (void)hipStreamDestroy(st);
+    if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
+    for (auto e : kv.second.acc) if (e) (void)hipEventDestroy(e);
+  }
+  delete h;
+}
+
+static int hifigan_get_side(sat_hifigan* h, void* stream, hifigan_side** out) {
+  std::lock_guard<std::mutex> lock(h->mu);
+  auto it = h->sides.find(stream);
+  if (it == h->sides.end()) {
+    hifigan_side sd;
+    for (auto& st : sd.s) SAT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    SAT_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+    for (auto& e : sd.acc) SAT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    it = h->sides.emplace(stream, sd).first;
+  }
+  *out = &it->second;
+  return SAT_OK;
+}
 
 extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int value) {
   SAT_REQUIRE(h && name, "hifigan_set_option: null pointer");
   if (std::string(name) == "fuse_pairs") { h->fuse_pairs = value; return SAT_OK; }
   if (std::string(name) == "split_acts") { h->split_acts = value; return SAT_OK; }
   if (std::string(name) == "planes_residual") { h->planes_residual = value; return SAT_OK; }
+  if (std::string(name) == "branch_streams") { h->branch_streams = value; return SAT_OK; }
   set_error("hifigan_set_option: unknown option %s", name);
   return SAT_ERR_INVALID;
 }
@@ -246,13 +282,20 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
     const int cmode = h->convs[1].mode;                                // SAT_CONV_F16X3 or SAT_CONV_F16F8
     const int yfmt = cmode == SAT_CONV_F16F8 ? 2 : 1;                  // plane format every consumer reads
     char* ws = (char*)workspace;
-    float* Hf = (float*)(ws + 0 * slot);   void* Hs = ws + 1 * slot;    // upsampled x (residual + planes)
-    void* T1s = ws + 2 * slot;                                         // inner activation of a pair
-    float* RAf = (float*)(ws + 3 * slot);  void* RAs = ws + 4 * slot;
-    float* RBf = (float*)(ws + 5 * slot);  void* RBs = ws + 6 * slot;
-    float* ACCf = (float*)(ws + 7 * slot);                             // MRF sum
-    void* XS = ws + 8 * slot;                                          // stage input planes
-    void* XSn = ws + 9 * slot;
+    float* Hf = (float*)(ws + 0 * slot);   void* Hs = ws + 1 * slot;    // upsampled x (f32 for the split pass, planes)
+    float* ACCf = (float*)(ws + 2 * slot);                             // MRF sum
+    void* XS = ws + 3 * slot;                                          // stage input planes
+    void* XSn = ws + 4 * slot;
+    // per resblock branch: planes of the inner activation and of the two ping-pong outputs (+ their f32
+    // twins, only written when residuals are not rebuilt from planes)
+    auto br = [&](int j, int which) { return ws + (size_t)(5 + j * 5 + which) * slot; };
+    const bool planes_res_all = cmode == SAT_CONV_F16X3 && h->planes_residual;
+    hifigan_side* side = nullptr;
+    const int nk0 = h->n_rbk();
+    if (planes_res_all && h->branch_streams && nk0 == 3) {
+      int st = hifigan_get_side(const_cast<sat_hifigan*>(h), stream, &side);
+      if (st != SAT_OK) return st;
+    }
     {
       sat_conv1d_desc d = base_desc(h->in_ch, h->c0, T, T, 1);
       d.ksize = 7;
@@ -287,8 +330,18 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         s = sat_act_split_f32(Hf, Hs, B, Cn, Tn, 0.1f, cmode == SAT_CONV_F16F8 ? SAT_SPLIT_F8 : SAT_SPLIT_F16, stream);
         if (s != SAT_OK) return s;
       }
+      if (side && i < h->branch_streams) {
+        SAT_HIP(hipEventRecord(side->fork, (hipStream_t)stream));
+        for (auto st : side->s) SAT_HIP(hipStreamWaitEvent(st, side->fork, 0));
+      }
       for (int j = 0; j < nk; ++j) {
         const int rk = h->rb_kernels[j];
+        // branch j on its own stream (the last, longest branch on the caller's); sum order kept by events
+        const bool fan = side && i < h->branch_streams;   // option value = number of leading stages fanned out
+        void* stream_j = fan && j < 2 ? (void*)side->s[j] : stream;
+        void* T1s = br(j, 0);
+        float* RAf = (float*)br(j, 1);  void* RAs = br(j, 2);
+        float* RBf = (float*)br(j, 3);  void* RBs = br(j, 4);
         const float* rf = Hf;
         const void* rs = Hs;
         for (int pair = 0; pair < 3; ++pair) {
@@ -330,11 +383,18 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
           }
           d2.y_split = dsts;
           int s;
+          // the MRF sum is read-modify-write on ACC: branch j's last kernel waits for branch j-1's
+          auto wait_prev_sum = [&]() -> int {
+            if (fan && pair == 2 && j > 0) SAT_HIP(hipStreamWaitEvent((hipStream_t)stream_j, side->acc[j - 1], 0));
+            return SAT_OK;
+          };
           if (Cn <= 32 && h->fuse_pairs && cmode == SAT_CONV_F16X3) {
             sat_conv1d_desc df = d2;
             df.dilation = dil;
             df.x_split = rs;
-            s = sat_resblock_pair_f16x3(&df, planes_res ? nullptr : rf, cv1.w, cv1.bias, cv2.w, dstf, stream);
+            s = wait_prev_sum();
+            if (s != SAT_OK) return s;
+            s = sat_resblock_pair_f16x3(&df, planes_res ? nullptr : rf, cv1.w, cv1.bias, cv2.w, dstf, stream_j);
             if (s != SAT_OK) return s;
           } else {
             sat_conv1d_desc d1 = base_desc(Cn, Cn, Tn, Tn, 1);
@@ -347,12 +407,15 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             d1.y_split = T1s;
             d1.y_split_slope = 0.1f;
             d1.no_y = 1;
-            s = sat_conv1d_f32(&d1, nullptr, cv1.w, nullptr, stream);
+            s = sat_conv1d_f32(&d1, nullptr, cv1.w, nullptr, stream_j);
             if (s != SAT_OK) return s;
             d2.x_split = T1s;
-            s = sat_conv1d_f32(&d2, nullptr, cv2.w, dstf, stream);
+            s = wait_prev_sum();
+            if (s != SAT_OK) return s;
+            s = sat_conv1d_f32(&d2, nullptr, cv2.w, dstf, stream_j);
             if (s != SAT_OK) return s;
           }
+          if (fan && pair == 2) SAT_HIP(hipEventRecord(side->acc[j], (hipStream_t)stream_j));
           rf = dstf;
           rs = dsts;
         }

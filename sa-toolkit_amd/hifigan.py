@@ -21,6 +21,9 @@ class CoreHifiGan(CoreHifiGanParams):
     precision = os.environ.get("SATOOLS_AMD_GEN_PRECISION", "f16x3")
     #: hand activations between layers as split planes (csrc/hifigan.hip); 0 = f32 tensors
     split_acts = int(os.environ.get("SATOOLS_AMD_GEN_SPLIT_ACTS", "1"))
+    #: number of leading generator stages whose three resblock branches run on separate HIP streams: -2 % for a
+    #: single convert() in flight, a loss once two are (bench --jobs 2), so off by default
+    branch_streams = int(os.environ.get("SATOOLS_AMD_GEN_BRANCH_STREAMS", "0"))
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -31,7 +34,7 @@ class CoreHifiGan(CoreHifiGanParams):
 
     # -- device-side weight cache ---------------------------------------------------------
     def _param_key(self):
-        return (self.precision, self.split_acts) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        return (self.precision, self.split_acts, self.branch_streams) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
 
     def invalidate(self):
         self._packed_key = None
@@ -82,6 +85,7 @@ class CoreHifiGan(CoreHifiGanParams):
             packed.append((wp, b))
             check(l.sat_hifigan_set_conv(self._handle, i, ptr(wp), ptr(b), mode), "sat_hifigan_set_conv")
         check(l.sat_hifigan_set_option(self._handle, b"split_acts", int(self.split_acts)), "sat_hifigan_set_option")
+        check(l.sat_hifigan_set_option(self._handle, b"branch_streams", int(self.branch_streams)), "sat_hifigan_set_option")
         self._packed = packed  # keeps the device buffers alive
         self._packed_key = key
 

@@ -384,6 +384,12 @@ def test_generator_split_plane_pipeline_equals_f32_handover(model, gold):
         pytest.skip("split planes belong to the split-f16 generator")
     x = torch.randn(2, g.imput_dim, 25, generator=torch.Generator().manual_seed(3)).to(DEV)
     y2 = g(x)[0].clone()                     # default: planes only, residuals rebuilt from hi + lo (22 bits)
+    check(lib().sat_hifigan_set_option(g._handle, b"branch_streams", 0), "set_option")
+    y2s = g(x)[0].clone()                    # the three resblock branches of a stage on one stream
+    check(lib().sat_hifigan_set_option(g._handle, b"branch_streams", 5), "set_option")
+    assert torch.equal(y2, g(x)[0])
+    check(lib().sat_hifigan_set_option(g._handle, b"branch_streams", g.branch_streams), "set_option")
+    assert torch.equal(y2, y2s)
     check(lib().sat_hifigan_set_option(g._handle, b"planes_residual", 0), "set_option")
     try:
         y1 = g(x)[0].clone()                 # planes + f32 copies for the residuals
