@@ -1163,6 +1163,228 @@ static int launch_pair(const ConvArgs& a, int B, hipStream_t s) {
   return SAT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ResBlock1 step for the C = 16 stage on the 16x16x32 MFMA shape: 16 rows = the 16 channels exactly
+// (the 32x32 tile pads them to 32 and wastes half the matrix work), K = 32 = a PAIR of taps x 16
+// channels.  Split planes in, split planes out; both weight tiles (2 x 12 KB at k = 11), the input
+// tile and the intermediate t1 live in LDS at once, so a block issues ONE round of global loads
+// (11 x 16 B per lane) and the residual comes from the input tile it already holds.
+//   lanes: A[row l&15][k = 8(l>>4)..], B[k = 8(l>>4)..][col l&15], D col = l&15, rows 4(l>>4) + r
+//   k-group g = l>>4: tap (g>>1) of the pair, channel half (g&1) -> the same 16-byte units as before
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int KS>
+__global__ void __launch_bounds__(256, 2) resblock_pair16_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  constexpr int XWI = 5, XWP = 64 * XWI;
+  constexpr int NTP = (KS + 1) / 2;         // tap pairs; an odd tap count gets a zero phantom tap
+  constexpr int W_REAL = KS * 64;           // 16-byte units of one conv's weights: [tap][hi|lo][half][16 rows]
+  constexpr int WU = 2 * NTP * 64;
+  constexpr int W_IT = (W_REAL + 255) / 256;
+  uint4* ldsx = lds4;                       // [4][XWP]
+  uint4* ldsw1 = ldsx + 4 * XWP;            // [2*NTP][4][16]
+  uint4* ldsw2 = ldsw1 + WU;
+  uint4* ldst = ldsw2 + WU;                 // [4][FP_W1]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int j16 = lane & 15;
+  const int g = lane >> 4;
+  const int gh = g & 1, gt = g >> 1;        // channel half / tap of the pair
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * FP_TO;
+  const int h2 = (KS - 1) / 2;
+  const int xi0 = t0 - FP_OFF - p.pad_left;
+  const unsigned OOB = 0x80000000u;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.x16 + (long long)b * 16 * p.T_in * 4), 0, (unsigned)(16 * p.T_in * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)p.w_gs, 0x00020000);
+  const int seg_bytes = p.co_pad * 16;
+
+  // ---- the block's only round of input loads ----
+  {
+    uint4 xst[XWI], w1st[W_IT], w2st[W_IT];
+    const int pl = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int it = 0; it < XWI; ++it) {
+      const int xi = xi0 + lane + 64 * it;
+      const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((pl * p.T_in + xi) * 16) : OOB;
+      xst[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + 256 * i;
+      const unsigned voff = u < W_REAL ? (unsigned)((u & 15) * 16 + (u >> 4) * seg_bytes) : OOB;
+      w1st[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w1rs, voff, 0, 0));
+      w2st[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w2rs, voff, 0, 0));
+    }
+#pragma unroll
+    for (int it = 0; it < XWI; ++it) ldsx[pl * XWP + lane + 64 * it] = xst[it];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + 256 * i;
+      if (u < WU) {            // units past W_REAL (the phantom tap) were loaded out of range: zeros
+        ldsw1[u] = w1st[i];
+        ldsw2[u] = w2st[i];
+      }
+    }
+  }
+  float bias1[4], bias2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bias1[k] = p.bias1[4 * g + k];
+    bias2[k] = p.bias[4 * g + k];
+  }
+  __syncthreads();
+
+  // ================= phase 1: t1 = lrelu(conv1(x planes) + b1) on the 256-column window =================
+  f32x4v acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc[s] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  {
+    const uint4* wl = ldsw1 + gh * 16 + j16;
+    const uint4* xl = ldsx + gh * XWP + wave * 64 + j16;
+#pragma unroll
+    for (int tp = 0; tp < NTP; ++tp) {
+      const int tap = 2 * tp + gt;
+      const h8 a_hi = __builtin_bit_cast(h8, wl[(tap * 4 + 0) * 16]);
+      const h8 a_lo = __builtin_bit_cast(h8, wl[(tap * 4 + 2) * 16]);
+      const uint4* xt = xl + tap * p.dil;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const h8 b_hi = __builtin_bit_cast(h8, xt[16 * s]);
+        const h8 b_lo = __builtin_bit_cast(h8, xt[2 * XWP + 16 * s]);
+        acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc[s], 0, 0, 0);
+      }
+    }
+  }
+  // t1 -> LDS planes: this lane's four consecutive channels 4g .. 4g+3 = 8 bytes of the unit (half g>>1)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int col = wave * 64 + 16 * s + j16;
+    const int pos = t0 - FP_OFF + col;
+    const bool inside = pos >= 0 && pos < p.T_in;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = acc[s][k] + bias1[k];
+      t = t > 0.f ? t : t * p.in_slope;
+      v[k] = inside ? t : 0.f;      // t1 outside the utterance is conv2's zero padding
+    }
+    const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+    const auto h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+    const auto l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
+    const auto l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+    ((uint2*)(ldst + (0 + gt) * FP_W1 + col))[gh] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    ((uint2*)(ldst + (2 + gt) * FP_W1 + col))[gh] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+  }
+  __syncthreads();
+
+  // ================= phase 2: out = conv2(t1) + b2 + x on 224 columns (14 sub-tiles: 4, 4, 4, 2) =================
+  const int ns = wave < 3 ? 4 : 2;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc[s] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  {
+    const uint4* wl = ldsw2 + gh * 16 + j16;
+    const uint4* tl = ldst + gh * FP_W1 + wave * 64 + j16 + FP_OFF - h2;
+#pragma unroll
+    for (int tp = 0; tp < NTP; ++tp) {
+      const int tap = 2 * tp + gt;
+      const h8 a_hi = __builtin_bit_cast(h8, wl[(tap * 4 + 0) * 16]);
+      const h8 a_lo = __builtin_bit_cast(h8, wl[(tap * 4 + 2) * 16]);
+      const uint4* xt = tl + tap;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < ns) {     // wave-uniform
+          const h8 b_hi = __builtin_bit_cast(h8, xt[16 * s]);
+          const h8 b_lo = __builtin_bit_cast(h8, xt[2 * FP_W1 + 16 * s]);
+          acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc[s], 0, 0, 0);
+          acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, acc[s], 0, 0, 0);
+          acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc[s], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ================= epilogue: + b2 + x (from the input tile in LDS), MRF sum, stores =================
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y + (long long)b * p.y_bs), 0, (unsigned)(16 * p.y_cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y16 ? (char*)p.y16 + (long long)b * 16 * p.T_q * 4 : (char*)p.y), 0, p.y16 ? (unsigned)(16 * p.T_q * 4) : 0u, 0x00020000);
+  const int y_rb = (int)p.y_cs * 4;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s >= ns) continue;
+    const int o = wave * 64 + 16 * s + j16;
+    const int q = t0 + o;
+    const bool ok = q < p.T_q;
+    // residual: the block input at this position, still in the LDS tile (planes of lrelu(x): undo it)
+    const int xcol = o + FP_OFF + p.pad_left;
+    const uint2 rh = ((const uint2*)(ldsx + (0 + gt) * XWP + xcol))[gh];
+    const uint2 rl = ((const uint2*)(ldsx + (2 + gt) * XWP + xcol))[gh];
+    float r[4];
+    decode_res16(__builtin_bit_cast(float, rh.x), __builtin_bit_cast(float, rh.y), __builtin_bit_cast(float, rl.x),
+                 __builtin_bit_cast(float, rl.y), p.res16_inv, r);
+    const unsigned yoff = ok ? (unsigned)((4 * g) * y_rb + q * 4) : OOB;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = acc[s][k] + bias2[k] + r[k];
+    if (p.accum) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yoff + k * y_rb, 0, 0)) + v[k];
+    }
+    if (p.accum_div != 0.f) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] / p.accum_div;
+    }
+    if (!p.no_y) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), yrs, yoff + k * y_rb, 0, 0);
+    }
+    if (p.y16) {
+      float u[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = v[k] > 0.f ? v[k] : v[k] * p.y16_slope;
+      const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+      const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+      const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+      const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      u32x2 hv, lv;
+      hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
+      lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
+      const unsigned off = ok ? (unsigned)(((0 + gt) * p.T_q + q) * 16 + 8 * gh) : OOB;
+      __builtin_amdgcn_raw_buffer_store_b64(hv, y16rs, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(lv, y16rs, off, 2 * p.T_q * 16, 0);
+    }
+  }
+}
+
+template <int KS>
+static int launch_pair16(const ConvArgs& a, int B, hipStream_t s) {
+  ConvArgs p = a;
+  if (FP_W1 + (p.ksize - 1) * p.dil > 320) {
+    set_error("resblock_pair: dilation %d too large", p.dil);
+    return SAT_ERR_INVALID;
+  }
+  constexpr int WU = 2 * ((KS + 1) / 2) * 64;
+  const size_t lds_bytes = ((size_t)4 * 320 + 2 * WU + 4 * FP_W1) * 16;
+  auto kern = resblock_pair16_kernel<KS>;
+  if (lds_bytes > 64 * 1024)
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  dim3 grid(ceil_div(p.T_q, FP_TO), 1, B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
+  SAT_LAUNCH_CHECK("resblock_pair16_kernel");
+  return SAT_OK;
+}
+
 // f32 [B][C][T] -> split planes of lrelu(x, slope): thread = (utterance, 8-channel group, position);
 // 8 coalesced dword loads, two coalesced 16-byte stores (HBM-streaming)
 __global__ void __launch_bounds__(256) act_split_kernel(const float* __restrict__ x, uint4* __restrict__ y,
@@ -1416,6 +1638,14 @@ extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x,
   }
   SAT_REQUIRE((long long)a.rows_g * a.T_q * 4 < (1LL << 31), "resblock_pair: slab too large");
   hipStream_t s = (hipStream_t)stream;
+  if (a.cin_g == 16 && a.x16 && a.res16) {
+    // C = 16 with split planes end to end: the 16-row MFMA shape, everything resident
+    switch (a.ksize) {
+      case 3: return launch_pair16<3>(a, d->B, s);
+      case 7: return launch_pair16<7>(a, d->B, s);
+      default: return launch_pair16<11>(a, d->B, s);
+    }
+  }
   switch (a.ksize) {
     case 3: return launch_pair<3>(a, d->B, s);
     case 7: return launch_pair<7>(a, d->B, s);

@@ -353,7 +353,8 @@ def test_conv1d_f16f8_matches_its_decomposition(case):
     assert torch.equal(ys, ops.act_split(y.float().to(DEV), 0.1, fmt=1))        # output planes in the format it reads
 
 
-@pytest.mark.parametrize("case", [(16, 11, 5, 2500), (32, 3, 5, 449), (32, 7, 1, 224)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(16, 3, 1, 1000), (16, 7, 3, 700), (16, 11, 5, 2500), (16, 11, 1, 223), (32, 3, 5, 449), (32, 7, 1, 224)],
+                         ids=lambda c: "x".join(map(str, c)))
 def test_fused_pair_split_planes(case):
     ops, packing = _ops()
     C, k, d, T = case
@@ -372,6 +373,16 @@ def test_fused_pair_split_planes(case):
                       planes_residual=True, no_y=True, out=y2)
     assert (y2 == 7.0).all()
     assert (ops.unsplit(ys2) - ops.unsplit(ys)).abs().max() <= 2.0 ** -19 * x.abs().max()
+    # planes end to end with the MRF sum: out = (acc + pair(x)) / 3 in f32, plus planes of it (C = 16: the
+    # 16x16x32-MFMA kernel)
+    acc0 = _rand(2, C, T, seed=6).to(DEV)
+    out = acc0.clone()
+    ys3 = torch.zeros_like(ys)
+    ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=ops.act_split(x, 0.1), y_split=ys3, y_split_slope=0.1,
+                      planes_residual=True, out=out, accum=True, accum_div=3.0)
+    ref = (acc0 + y0) / 3
+    assert (out - ref).abs().max() <= 2e-6
+    assert (ops.unsplit(ys3) - F.leaky_relu(ref, 0.1)).abs().max() <= 2e-6
 
 
 def test_generator_split_plane_pipeline_equals_f32_handover(model, gold):
