@@ -1385,6 +1385,175 @@ static int launch_pair16(const ConvArgs& a, int B, hipStream_t s) {
   return SAT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ResBlock1 step for C = 32 with split planes end to end: the fused pair kernel above with its four
+// global-load round trips (x + W1 chunk 0, x + W1 chunk 1, W2 chunk 0, W2 chunk 1) pipelined through
+// registers — each is issued before the previous step's MFMA phase — and the residual (the input
+// planes again, L2-resident) prefetched under the last one.
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ void __launch_bounds__(256, 2) resblock_pair32_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  constexpr int CO_B = 32;
+  constexpr int XWI = 5, XWP = 64 * XWI;
+  constexpr int W_UNITS = KS * 4 * CO_B;
+  constexpr int W_IT = (W_UNITS + 255) / 256;
+  uint4* ldsx = lds4;                       // [4][XWP]       input chunk
+  uint4* ldsw = lds4 + 4 * XWP;             // [KS][4][32]    weight chunk
+  uint4* ldst = ldsw + W_UNITS;             // [2][4][FP_W1]  t1, both chunks
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * FP_TO;
+  const int h2 = (KS - 1) / 2;
+  const int xi0 = t0 - FP_OFF - p.pad_left;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.x16 + (long long)b * 32 * p.T_in * 4), 0, (unsigned)(32 * p.T_in * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)p.w_gs, 0x00020000);
+  const int seg_bytes = p.co_pad * 16;
+  const int pl = __builtin_amdgcn_readfirstlane(wave);
+
+  uint4 xst[XWI], wst[W_IT];
+  auto issue_x = [&](int chunk) {
+#pragma unroll
+    for (int it = 0; it < XWI; ++it) {
+      const int xi = xi0 + lane + 64 * it;
+      const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((pl * p.T_in + xi) * 16) : 0x80000000u;
+      xst[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, chunk * 4 * p.T_in * 16, 0));
+    }
+  };
+  auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rs, int chunk) {
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + 256 * i;
+      const unsigned voff = u < W_UNITS ? (unsigned)((u % CO_B) * 16 + (u / CO_B) * seg_bytes) : 0x80000000u;
+      wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, chunk * (KS * 4) * seg_bytes, 0));
+    }
+  };
+  auto publish_x = [&]() {
+#pragma unroll
+    for (int it = 0; it < XWI; ++it) ldsx[pl * XWP + lane + 64 * it] = xst[it];
+  };
+  auto publish_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int u = tid + 256 * i;
+      if (u < W_UNITS) ldsw[u] = wst[i];
+    }
+  };
+  f32x16 acc[1][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][n][r] = 0.f;
+  };
+  // one chunk of MFMAs: B fragments at `base + n*128 + tap*step` in an image of plane pitch `pitch`
+  auto mfma_chunk = [&](const uint4* base, int pitch, int step, bool seven) {
+    const uint4* wb = ldsw + lh * CO_B + l31;
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      const h8 a_hi = __builtin_bit_cast(h8, wb[(t * 4 + 0) * CO_B]);
+      const h8 a_lo = __builtin_bit_cast(h8, wb[(t * 4 + 2) * CO_B]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        if (!seven || wave + 4 * n < FP_TO / 32) {   // wave-uniform: conv2 has 7 output sub-tiles over 4 waves
+          const uint4* xt = base + n * 128 + t * step;
+          const h8 b_hi = __builtin_bit_cast(h8, xt[0]);
+          const h8 b_lo = __builtin_bit_cast(h8, xt[2 * pitch]);
+          acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[0][n], 0, 0, 0);
+          acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[0][n], 0, 0, 0);
+          acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[0][n], 0, 0, 0);
+        }
+      }
+    }
+  };
+  const uint4* xbase = ldsx + lh * XWP + wave * 32 + l31;
+
+  // ---- conv1, chunk 0 and 1 ----
+  issue_x(0);
+  issue_w(w1rs, 0);
+  zero_acc();
+  publish_x();
+  publish_w();
+  __syncthreads();
+  issue_x(1);
+  issue_w(w1rs, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_chunk(xbase, XWP, p.dil, false);
+  __syncthreads();
+  publish_x();
+  publish_w();
+  __syncthreads();
+  issue_w(w2rs, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_chunk(xbase, XWP, p.dil, false);
+  // t1 -> LDS as conv2's B operand (hi|lo planes of both chunks)
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = (wave + 4 * n) * 32 + l31;
+    const int pos = t0 - FP_OFF + col;
+    const bool inside = pos >= 0 && pos < p.T_in;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = acc[0][n][4 * rg + k] + p.bias1[8 * rg + 4 * lh + k];
+        t = t > 0.f ? t : t * p.in_slope;
+        v[k] = inside ? t : 0.f;
+      }
+      const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+      const auto h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+      const auto l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
+      const auto l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+      ((uint2*)(ldst + (((rg >> 1) * 4 + 0 + (rg & 1)) * FP_W1 + col)))[lh] =
+          make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+      ((uint2*)(ldst + (((rg >> 1) * 4 + 2 + (rg & 1)) * FP_W1 + col)))[lh] =
+          make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    }
+  }
+  // ---- conv2, chunk 0 and 1 ----
+  zero_acc();
+  __syncthreads();
+  publish_w();
+  __syncthreads();
+  issue_w(w2rs, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  const uint4* tbase = ldst + lh * FP_W1 + FP_OFF - h2 + wave * 32 + l31;
+  mfma_chunk(tbase, FP_W1, 1, true);
+  __syncthreads();
+  publish_w();
+  __syncthreads();
+  float rpre[1][2][16];
+  epilogue_prefetch_res<1, 2>(p, rpre, b, 0, 0, t0 + wave * 32, l31, lh, 128, t0 + FP_TO);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_chunk(tbase + 4 * FP_W1, FP_W1, 1, true);
+  conv_epilogue<1, 2, true>(p, acc, b, 0, 0, t0 + wave * 32, l31, lh, 128, t0 + FP_TO, rpre);
+}
+
+template <int KS>
+static int launch_pair32(const ConvArgs& a, int B, hipStream_t s) {
+  ConvArgs p = a;
+  if (FP_W1 + (p.ksize - 1) * p.dil > 320) {
+    set_error("resblock_pair: dilation %d too large", p.dil);
+    return SAT_ERR_INVALID;
+  }
+  const size_t lds_bytes = ((size_t)4 * 320 + (size_t)KS * 4 * 32 + (size_t)2 * 4 * FP_W1) * 16;
+  auto kern = resblock_pair32_kernel<KS>;
+  if (lds_bytes > 64 * 1024)
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  dim3 grid(ceil_div(p.T_q, FP_TO), 1, B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
+  SAT_LAUNCH_CHECK("resblock_pair32_kernel");
+  return SAT_OK;
+}
+
 // f32 [B][C][T] -> split planes of lrelu(x, slope): thread = (utterance, 8-channel group, position);
 // 8 coalesced dword loads, two coalesced 16-byte stores (HBM-streaming)
 __global__ void __launch_bounds__(256) act_split_kernel(const float* __restrict__ x, uint4* __restrict__ y,
@@ -1644,6 +1813,13 @@ extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x,
       case 3: return launch_pair16<3>(a, d->B, s);
       case 7: return launch_pair16<7>(a, d->B, s);
       default: return launch_pair16<11>(a, d->B, s);
+    }
+  }
+  if (a.cin_g == 32 && a.x16 && a.res16) {
+    switch (a.ksize) {
+      case 3: return launch_pair32<3>(a, d->B, s);
+      case 7: return launch_pair32<7>(a, d->B, s);
+      default: return launch_pair32<11>(a, d->B, s);
     }
   }
   switch (a.ksize) {

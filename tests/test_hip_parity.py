@@ -353,7 +353,7 @@ def test_conv1d_f16f8_matches_its_decomposition(case):
     assert torch.equal(ys, ops.act_split(y.float().to(DEV), 0.1, fmt=1))        # output planes in the format it reads
 
 
-@pytest.mark.parametrize("case", [(16, 3, 1, 1000), (16, 7, 3, 700), (16, 11, 5, 2500), (16, 11, 1, 223), (32, 3, 5, 449), (32, 7, 1, 224)],
+@pytest.mark.parametrize("case", [(16, 3, 1, 1000), (16, 7, 3, 700), (16, 11, 5, 2500), (16, 11, 1, 223), (32, 3, 5, 449), (32, 7, 1, 224), (32, 11, 5, 1500)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_fused_pair_split_planes(case):
     ops, packing = _ops()
