@@ -72,6 +72,7 @@ struct ConvArgs {
 };
 #ifdef SAT_STAMPS
 long long* g_stamp_buffer = nullptr;
+int g_stamp_variant = 0;   // 1: no output stores, 2: no residual, 3: neither
 #define SAT_STAMP(i) do { \
     __builtin_amdgcn_sched_barrier(0); \
     unsigned long long t_; \
@@ -909,6 +910,8 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
   ConvArgs p = a;
 #ifdef SAT_STAMPS
   p.dbg = g_stamp_buffer;
+  if (g_stamp_variant & 1) p.y16 = nullptr;
+  if (g_stamp_variant & 2) p.res16 = nullptr, p.res = nullptr;
 #endif
   p.xw = T_B + (p.ksize - 1) * p.dil;
   if (p.xw > 64 * XWI) {
@@ -917,8 +920,16 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
   }
   p.co_tiles_g = ceil_div(p.rows_g, CO_B);
   const size_t lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * CO_B) * 16;
-  auto kern = !p.x16 ? conv1d_f16x3_kernel<MT, NT, KS, XWI>
-              : p.f8 ? conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, true> : conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false>;
+  void (*kern)(const ConvArgs) = conv1d_f16x3_kernel<MT, NT, KS, XWI>;
+  if (p.x16) {
+    kern = nullptr;
+    if constexpr (KS == 3 || KS == 7 || KS == 11)   // split-plane input: the generator's tap counts only
+      kern = p.f8 ? conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, true> : conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false>;
+    if (!kern) {
+      set_error("conv1d(split planes): %d taps not instantiated (3, 7, 11)", KS);
+      return SAT_ERR_INVALID;
+    }
+  }
   if (lds_bytes > 64 * 1024)
     SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   dim3 grid(ceil_div(p.T_q, T_B), p.co_tiles_g * groups, B);

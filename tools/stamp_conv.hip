@@ -25,6 +25,7 @@ __global__ void fill(unsigned* p, size_t n, unsigned seed) {
 int main(int argc, char** argv) {
   const int C = argc > 1 ? atoi(argv[1]) : 256, T = argc > 2 ? atoi(argv[2]) : 1250;
   const int k = argc > 3 ? atoi(argv[3]) : 11, dil = argc > 4 ? atoi(argv[4]) : 5, B = argc > 5 ? atoi(argv[5]) : 32;
+  sat::g_stamp_variant = argc > 6 ? atoi(argv[6]) : 0;   // 1: no output stores, 2: no residual, 3: neither
   const size_t n = (size_t)B * C * T;
   float *res, *y;
   void *xs, *ys, *w;
@@ -42,7 +43,8 @@ int main(int argc, char** argv) {
   d.B = B; d.C_in = C; d.T_in = T; d.C_out = C; d.T_q = T; d.ksize = k; d.dilation = dil; d.stride = 1; d.groups = 1; d.up = 1;
   d.pad_left = (k * dil - dil) / 2; d.mode = SAT_CONV_F16X3;
   d.x_cstride = T; d.x_bstride = (int64_t)C * T; d.y_cstride = T; d.y_bstride = (int64_t)C * T;
-  d.res = res; d.res_scale = 1.f; d.res_cstride = T; d.res_bstride = (int64_t)C * T; d.res_tstride = 1;
+  // the generator's conv2 of a ResBlock step: residual from split planes, planes out, no f32 store
+  d.res_split = res; d.res_split_slope = 0.1f; d.res_scale = 1.f; d.res_tstride = 1; d.no_y = 1;
   d.bias = bias; d.x_split = xs; d.y_split = ys; d.y_split_slope = 0.1f;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int pass = 0; pass < 2; ++pass) {
