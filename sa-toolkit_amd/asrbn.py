@@ -63,9 +63,11 @@ class _LayerCache:
 class _TdnnfBase(nn.Module):
     """shared machinery of the two ASR-BN nets: TDNNF stack forward on the HIP kernels"""
 
-    #: arithmetic of the TDNNF matrix products: "f32" (exact f32 MFMA, default: the VQ arg-min behind this
-    #: stack is decision-critical) or "f16x3" (split-f16, ~2^-21 relative per product, about 2x faster)
-    precision = os.environ.get("SATOOLS_AMD_TDNNF_PRECISION", "f32")
+    #: arithmetic of the TDNNF matrix products: "f16x3" (split-f16 on the f16 matrix cores, ~2^-21 relative per
+    #: product — the size of the f32 re-association differences between any two f32 implementations, which is
+    #: what decides a VQ arg-min near a tie either way; VQ indices identical to the reference's on every fixture
+    #: frame with both settings, tests/test_hip_parity.py) or "f32" (exact f32 MFMA, 0.8 ms per batch slower)
+    precision = os.environ.get("SATOOLS_AMD_TDNNF_PRECISION", "f16x3")
 
     def _init_cache(self):
         self._cache = None
