@@ -16,6 +16,8 @@ Everything runs on the HIP kernels with activations channel-major [B][C][T]:
     head slice of Q / of V^T stored with row pitch 256 is exactly the kernel's packed-weight layout, so no
     batched-GEMM kernel is needed; softmax over keys is a column kernel in between.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -149,10 +151,20 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         self._w2_key = None
 
     # ---- kernel-ready weights of the wav2vec2 part -------------------------------------------
+    #: arithmetic of the wav2vec2 matrix products (conv feature extractor after layer 0, feature projection,
+    #: the 24 x 6 transformer Linear layers): "f16x3" (split-f16 on the f16 matrix cores, ~2^-21 relative per
+    #: product) or "f32" (exact f32 MFMA).  The grouped positional conv and the attention products stay f32.
+    w2v2_precision = os.environ.get("SATOOLS_AMD_W2V2_PRECISION", "f16x3")
+
     def _prepare_w2v2(self, device):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.preprocessor.parameters())
+        key = (self.w2v2_precision,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.preprocessor.parameters())
         if self._w2_key == key:
             return self._w2
+        if self.w2v2_precision not in ("f16x3", "f32"):
+            raise _lib.SatError(f"unknown wav2vec2 precision {self.w2v2_precision!r}")
+        split = self.w2v2_precision == "f16x3"
+        pack_mm = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight
+        self._mm_mode = _lib.CONV_F16X3 if split else _lib.CONV_F32
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         pre = self.preprocessor
         W = {"fe": []}
@@ -163,11 +175,11 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
                 ent["w"] = w.reshape(w.shape[0], w.shape[2]).contiguous()       # [512][10]
             else:
                 wc, kp = _polyphase_stride2_weight(w)
-                ent["w"], ent["k"] = packing.pack_conv_weight(wc), kp
+                ent["w"], ent["k"] = pack_mm(wc), kp
             W["fe"].append(ent)
         fp = pre.encoder.feature_projection
         W["fp"] = {"g": f32(fp.layer_norm.weight), "beta": f32(fp.layer_norm.bias),
-                   "w": packing.pack_conv_weight(f32(fp.projection.weight).unsqueeze(-1)), "b": f32(fp.projection.bias)}
+                   "w": pack_mm(f32(fp.projection.weight).unsqueeze(-1)), "b": f32(fp.projection.bias)}
         tr = pre.encoder.transformer
         pc = tr.pos_conv_embed.conv
         wv, wg = f32(pc.weight_v), f32(pc.weight_g)
@@ -179,14 +191,14 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             at = lay.attention
             W["layers"].append({
                 "ln1": (f32(lay.layer_norm.weight), f32(lay.layer_norm.bias)),
-                "q_w": packing.pack_conv_weight(f32(at.q_proj.weight).unsqueeze(-1)), "q_b": f32(at.q_proj.bias),
-                "k_w": packing.pack_conv_weight(f32(at.k_proj.weight).unsqueeze(-1)), "k_b": f32(at.k_proj.bias),
-                "v_w": packing.pack_conv_weight(f32(at.v_proj.weight).unsqueeze(-1)), "v_b": f32(at.v_proj.bias),
-                "o_w": packing.pack_conv_weight(f32(at.out_proj.weight).unsqueeze(-1)), "o_b": f32(at.out_proj.bias),
+                "q_w": pack_mm(f32(at.q_proj.weight).unsqueeze(-1)), "q_b": f32(at.q_proj.bias),
+                "k_w": pack_mm(f32(at.k_proj.weight).unsqueeze(-1)), "k_b": f32(at.k_proj.bias),
+                "v_w": pack_mm(f32(at.v_proj.weight).unsqueeze(-1)), "v_b": f32(at.v_proj.bias),
+                "o_w": pack_mm(f32(at.out_proj.weight).unsqueeze(-1)), "o_b": f32(at.out_proj.bias),
                 "ln2": (f32(lay.final_layer_norm.weight), f32(lay.final_layer_norm.bias)),
-                "f1_w": packing.pack_conv_weight(f32(lay.feed_forward.intermediate_dense.weight).unsqueeze(-1)),
+                "f1_w": pack_mm(f32(lay.feed_forward.intermediate_dense.weight).unsqueeze(-1)),
                 "f1_b": f32(lay.feed_forward.intermediate_dense.bias),
-                "f2_w": packing.pack_conv_weight(f32(lay.feed_forward.output_dense.weight).unsqueeze(-1)),
+                "f2_w": pack_mm(f32(lay.feed_forward.output_dense.weight).unsqueeze(-1)),
                 "f2_b": f32(lay.feed_forward.output_dense.bias),
             })
         self._w2, self._w2_key = W, key
@@ -195,6 +207,7 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
     # ---- wav2vec2 forward: [B, n] -> last layer output [B, 1024, frames] ------------------------
     def w2v2_features(self, wav):
         W = self._prepare_w2v2(wav.device)
+        mm = self._mm_mode
         B, n = wav.shape
         heads, hd = 16, 64
         # conv feature extractor
@@ -206,11 +219,11 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             x = ops.layernorm_ch(x, e["g"], e["beta"], gelu=True, split_phases=not last)
             if not last:
                 nxt = W["fe"][i + 1]
-                x = ops.conv1d(x, nxt["w"], 512, nxt["k"], bias=nxt["b"], pad_left=0, pad_right=0, t_out=self._fe_len[i + 1])
+                x = ops.conv1d(x, nxt["w"], 512, nxt["k"], bias=nxt["b"], pad_left=0, pad_right=0, t_out=self._fe_len[i + 1], mode=mm)
         T = x.shape[2]
         # feature projection
         x = ops.layernorm_ch(x, W["fp"]["g"], W["fp"]["beta"])
-        x = ops.conv1d(x, W["fp"]["w"], 1024, 1, bias=W["fp"]["b"])
+        x = ops.conv1d(x, W["fp"]["w"], 1024, 1, bias=W["fp"]["b"], mode=mm)
         # positional conv (grouped, k = 128, pad 64, last sample dropped) + GELU, added to x
         x = ops.conv1d(x, W["pos"]["w"], 1024, 128, bias=W["pos"]["b"], pad_left=64, pad_right=63, groups=16,
                        gelu=True, post_res=x)
@@ -222,19 +235,19 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             q = torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device)
             k = torch.empty_like(q)
             v = torch.empty_like(q)
-            ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], out=q[:, :, :T])
-            ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], out=k[:, :, :T])
-            ops.conv1d(h, L["v_w"], 1024, 1, bias=L["v_b"], out=v[:, :, :T])
+            ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], out=q[:, :, :T], mode=mm)
+            ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], out=k[:, :, :T], mode=mm)
+            ops.conv1d(h, L["v_w"], 1024, 1, bias=L["v_b"], out=v[:, :, :T], mode=mm)
             # S^T[j][q] = sum_c K[c][j] Q[c][q]  per (utterance, head): K as packed weights, Q as input
             st = torch.empty(G * T, tp, dtype=torch.float32, device=x.device)
             ops.attention_scores(q, k, st, B, heads, hd, T)
             ops.softmax_cols(st, G, T, scale=hd ** -0.5)
             vt = ops.transpose_heads(v, B, heads, hd, T)                           # [G][jpad][64]
             o = ops.attention_apply(st, vt, B, heads, hd, T)                        # [B, 1024, T]
-            x = ops.conv1d(o, L["o_w"], 1024, 1, bias=L["o_b"], res=x)
+            x = ops.conv1d(o, L["o_w"], 1024, 1, bias=L["o_b"], res=x, mode=mm)
             h = ops.layernorm_ch(x, *L["ln2"])
-            h = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True)
-            x = ops.conv1d(h, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x)
+            h = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True, mode=mm)
+            x = ops.conv1d(h, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm)
         return x
 
     def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
