@@ -168,6 +168,34 @@ def main():
             torch.cuda.synchronize()
             gen_ms = ev0.elapsed_time(ev1) / reps
 
+    # the single dominant kernel (20 % of GPU time in profiles/r01j_*): the 11-tap split-f16 conv of the
+    # generator's first resblock stage, timed alone with events on its launch stream
+    dom = None
+    if rank == 0 and model.hifigan.precision == "f16x3":
+        with torch.no_grad():
+            from satools_amd import ops, packing
+            C, T, k, d = 256, 1250, 11, 5
+            g = torch.Generator(device="cpu").manual_seed(0)
+            xk = torch.randn(BATCH, C, T, generator=g).to(dev)
+            wk = packing.pack_conv_weight_f16x3((torch.randn(C, C, k, generator=g) * 0.02).to(dev))
+            bk = torch.zeros(C, device=dev)
+            xs, rs, ys = ops.act_split(xk, 0.1), ops.act_split(xk * 0.5, 0.1), ops.split_like(BATCH, C, T, dev)
+            run = lambda: ops.conv1d(xk, wk, C, k, bias=bk, dilation=d, pad_left=(k * d - d) // 2, mode=1, x_split=xs,
+                                     y_split=ys, y_split_slope=0.1, res_split=rs, res_split_slope=0.1, no_y=True, out=xk)
+            for _ in range(3):
+                run()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(20):
+                run()
+            ev1.record()
+            torch.cuda.synchronize()
+            us = ev0.elapsed_time(ev1) / 20 * 1e3
+            flop = 2.0 * BATCH * C * C * k * T
+            dom = {"name": "conv1d_f16x3_planes_kernel<2,2,11,5> (C=256, T=1250, 11 taps, dilation 5, batch 32; 18 launches per forward)",
+                   "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
+                   "frac": round(flop / us / 1e6 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)}
+
     if rank == 0:
         total_audio = world * a.steps * BATCH * UTT_SECONDS
         achieved = GEN_FLOP_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
@@ -185,8 +213,12 @@ def main():
                             f"{tj['write_GB']} GB; per-layer streaming model {tj['algorithmic_GB_per_layer_model']} GB")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
-                    "kernel": ("conv1d_f16x3_kernel" if split else "conv1d_mfma_kernel") + " family: the 96 MFMA conv "
-                              f"launches of one generator forward (+ output stage), {gen_ms:.3f} ms per batch of {BATCH}",
+                    "kernel": ("split-f16 conv family (conv1d_f16x3_planes_kernel, resblock_pair16/32_kernel)" if split else "conv1d_mfma_kernel")
+                              + f": all launches of one generator forward (+ upsampler split pass and output stage), {gen_ms:.3f} ms per batch of {BATCH}",
+                    "dominant_kernel": dom,
+                    "practical_ceiling": {"value": 592.0, "unit": "TFLOP/s", "frac": round(achieved / 592.0, 4),
+                                          "note": "bare loop of the same three f16 MFMAs per product on random operands: the chip holds "
+                                                  "~1.78 GHz under that load (tools/mfma_rate.hip)"} if split else None,
                     "arithmetic": ("f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = "
                                    "dense f16 MFMA peak / 3" if split else "exact f32 MFMA"),
                     "algorithmic_flop_per_launch_group": GEN_FLOP_PER_UTT * BATCH,

@@ -23,7 +23,7 @@ def load(path, counter):
 
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    gen = lambda n: ("conv1d_f16x3" in n or "resblock_pair" in n or "convpost" in n)
+    gen = lambda n: ("conv1d_f16x3" in n or "resblock_pair" in n or "convpost" in n or "act_split" in n)
     # generator forwards in that run: 3 convert() steps + 1 warm + 3 timed forwards of the roofline probe
     n_post = fetch.get("sat::convpost_kernel", [1])[0]
     out = {"generator_forwards_in_run": n_post, "kernels": {}}
