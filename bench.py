@@ -19,8 +19,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # The path keeps several HIP streams busy per process (jobs in flight x (launch stream + YAAPT side
 # stream)); the HIP runtime multiplexes streams onto 4 hardware queues by default, which serialises
-# independent streams (measured 15.4 -> 14.3 ms/step).  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# independent streams (measured 15.4 -> 14.3 ms/step at 2 jobs).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 TAG = "hifigan_bn_tdnnf_600h_vq_48_v1"
 BATCH = 32
@@ -74,9 +74,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--jobs", type=int, default=2,
+    ap.add_argument("--jobs", type=int, default=4,
                     help="convert() calls in flight per GPU, each on its own HIP stream (the reference's "
                          "jobs_per_compute_device, satools/satools/bin/anonymize:85-93)")
     ap.add_argument("--tag", default=TAG, help="model tag (default: the headline config; the wav2vec2 tag is BASELINE configs[2])")
@@ -111,9 +111,11 @@ def main():
     f0 = analytic_f0(seeds).to(dev)
     targets = synthetic.targets(model.spk, seeds)
     gathered = ([torch.empty(world * BATCH, 1, N_SAMPLES + 1, dtype=torch.float32, device=dev)
-                 for _ in range(max(1, a.jobs))] if world > 1 else None)
+                 for _ in range(max(1, a.jobs))] if world > 1 else None)   # indexed modulo the job count
 
-    jobs = max(1, a.jobs)
+    # every job stream owns its workspaces: never more streams than warmup steps, so that each one has run
+    # (and allocated) before the timed region starts
+    jobs = max(1, min(a.jobs, a.warmup) if a.warmup > 0 else 1)
     streams = [torch.cuda.Stream(device=dev) for _ in range(jobs)]
     step_no = [0]
 

@@ -34,29 +34,58 @@ static void phase_window(int k, int u, int pad, int* dmin, int* dmax) {
 constexpr int POST_TILE = 1024;
 constexpr int POST_MAXC = 64;
 
+template <int C>
 __global__ void __launch_bounds__(256) convpost_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias,
-                                                       float* __restrict__ y, int C, int T) {
+                                                       float* __restrict__ y, int C_rt, int T) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int W = POST_TILE + 6;
-  float* wl = lds + (size_t)C * W;  // weights [C][7]
+  constexpr int NCOL = (W + 255) / 256;
+  const int Cn = C > 0 ? C : C_rt;
+  float* wl = lds + (size_t)Cn * W;  // weights [C][7]
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * POST_TILE;  // first output index of the tile
   const int To = T + 1;
-  const float* xb = x + (size_t)b * C * T;
-  for (int i = threadIdx.x; i < C * 7; i += 256) wl[i] = w[i];
-  for (int c = 0; c < C; ++c) {
-    const float* xr = xb + (size_t)c * T;
-    for (int col = threadIdx.x; col < W; col += 256) {
-      const int i = t0 - 3 + col;  // index into the reflection-padded signal
-      float v = 0.f;
-      if (i >= 0 && i < To) {
-        const int xi = i == 0 ? 1 : i - 1;
-        v = xr[xi];
-        v = v > 0.f ? v : v * 0.01f;
+  for (int i = threadIdx.x; i < Cn * 7; i += 256) wl[i] = w[i];
+  if constexpr (C > 0) {
+    // every global load of the tile is issued before the first LDS store (80 in flight per lane at C = 16);
+    // rows behind one buffer descriptor, columns outside the padded signal read as 0 by the range check
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(x + (size_t)b * C * T), 0, (unsigned)((size_t)C * T * 4), 0x00020000);
+    float v[C][NCOL];
+#pragma unroll
+    for (int k = 0; k < NCOL; ++k) {
+      const int col = threadIdx.x + 256 * k;
+      const int i = t0 - 3 + col;          // index into the reflection-padded signal
+      const int xi = i == 0 ? 1 : i - 1;
+      const unsigned voff = (col < W && i >= 0 && i < To) ? (unsigned)(xi * 4) : 0x80000000u;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        v[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, c * T * 4, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NCOL; ++k) {
+      const int col = threadIdx.x + 256 * k;
+      if (col < W) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) lds[c * W + col] = v[c][k] > 0.f ? v[c][k] : v[c][k] * 0.01f;
       }
-      lds[c * W + col] = v;
+    }
+  } else {
+    const float* xb = x + (size_t)b * Cn * T;
+    for (int c = 0; c < Cn; ++c) {
+      const float* xr = xb + (size_t)c * T;
+      for (int col = threadIdx.x; col < W; col += 256) {
+        const int i = t0 - 3 + col;
+        float v = 0.f;
+        if (i >= 0 && i < To) {
+          const int xi = i == 0 ? 1 : i - 1;
+          v = xr[xi];
+          v = v > 0.f ? v : v * 0.01f;
+        }
+        lds[c * W + col] = v;
+      }
     }
   }
   __syncthreads();
@@ -67,7 +96,8 @@ __global__ void __launch_bounds__(256) convpost_kernel(const float* __restrict__
     const int t = t0 + lt;
     if (t >= To) continue;
     float acc = 0.f;
-    for (int c = 0; c < C; ++c) {
+#pragma unroll 4
+    for (int c = 0; c < Cn; ++c) {
       const float* row = lds + c * W + lt;
       const float* wr = wl + c * 7;
 #pragma unroll
@@ -230,11 +260,14 @@ extern "C" int sat_hifigan_convpost_f32(const float* x, const float* w, const fl
   SAT_REQUIRE(x && w && bias && y, "convpost: null pointer");
   SAT_REQUIRE(B > 0 && C > 0 && C <= POST_MAXC && T >= 2, "convpost: unsupported shape B=%d C=%d T=%d", B, C, T);
   const size_t lds = ((size_t)C * (POST_TILE + 6) + (size_t)C * 7) * sizeof(float);
+  // C = 16 (the reference generator's last stage): batched tile loads; the accumulation order over (c, j) is
+  // the same in both instantiations
+  auto kern = (C == 16 && (size_t)C * T * 4 < (1ull << 31)) ? convpost_kernel<16> : convpost_kernel<0>;
   if (lds > 64 * 1024) {
-    SAT_HIP(hipFuncSetAttribute((const void*)convpost_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   dim3 grid(ceil_div(T + 1, POST_TILE), B);
-  hipLaunchKernelGGL(convpost_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, T);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, T);
   SAT_LAUNCH_CHECK("convpost_kernel");
   return SAT_OK;
 }
