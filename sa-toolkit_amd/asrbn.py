@@ -114,10 +114,24 @@ class _TdnnfBase(nn.Module):
         self._cache = cache
         self._cache_key = key
 
-    def _tdnnf_layer(self, lay, c, x, return_bottleneck=False, want_aux=False):
-        """x [B, feat, T] -> [B, out, T'] (or the bottleneck [B, bott, T'])"""
+    def _tdnnf_layer(self, lay, c, x, xs=None, return_bottleneck=False, want_aux=False):
+        """x [B, feat, T] -> [B, out, T'] (or the bottleneck [B, bott, T']).  In split-f16 mode the layers
+        hand their activations on as split planes as well (`xs`, csrc/conv1d_mfma.hip): linearB then
+        stages its 1024 x 3 input with 16-byte copies and linearA reads the bottleneck from planes; the
+        f32 tensor stays for the bypass connection.  Returns (y, planes of y or None)."""
         ctx, sub = lay.context_len, int(lay.subsampling_factor)
-        z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, stride=sub, pad_left=0, pad_right=0, mode=c.modeB)
+        B = x.shape[0]
+        planes_in = c.modeB == 1 and xs is not None and x.shape[1] % 16 == 0
+        need_z = c.codebook is not None or return_bottleneck
+        zs = None
+        if planes_in and not need_z and lay.bottleneck_dim % 16 == 0:
+            t_q = x.shape[2] - (ctx - 1)
+            zs = ops.split_like(B, lay.bottleneck_dim, t_q, x.device)
+            z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, pad_left=0, pad_right=0, mode=1,
+                           x_split=xs, y_split=zs, y_split_slope=1.0, no_y=True)     # z: shape carrier only
+        else:
+            z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, stride=sub, pad_left=0, pad_right=0, mode=c.modeB,
+                           x_split=xs if planes_in else None)
         aux = None
         if c.codebook is not None:
             zq, idx, dist = ops.vq(z, c.codebook, want_dist=want_aux)
@@ -131,15 +145,21 @@ class _TdnnfBase(nn.Module):
             if ctx == 2:
                 lidx = 1
             kw = dict(res=x, res_scale=lay.bypass_scale, res_toff=lidx, res_tstride=sub)
-        return ops.conv1d(z, c.wA, lay.out_dim, 1, bias=c.bA, ch_scale=c.scale, ch_shift=c.shift, relu=True, mode=c.modeA, **kw)
+        ys = None
+        if c.modeA == 1 and lay.out_dim % 16 == 0:
+            ys = ops.split_like(B, lay.out_dim, z.shape[2], x.device)
+        y = ops.conv1d(z, c.wA, lay.out_dim, 1, bias=c.bA, ch_scale=c.scale, ch_shift=c.shift, relu=True, mode=c.modeA,
+                       x_split=zs, y_split=ys, y_split_slope=1.0, **kw)
+        return y, ys
 
     def _run_stack(self, x, want_aux=False):
         """x [B, C, T] (already padded) through tdnn1, tdnnfs[:-2], and the bottleneck of tdnnfs[-2]"""
         self._prepare(x.device)
         layers = self._stack_layers()
+        xs = None
         for lay, c in zip(layers[:-1], self._cache[:-1]):
-            x = self._tdnnf_layer(lay, c, x)
-        return self._tdnnf_layer(layers[-1], self._cache[-1], x, return_bottleneck=True, want_aux=want_aux)
+            x, xs = self._tdnnf_layer(lay, c, x, xs)
+        return self._tdnnf_layer(layers[-1], self._cache[-1], x, xs, return_bottleneck=True, want_aux=want_aux)
 
 
 class _AsrHead(nn.Module):

@@ -726,7 +726,10 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) 
 // un-pipelined form spent 1.7-2.7k cycles per chunk waiting on loads and 22-32k cycles in the epilogue
 // against a 4.2k-cycle MFMA phase (k = 11).
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int KS, int XWI, bool F8>
+// S: 16-channel sub-chunks per pipeline stage.  With few taps the matrix work of a 16-channel chunk (1152
+// cycles at 3 taps) is dwarfed by the ~2800 cycles of barriers, LDS stores and load issue around it: S = 2
+// halves the number of stages.
+template <int MT, int NT, int KS, int XWI, bool F8, int S>
 __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   constexpr int CO_B = 32 * MT;
@@ -734,8 +737,9 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvA
   constexpr int XWP = 64 * XWI;
   constexpr int W_UNITS = KS * 4 * CO_B;
   constexpr int W_IT = (W_UNITS + 255) / 256;
-  uint4* ldsx = lds4;                     // [4][XWP]
-  uint4* ldsw = lds4 + 4 * XWP;           // [KS][2][2][CO_B]
+  uint4* ldsx = lds4;                     // [S][4][XWP]
+  uint4* ldsw = lds4 + S * 4 * XWP;       // [S][KS][2][2][CO_B]
+  static_assert(!F8 || S == 1, "e4m3 cross terms: one sub-chunk per stage");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -747,7 +751,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvA
   const int q_b = blockIdx.x * T_B;
   const int q_w = q_b + wave * (32 * NT);
   const int xi0 = q_b - p.pad_left;
-  const int nch = p.cin_pad / CI_CHUNK;
+  const int nch = p.cin_pad / CI_CHUNK / S;   // pipeline stages
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.x16 + (long long)b * p.cin_g * p.T_in * 4), 0, (unsigned)(p.cin_g * p.T_in * 4), 0x00020000);
@@ -764,39 +768,50 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  uint4 wst[W_IT], xst[XWI];
-  auto issue_loads = [&](int chunk) {
+  uint4 wst[S][W_IT], xst[S][XWI];
+  auto issue_loads = [&](int stage) {
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int u = tid + 256 * i;
-      const int seg = u / CO_B, r = u % CO_B;
-      wst[i] = make_uint4(0, 0, 0, 0);
-      if (u < W_UNITS)
-        wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
-                                               wrs, (co_w + r) * 16 + seg * seg_bytes, chunk * (KS * 4) * seg_bytes, 0));
-    }
+    for (int sc = 0; sc < S; ++sc) {
+      const int chunk = stage * S + sc;
 #pragma unroll
-    for (int it = 0; it < XWI; ++it) {
-      const int xi = xi0 + lane + 64 * it;
-      const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((pl * p.T_in + xi) * 16) : 0x80000000u;
-      xst[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, chunk * x_chunk_bytes, 0));
+      for (int i = 0; i < W_IT; ++i) {
+        const int u = tid + 256 * i;
+        const int seg = u / CO_B, r = u % CO_B;
+        wst[sc][i] = make_uint4(0, 0, 0, 0);
+        if (u < W_UNITS)
+          wst[sc][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      wrs, (co_w + r) * 16 + seg * seg_bytes, chunk * (KS * 4) * seg_bytes, 0));
+      }
+#pragma unroll
+      for (int it = 0; it < XWI; ++it) {
+        const int xi = xi0 + lane + 64 * it;
+        const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((pl * p.T_in + xi) * 16) : 0x80000000u;
+        xst[sc][it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, chunk * x_chunk_bytes, 0));
+      }
     }
   };
   auto publish = [&]() {
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int u = tid + 256 * i;
-      if (u < W_UNITS) ldsw[u] = wst[i];
-    }
+    for (int sc = 0; sc < S; ++sc) {
 #pragma unroll
-    for (int it = 0; it < XWI; ++it) ldsx[pl * XWP + lane + 64 * it] = xst[it];
+      for (int i = 0; i < W_IT; ++i) {
+        const int u = tid + 256 * i;
+        if (u < W_UNITS) ldsw[sc * W_UNITS + u] = wst[sc][i];
+      }
+#pragma unroll
+      for (int it = 0; it < XWI; ++it) ldsx[(sc * 4 + pl) * XWP + lane + 64 * it] = xst[sc][it];
+    }
   };
-  const uint4* xb = ldsx + lh * XWP + wave * (32 * NT) + l31;
-  const uint4* wb = ldsw + lh * CO_B + l31;
+  const uint4* xb0 = ldsx + lh * XWP + wave * (32 * NT) + l31;
+  const uint4* wb0 = ldsw + lh * CO_B + l31;
   // F8: per-lane E8M0 scale bytes of the cross-term MFMA (lanes 0-31: W_lo8 . x_hi8, lanes 32-63: W_hi8 . x_lo8)
   const int sc_a = lh ? F8_E_WHI : F8_E_WLO;
   const int sc_b = lh ? F8_E_XLO : F8_E_XHI;
   auto mfma_phase = [&]() {
+#pragma unroll
+   for (int sc = 0; sc < S; ++sc) {
+    const uint4* xb = xb0 + sc * 4 * XWP;
+    const uint4* wb = wb0 + sc * W_UNITS;
     if constexpr (F8) {
       // hi*hi on the f16 MFMA per tap; both cross terms of a PAIR of taps in one block-scaled e4m3
       // MFMA (K = 64 = 2 terms x 2 taps x 16 channels) at twice the f16 rate per K
@@ -868,6 +883,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvA
           }
       }
     }
+   }
   };
 
   int chunk = 0;
@@ -919,14 +935,25 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
     return SAT_ERR_INVALID;
   }
   p.co_tiles_g = ceil_div(p.rows_g, CO_B);
-  const size_t lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * CO_B) * 16;
+  size_t lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * CO_B) * 16;
   void (*kern)(const ConvArgs) = conv1d_f16x3_kernel<MT, NT, KS, XWI>;
   if (p.x16) {
     kern = nullptr;
-    if constexpr (KS == 3 || KS == 7 || KS == 11)   // split-plane input: the generator's tap counts only
-      kern = p.f8 ? conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, true> : conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false>;
+    // split-plane input: the tap counts of the generator (3, 7, 11) and of the TDNNF stack (1, 3)
+    if constexpr (KS == 3 || KS == 7 || KS == 11)
+      kern = p.f8 ? conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, true, 1> : conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 1>;
+    if constexpr ((KS == 1 || KS == 3) && MT == 2) {
+      // few taps: two 16-channel sub-chunks per pipeline stage
+      if (!p.f8 && (p.cin_pad / CI_CHUNK) % 2 == 0) {
+        kern = conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 2>;
+        lds_bytes *= 2;
+      }
+    }
+    if constexpr (KS == 1) {
+      if (!kern && !p.f8) kern = conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 1>;
+    }
     if (!kern) {
-      set_error("conv1d(split planes): %d taps not instantiated (3, 7, 11)", KS);
+      set_error("conv1d(split planes): %d taps not instantiated", KS);
       return SAT_ERR_INVALID;
     }
   }
