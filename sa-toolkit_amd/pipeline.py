@@ -1,0 +1,316 @@
+"""Data plane of the `anonymize` batch job: wav.scp in, anonymized PCM16 wavs + wav.scp out
+(reference: satools/satools/bin/anonymize:22-110, satools/satools/bin/pipeline.py:19-187,
+satools/satools/script_utils.py:495-525, satools/satools/utils/kaldi.py:85-128).
+
+Same observable behaviour as the reference's job — the same shards (`split_dict`), the same batches in the
+same order (the F0 normalisation and `pad_input` are batch-coupled, so batch composition is part of the
+result), the same target choices for the same `random` state, the same output tree — on a data plane laid
+out for one MI355X per process:
+
+  * F0 is computed on the GPU inside `convert()`; the reference runs YAAPT in up to 18 DataLoader worker
+    PROCESSES per job and hands the track over through `set_f0`.  Here the loader threads only read audio.
+  * `jobs_per_compute_device` shards of one GPU are served by ONE process, each shard on its own HIP stream
+    (the reference forks one process per shard and lets the driver time-slice them).
+  * crop + PCM16 encoding + file writing happen on a small thread pool while the next batch runs (the
+    reference forks a process per batch).
+
+torchaudio is third-party to the reference and not present: wav decoding / PCM_S16 encoding are restated
+with scipy / numpy (`load_wav_from_scp`, `save_pcm16`) — parity unpinned for the float -> int16 rounding."""
+import glob
+import io
+import logging
+import os
+import random
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .infer_helper import load_model
+
+
+# ---- script_utils.py:495-525 -------------------------------------------------------------------
+def read_wav_scp(wav_scp):
+    """kaldi table file -> dict: first column -> rest of the line joined by single spaces"""
+    utt2wav = {}
+    with open(wav_scp) as ipf:
+        for line in ipf:
+            lns = line.strip().split()
+            utt2wav[lns[0]] = " ".join(lns[1:])
+    return utt2wav
+
+
+def split_dict(a, n):
+    """n contiguous shards in key order, the first len(a) % n one longer"""
+    keys = list(a.keys())
+    k, m = divmod(len(keys), n)
+    return [{key: a[key] for key in keys[i * k + min(i, m):(i + 1) * k + min(i + 1, m)]} for i in range(n)]
+
+
+# ---- utils/kaldi.py:85-128 (torchaudio.load restated) ---------------------------------------------
+def _decode_wav(fileobj):
+    from scipy.io import wavfile
+    sr, data = wavfile.read(fileobj)
+    if data.dtype == np.int16:
+        x = data.astype(np.float32) / 32768.0
+    elif data.dtype == np.int32:
+        x = data.astype(np.float32) / 2147483648.0
+    elif data.dtype == np.uint8:
+        x = (data.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = data.astype(np.float32)
+    if x.ndim == 1:
+        x = x[None, :]
+    else:
+        x = x.T
+    return torch.from_numpy(np.ascontiguousarray(x)), int(sr)
+
+
+def load_wav_from_scp(wav, frame_offset=0, num_frames=-1):
+    """a wav.scp entry (a path, or a shell command ending in `|` that writes a wav to stdout) -> ([channels, n] f32
+    in [-1, 1], sample rate)"""
+    wav = wav.strip()
+    if wav.endswith("|"):
+        with open(os.devnull, "w") as devnull:
+            try:
+                proc = subprocess.Popen(wav[:-1], stdout=subprocess.PIPE, shell=True, stderr=devnull)
+                sample, sr = _decode_wav(io.BytesIO(proc.communicate()[0]))
+            except Exception as e:
+                raise IOError("Error processing wav file: {}\n{}".format(wav, e))
+    else:
+        sample, sr = _decode_wav(wav)
+    if frame_offset or num_frames >= 0:
+        end = None if num_frames < 0 else frame_offset + num_frames
+        sample = sample[:, frame_offset:end]
+    return sample, sr
+
+
+def save_pcm16(path, wav, freq):
+    """torchaudio.save(path, wav, freq, encoding='PCM_S', bits_per_sample=16) restated: [channels, n] f32 -> RIFF"""
+    from scipy.io import wavfile
+    x = wav.detach().cpu().numpy().astype(np.float64)
+    pcm = np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16)
+    wavfile.write(str(path), int(freq), np.ascontiguousarray(pcm.T))
+
+
+# ---- pipeline.py:19-66 ---------------------------------------------------------------------------
+def copy_data_dir(dataset_path, output_path):
+    """utt2spk, wav.scp ... but not the directories inside (they may hold clear or anonymized wavs)"""
+    os.makedirs(output_path, exist_ok=True)
+    for p in glob.glob(str(Path(dataset_path) / "*"), recursive=False):
+        if os.path.isfile(p):
+            shutil.copy(p, output_path)
+
+
+def collate_fn(item_list):
+    """zero-pad audio (and f0 when present) to the batch maximum -> (audio [B, n_max], f0 [B, T_max] or None,
+    lengths [B] int64, utids, freqs)"""
+    batch_size = len(item_list)
+    audios = [i["audio"] for i in item_list]
+    lengths = torch.tensor([a.shape[-1] for a in audios])
+    out = torch.zeros([batch_size, int(torch.max(lengths).item())])
+    for i, a in enumerate(audios):
+        out[i, :a.shape[-1]] = a.squeeze()
+    f0 = None
+    if all(i.get("f0") is not None for i in item_list):
+        f0s = [i["f0"] for i in item_list]
+        f0 = torch.zeros([batch_size, max(f.shape[-1] for f in f0s)])
+        for i, f in enumerate(f0s):
+            f0[i, :f.shape[-1]] = f.squeeze()
+    return out, f0, lengths, [i["utid"] for i in item_list], [i["freq"] for i in item_list]
+
+
+class TargetSelector:
+    """the six target-selection algorithms of pipeline.py:109-143, with the reference's call sequence on a
+    `random.Random` stream.  The reference's jobs are forked children: each starts from the PARENT's global
+    `random` state, so every shard replays the same stream — pass `random.getstate()` of the launcher."""
+
+    ALGORITHMS = ("constant", "none", "bad_for_evaluation", "random_per_utt", "random_per_spk_uniq", "random_per_spk")
+
+    def __init__(self, algorithm, possible_targets, source_utt2spk, constant_spkid="?", rng_state=None):
+        if algorithm not in self.ALGORITHMS:
+            raise ValueError(f"{algorithm} not implemented")
+        self.algorithm = algorithm
+        self.possible_targets = None if possible_targets is None else list(possible_targets)
+        self.source_utt2spk = source_utt2spk
+        self.constant_spkid = constant_spkid
+        self.out_spk2target = {}
+        self.rng = random.Random()
+        self.rng.setstate(rng_state if rng_state is not None else random.getstate())
+
+    def __call__(self, utids):
+        a, rng = self.algorithm, self.rng
+        if a == "constant":
+            return [self.constant_spkid] * len(utids)
+        if a == "none":
+            return []
+        out = []
+        for ut in utids:
+            if a == "random_per_utt":
+                out.append(rng.choice(self.possible_targets))
+                continue
+            spk = self.source_utt2spk[ut]
+            if a == "bad_for_evaluation":
+                if spk not in self.out_spk2target:
+                    self.out_spk2target[spk] = rng.sample(self.possible_targets, 2)
+                out.append(rng.choice(self.out_spk2target[spk]))
+            elif a == "random_per_spk_uniq":
+                if spk not in self.out_spk2target:
+                    self.out_spk2target[spk] = rng.choice(self.possible_targets)
+                    self.possible_targets.remove(self.out_spk2target[spk])     # one target per source speaker
+                out.append(self.out_spk2target[spk])
+            else:   # random_per_spk
+                if spk not in self.out_spk2target:
+                    self.out_spk2target[spk] = rng.choice(self.possible_targets)
+                out.append(self.out_spk2target[spk])
+        return out
+
+
+class _Shard:
+    """one reference 'job': a shard of wav.scp, its batches in order, its target selector, its stream"""
+
+    def __init__(self, wavscp, batch_size, selector, stream):
+        self.items = list(wavscp.items())
+        self.batch_size = batch_size
+        self.selector = selector
+        self.stream = stream
+        self.pos = 0
+
+    def next_keys(self):
+        if self.pos >= len(self.items):
+            return None
+        chunk = self.items[self.pos:self.pos + self.batch_size]
+        self.pos += self.batch_size
+        return chunk
+
+
+def process_data(dataset_path, target_selection_algorithm, wavscps, settings, progress=None, model=None, rng_state=None,
+                 scp_out=None, f0_mode="per_utterance"):
+    """anonymize the shard(s) `wavscps` (a dict, or a list of dicts = the jobs of this compute device) of the
+    kaldi data dir `dataset_path` into `<dataset_path><new_datadir_suffix>/` (pipeline.py:68-187).
+    `settings`: an object with the reference's Pipeline fields (+ `device`).  Returns the number of utterances.
+
+    f0_mode "per_utterance" (default, the reference's semantics: its Dataset runs get_f0 on every utterance at
+    its own length, the collate zero-pads the tracks, `set_f0` hands them over; utterances of equal length in a
+    batch share one YAAPT launch) or "batch" (YAAPT once on the zero-padded batch inside convert(): the same
+    result when the utterances of a batch have one length, faster otherwise).
+    scp_out: where the `utt path` lines go (default `<out>/wav.scp`; the CLI gives every process its own part
+    file and merges them — the reference lets its jobs overwrite each other's wav.scp)."""
+    if isinstance(wavscps, dict):
+        wavscps = [wavscps]
+    dataset_path = Path(str(dataset_path))
+    output_path = Path(str(dataset_path) + settings.new_datadir_suffix)
+    device = torch.device(settings.device)
+    copy_data_dir(dataset_path, output_path)
+    results_dir = output_path / settings.results_dir
+    os.makedirs(results_dir, exist_ok=True)
+
+    if model is None:
+        option_args = {}
+        if settings.f0_modification != "":
+            option_args["f0_transformation"] = settings.f0_modification
+        model = load_model(settings.model, option_args=option_args)
+        model.to(device)
+        model.eval()
+    possible_targets = model.spk.copy() if hasattr(model, "spk") else None
+    if possible_targets is None:
+        logging.info("Model without explicit target")
+    source_utt2spk = read_wav_scp(dataset_path / "utt2spk")
+    if rng_state is None:
+        rng_state = random.getstate()
+
+    use_streams = device.type == "cuda"
+    shards = [_Shard(w, settings.batch_size,
+                     TargetSelector(target_selection_algorithm, possible_targets, source_utt2spk,
+                                    getattr(settings, "target_constant_spkid", "?"), rng_state),
+                     torch.cuda.Stream(device=device) if use_streams else None) for w in wavscps]
+
+    nj = max(1, min(int(settings.data_loader_nj), 18))
+    readers = ThreadPoolExecutor(max_workers=nj)
+    writers = ThreadPoolExecutor(max_workers=4)
+
+    def read_batch(chunk):
+        items = []
+        for utid, entry in chunk:
+            audio, freq = load_wav_from_scp(str(entry))
+            items.append({"utid": utid, "audio": audio, "f0": None, "freq": freq})
+        return collate_fn(items)
+
+    def write_batch(wav_conv, done_event, utid, freq, original_len):
+        if done_event is not None:
+            done_event.synchronize()
+        for i in range(wav_conv.shape[0]):
+            wav = wav_conv[i]
+            if len(wav.shape) == 1:
+                wav = wav.unsqueeze(0)
+            save_pcm16(results_dir / f"{utid[i]}.wav", wav[:, :int(original_len[i])], freq)
+
+    pending_writes, n_done = [], 0
+    scp_lines = [[] for _ in shards]
+    # round-robin over the jobs of this device: one batch of each in flight, each on its own stream; the next
+    # batches are being read meanwhile
+    prefetch = [readers.submit(read_batch, c) if (c := s.next_keys()) else None for s in shards]
+    with torch.no_grad():
+        while any(p is not None for p in prefetch):
+            for si, sh in enumerate(shards):
+                if prefetch[si] is None:
+                    continue
+                audio, _f0, original_len, utid, freq = prefetch[si].result()
+                nxt = sh.next_keys()
+                prefetch[si] = readers.submit(read_batch, nxt) if nxt else None
+                targets = sh.selector(utid)
+                kw = {"target": targets} if len(targets) != 0 else {}
+                ctx = torch.cuda.stream(sh.stream) if sh.stream is not None else _null()
+                with ctx:
+                    x = audio.pin_memory().to(device, non_blocking=True) if use_streams else audio.to(device)
+                    if f0_mode == "per_utterance":
+                        tracks = [None] * len(utid)
+                        by_len = {}
+                        for i, n in enumerate(original_len.tolist()):
+                            by_len.setdefault(n, []).append(i)
+                        for n, idx in by_len.items():
+                            f0g = model.get_f0(x[idx, :n])
+                            for j, i in enumerate(idx):
+                                tracks[i] = f0g[j]
+                        f0 = torch.zeros(len(utid), max(t.shape[-1] for t in tracks), dtype=torch.float32, device=tracks[0].device)
+                        for i, t in enumerate(tracks):
+                            f0[i, :t.shape[-1]] = t.reshape(-1)
+                        model.set_f0(f0.to(device))
+                    elif f0_mode != "batch":
+                        raise ValueError(f"unknown f0_mode {f0_mode!r}")
+                    wav_conv = model.convert(x, **kw)
+                    if use_streams:
+                        host = torch.empty(wav_conv.shape, dtype=wav_conv.dtype, pin_memory=True)
+                        host.copy_(wav_conv, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(sh.stream)
+                    else:
+                        host, ev = wav_conv.cpu(), None
+                pending_writes.append(writers.submit(write_batch, host, ev, utid, freq[0], original_len))
+                for u in utid:
+                    scp_lines[si].append(f"{u} {results_dir / f'{u}.wav'}\n")
+                n_done += len(utid)
+                if progress is not None:
+                    with progress.get_lock():
+                        progress.value += len(utid)
+    for w in pending_writes:
+        w.result()
+    readers.shutdown()
+    writers.shutdown()
+    # like the reference, each job (re)writes wav.scp of the output dir with ITS utterances; with several jobs
+    # per process the lines are concatenated in job order
+    with open(scp_out if scp_out is not None else output_path / "wav.scp", "wt", encoding="utf-8") as writer:
+        for lines in scp_lines:
+            writer.writelines(lines)
+    return n_done
+
+
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

@@ -1,0 +1,88 @@
+"""`anonymize` data plane on the GPU: the batch job's outputs are model.convert's"""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = "hifigan_bn_tdnnf_600h_vq_48_v1"
+
+
+def _dataset(root, lengths):
+    from pipeline_toy import write_wav
+    from satools_amd import synthetic
+    os.makedirs(os.path.join(root, "clear"), exist_ok=True)
+    scp, u2s = [], []
+    for i, n in enumerate(lengths):
+        x = synthetic.harm_batch([i], n)[0].numpy().astype(np.float64)
+        path = os.path.join(root, "clear", f"utt{i:02d}.wav")
+        write_wav(path, x)
+        scp.append(f"utt{i:02d} {path}\n")
+        u2s.append(f"utt{i:02d} src{i % 2}\n")
+    open(os.path.join(root, "wav.scp"), "w").writelines(scp)
+    open(os.path.join(root, "utt2spk"), "w").writelines(u2s)
+
+
+def test_process_data_outputs_are_convert_outputs(tmp_path):
+    import satools_amd
+    from satools_amd import pipeline as pl
+    from pipeline_toy import read_wav
+    data = str(tmp_path / "data" / "toy")
+    _dataset(data, [16000, 16000, 16000, 12800, 12800])
+    model = satools_amd.load_model("synthetic:" + TAG)
+    model.to("cuda")
+    model.eval()
+    target = model.spk[5]
+    settings = types.SimpleNamespace(model="-", f0_modification="", target_constant_spkid=target, results_dir="wav",
+                                     batch_size=3, data_loader_nj=2, new_datadir_suffix="_anon", device="cuda")
+    scp = pl.read_wav_scp(os.path.join(data, "wav.scp"))
+    n = pl.process_data(data, "constant", scp, settings, model=model)
+    assert n == 5
+    # batch 0: three utterances of one length -> exactly convert() of that batch
+    wavs = torch.cat([pl.load_wav_from_scp(scp[f"utt{i:02d}"])[0] for i in range(3)]).to("cuda")
+    ref = model.convert(wavs, target=[target] * 3).cpu()
+    for i in range(3):
+        got, sr = read_wav(os.path.join(data + "_anon", "wav", f"utt{i:02d}.wav"))
+        exp = np.clip(np.rint(ref[i, 0, :16000].numpy().astype(np.float64) * 32768), -32768, 32767).astype(np.int16)
+        assert sr == 16000 and got.shape == (16000,) and np.array_equal(got, exp)
+    # batch 1: two utterances of 12800 samples, cropped to their length
+    for i in (3, 4):
+        got, _ = read_wav(os.path.join(data + "_anon", "wav", f"utt{i:02d}.wav"))
+        assert got.shape == (12800,) and np.abs(got).max() > 0
+
+
+def test_anonymize_cli_two_jobs(tmp_path):
+    data = str(tmp_path / "data" / "toy")
+    _dataset(data, [16000] * 6)
+    cfg = tmp_path / "anon.cfg"
+    cfg.write_text(f"""[var]
+tag = {TAG}
+[cmd]
+device = cuda
+ngpu = 0
+jobs_per_compute_device = 2
+pipeline = pipe
+[pipe]
+model = synthetic:${{:tag}}
+f0_modification = quant_16_awgn_2
+target_selection_algorithm = random_per_spk
+batch_size = 2
+data_loader_nj = 2
+""")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "anonymize"), "--config", str(cfg), "--directory", data],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = data + "_anon"
+    lines = [l.split() for l in open(os.path.join(out, "wav.scp")).read().splitlines()]
+    assert [l[0] for l in lines] == [f"utt{i:02d}" for i in range(6)]
+    from pipeline_toy import read_wav
+    for u, path in lines:
+        pcm, sr = read_wav(path)
+        assert sr == 16000 and pcm.shape == (16000,) and np.abs(pcm).max() > 0
+    assert os.path.exists(os.path.join(out, "utt2spk")) and not [f for f in os.listdir(out) if f.startswith(".wav.scp.part")]

@@ -1,0 +1,94 @@
+"""`anonymize` data plane against fixtures recorded from the reference's own process_data /
+collate_fn / split_dict run on the same toy data dir with the same stand-in model
+(tests/golden/make_pipeline_fixtures.py): shards, batch composition and order, the `random` call sequence
+of the six target-selection algorithms, F0 hand-over shapes, cropping, PCM16 output, output tree."""
+import json
+import multiprocessing
+import os
+import random
+import types
+
+import pytest
+import torch
+
+import satools_amd   # noqa: F401
+from satools_amd import pipeline as pl
+from pipeline_toy import StandInModel, make_dataset, read_wav
+
+FX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fx_pipeline.json")))
+
+
+def test_read_wav_scp_and_split_dict(tmp_path):
+    data = tmp_path / "data" / "toy"
+    make_dataset(str(data))
+    scp = pl.read_wav_scp(data / "wav.scp")
+    assert list(scp.keys()) == FX["read_wav_scp_keys"]
+    assert [list(d.keys()) for d in pl.split_dict(scp, 3)] == FX["split_dict_12_into_3"]
+    assert [list(d.keys()) for d in pl.split_dict(scp, 5)] == FX["split_dict_12_into_5"]
+    assert [list(d.keys()) for d in pl.split_dict({f"k{i}": str(i) for i in range(10)}, 3)] == FX["split_dict_10_into_3"]
+
+
+def test_collate_fn_matches_reference():
+    items = [{"utid": f"u{i}", "audio": torch.arange(n, dtype=torch.float32).unsqueeze(0) / 100, "f0": torch.ones(1, n // 3) * i, "freq": 16000}
+             for i, n in enumerate((7, 12, 9))]
+    a, f0, lens, utids, freqs = pl.collate_fn(items)
+    c = FX["collate"]
+    assert a.tolist() == c["audio"] and f0.tolist() == c["f0"] and lens.tolist() == c["lengths"]
+    assert utids == c["utids"] and freqs == c["freqs"]
+
+
+@pytest.mark.parametrize("algo", list(FX["runs"].keys()))
+def test_process_data_matches_reference_run(tmp_path, algo):
+    data = tmp_path / "data" / "toy"
+    make_dataset(str(data))
+    settings = types.SimpleNamespace(model="stand-in", f0_modification="quant_16_awgn_2", target_constant_spkid="tgt007",
+                                     results_dir="wav", batch_size=5, data_loader_nj=2, new_datadir_suffix="_anon", device="cpu")
+    StandInModel.calls = []
+    random.seed(0)
+    progress = multiprocessing.Value("i", 0)
+    n = pl.process_data(str(data), algo, pl.read_wav_scp(data / "wav.scp"), settings, progress, model=StandInModel())
+    ref = FX["runs"][algo]
+    assert n == 12 and progress.value == 12
+    assert StandInModel.calls == ref["calls"]                        # batch shapes, targets, f0 hand-over, in order
+    out = str(data) + "_anon"
+    assert open(os.path.join(out, "wav.scp")).read().replace(str(tmp_path), "$ROOT") == ref["wav_scp"]
+    assert {u: len(read_wav(os.path.join(out, "wav", u + ".wav"))[0]) for u in ref["out_lengths"]} == ref["out_lengths"]
+    assert sorted(f for f in os.listdir(out) if os.path.isfile(os.path.join(out, f))) == ref["copied_files"]
+    pcm, sr = read_wav(os.path.join(out, "wav", "utt03.wav"))
+    assert sr == 16000 and pcm[:16].tolist() == FX["utt03_first_pcm"]
+
+
+def test_jobs_of_one_device_keep_their_shards_and_rng(tmp_path):
+    """two jobs served by one process: each shard keeps its own batches and replays the launcher's random stream
+    (the reference forks one process per job from the same parent state)"""
+    data = tmp_path / "data" / "toy"
+    make_dataset(str(data))
+    scp = pl.read_wav_scp(data / "wav.scp")
+    shards = pl.split_dict(scp, 2)
+    settings = types.SimpleNamespace(model="stand-in", f0_modification="", target_constant_spkid="?", results_dir="wav",
+                                     batch_size=4, data_loader_nj=1, new_datadir_suffix="_anon", device="cpu")
+    random.seed(3)
+    state = random.getstate()
+    StandInModel.calls = []
+    pl.process_data(str(data), "random_per_utt", shards, settings, model=StandInModel(), rng_state=state)
+    both = StandInModel.calls
+    lines = open(str(data) + "_anon/wav.scp").read().split("\n")
+    assert [l.split()[0] for l in lines if l] == list(scp.keys())
+    singles = []
+    for sh in shards:
+        StandInModel.calls = []
+        pl.process_data(str(data), "random_per_utt", sh, settings, model=StandInModel(), rng_state=state)
+        singles.append(StandInModel.calls)
+    # interleaved round-robin: job 0 batch 0, job 1 batch 0, job 0 batch 1, ...
+    assert both[0::2] == singles[0] and both[1::2] == singles[1]
+
+
+def test_pipe_entries_and_unknown_algorithm(tmp_path):
+    data = tmp_path / "d"
+    make_dataset(str(data))
+    path = str(data / "clear" / "utt00.wav")
+    a, sr = pl.load_wav_from_scp(path)
+    b, _ = pl.load_wav_from_scp(f"cat {path} |")
+    assert sr == 16000 and torch.equal(a, b) and a.shape == (1, 3000)
+    with pytest.raises(ValueError):
+        pl.TargetSelector("nearest", ["a"], {})
