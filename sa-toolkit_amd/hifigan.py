@@ -98,6 +98,8 @@ class CoreHifiGan(CoreHifiGanParams):
             self._ws = {}
         ws = self._ws.get(key)
         if ws is None or ws.numel() * 4 < need or ws.device != device:
+            if len(self._ws) >= 8:
+                self._ws.clear()      # workspaces of streams that no longer exist (keys are raw stream handles)
             ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
             self._ws[key] = ws
         return ws, need

@@ -1,0 +1,51 @@
+"""end-to-end rate of the `anonymize` data plane on one GPU: wav files in, anonymized PCM16 wav files out
+(file reads, host->device, convert with F0 on path, device->host, crop, PCM16 encode, file writes).
+  python tools/bench_pipeline.py [n_utts] [jobs] [batch]"""
+import os
+import sys
+import tempfile
+import time
+import types
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import numpy as np
+import torch
+import satools_amd
+from satools_amd import pipeline as pl, synthetic
+from pipeline_toy import write_wav
+
+n_utts = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+jobs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+TAG = "hifigan_bn_tdnnf_600h_vq_48_v1"
+with tempfile.TemporaryDirectory() as tmp:
+    data = os.path.join(tmp, "data", "bench")
+    os.makedirs(os.path.join(data, "clear"))
+    scp, u2s = [], []
+    base = [synthetic.harm_batch([i], 80000)[0].numpy().astype(np.float64) for i in range(32)]
+    for i in range(n_utts):
+        path = os.path.join(data, "clear", f"utt{i:05d}.wav")
+        write_wav(path, base[i % 32])
+        scp.append(f"utt{i:05d} {path}\n")
+        u2s.append(f"utt{i:05d} src{i % 40}\n")
+    open(os.path.join(data, "wav.scp"), "w").writelines(scp)
+    open(os.path.join(data, "utt2spk"), "w").writelines(u2s)
+    model = satools_amd.load_model("synthetic:" + TAG)
+    model.to("cuda")
+    model.eval()
+    settings = types.SimpleNamespace(model="-", f0_modification="", target_constant_spkid="?", results_dir="wav", batch_size=batch,
+                                     data_loader_nj=8, new_datadir_suffix="_anon", device="cuda")
+    wavscp = pl.read_wav_scp(os.path.join(data, "wav.scp"))
+    warm = dict(list(wavscp.items())[:batch * jobs])
+    pl.process_data(data, "random_per_spk", pl.split_dict(warm, jobs), settings, model=model)       # weights, tables
+    # every process_data call sets up its streams, workspaces and page-locked staging buffers (~0.5 s per job):
+    # a cost of the job, amortised over its thousands of utterances, so use enough of them here
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = pl.process_data(data, "random_per_spk", pl.split_dict(wavscp, jobs), settings, model=model)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{n} utterances x 5 s, batch {batch}, {jobs} jobs on one GPU: {dt:.2f} s wall = {n * 5.0 / dt:.0f} x real-time "
+          f"(files in -> PCM16 files out; {dt / (n / batch) * 1e3:.1f} ms per batch)")
