@@ -70,8 +70,9 @@ int sat_device_info(char* name, int name_len, int* cu_count);
  *   SAT_CONV_F32   v_mfma_f32_32x32x2_f32, exact f32 (bit-for-bit a k-ordered fma chain)
  *   SAT_CONV_F16X3 operands split as hi + lo f16 (22 significand bits), products hi*hi + hi*lo + lo*hi
  *                  on v_mfma_f32_32x32x16_f16 with f32 accumulation (~2^-21 relative per product);
- *                  weights packed as w16[g][cin_pad/16][ksize][co_pad][hi16|lo16] f16; stride 1,
- *                  ksize in {3, 7, 11}; operands must lie inside the f16 range (|x| < 65504). */
+ *                  weights packed as w16[g][cin_pad/16][ksize][hi|lo][channel half][co_pad][8] f16; stride 1;
+ *                  ksize in {1, 2, 3, 7, 11} with f32 input, {1, 3, 7, 11} with split-plane input (x_split);
+ *                  operands must lie inside the f16 range (|x| < 65504). */
 #define SAT_CONV_F32 0
 #define SAT_CONV_F16X3 1
 /*   SAT_CONV_F16F8 hi*hi on the f16 MFMA; the two cross terms hi*lo + lo*hi (2^-11 of the product) on the
