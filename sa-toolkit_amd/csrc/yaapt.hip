@@ -150,30 +150,77 @@ __global__ void __launch_bounds__(128) yaapt_prefilter_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int brev13(int j) { return (int)(__brev((unsigned)j) >> (32 - FFT_LOG)); }
 
-__device__ void fft8192(float* re, float* im, const float2* __restrict__ tw) {
-  const int tid = threadIdx.x;
-#pragma unroll 1
-  for (int s = 1; s <= FFT_LOG; ++s) {
-    const int half = 1 << (s - 1);
-    const int tstep = (FFT_N / 2) >> (s - 1);
-#pragma unroll 4
-    for (int k = 0; k < FFT_N / 2 / 256; ++k) {
-      const int i = tid + 256 * k;
-      const int pos = i & (half - 1);
-      const int a = ((i >> (s - 1)) << s) + pos;
-      const int c = a + half;
-      const float2 w = tw[pos * tstep];
-      const float xr = re[c], xi = im[c];
-      const float tr = xr * w.x - xi * w.y;
-      const float ti = xr * w.y + xi * w.x;
-      const float ur = re[a], ui = im[a];
-      re[a] = ur + tr;
-      im[a] = ui + ti;
-      re[c] = ur - tr;
-      im[c] = ui - ti;
+// One pass = NST consecutive radix-2 stages (s .. s+NST-1) done in registers on groups of 2^NST elements
+// spaced 2^(s-1) apart: the butterflies, their twiddles and their order of operations are exactly those of the
+// stage-by-stage loop, so the result is bit-identical to it — only the LDS round trips and barriers between
+// the stages of a pass are gone (13 -> 4-5 passes).
+template <int NST>
+__device__ __forceinline__ void fft8192_pass(float* re, float* im, const float2* __restrict__ tw, int s) {
+  constexpr int R = 1 << NST;
+  const int h = 1 << (s - 1);
+#pragma unroll 2
+  for (int k = 0; k < FFT_N / R / 256; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    const int pos = i & (h - 1);
+    const int base = ((i >> (s - 1)) << (s - 1 + NST)) + pos;
+    float xr[R], xi[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      xr[j] = re[base + j * h];
+      xi[j] = im[base + j * h];
     }
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int d = 1 << st;                              // partner distance in group slots at stage s + st
+      const int tstep = (FFT_N / 2) >> (s - 1 + st);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if (j & d) continue;                              // j = the "a" element, j + d = the "c" element
+        const int p = pos + (j & (d - 1)) * h;            // index of a inside its half-block of stage s + st
+        const float2 w = tw[p * tstep];
+        const float tr = xr[j + d] * w.x - xi[j + d] * w.y;
+        const float ti = xr[j + d] * w.y + xi[j + d] * w.x;
+        const float ur = xr[j], ui = xi[j];
+        xr[j] = ur + tr;
+        xi[j] = ui + ti;
+        xr[j + d] = ur - tr;
+        xi[j + d] = ui - ti;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      re[base + j * h] = xr[j];
+      im[base + j * h] = xi[j];
+    }
   }
+  __syncthreads();
+}
+
+// stages first .. 13 of the 8192-point radix-2 DIT FFT (input in bit-reversed order)
+__device__ void fft8192_from(float* re, float* im, const float2* __restrict__ tw, int first) {
+  int s = first;
+  const int lead = (FFT_LOG - first + 1) % 3;
+  if (lead == 1) { fft8192_pass<1>(re, im, tw, s); s += 1; }
+  if (lead == 2) { fft8192_pass<2>(re, im, tw, s); s += 2; }
+  for (; s <= FFT_LOG; s += 3) fft8192_pass<3>(re, im, tw, s);
+}
+
+// Zero-padded real input of L <= 8192 >> z samples: in bit-reversed order the samples sit at multiples of 2^z
+// and the first z stages only copy each one over its block of 2^z (x + w*0 and x - w*0).  Fills re/im with that
+// state and returns the first stage left to do.  get(j) = sample j.
+template <typename Get>
+__device__ __forceinline__ int fft8192_load_padded(float* re, float* im, int L, Get get) {
+  const int z = L <= 1024 ? 3 : (L <= 2048 ? 2 : (L <= 4096 ? 1 : 0));
+  const int rep = 1 << z;
+  for (int i = threadIdx.x; i < FFT_N; i += 256) im[i] = 0.f;
+  const int nblk = FFT_N >> z;                             // sample j lands on block brev13(j) >> z
+  for (int j = threadIdx.x; j < nblk; j += 256) {
+    const float v = j < L ? get(j) : 0.f;
+    const int b0 = brev13(j);
+    for (int r = 0; r < rep; ++r) re[b0 + r] = v;
+  }
+  __syncthreads();
+  return z + 1;
 }
 
 // nlfer: frame (560 samples) x hann -> FFT -> sum |X[nl_lo:nl_hi]|
@@ -186,11 +233,8 @@ __global__ void __launch_bounds__(256) yaapt_nlfer_kernel(const float* __restric
   __shared__ float red[8];
   const int f = blockIdx.x, b = blockIdx.y;
   const float* x = filt + ((size_t)b * 2 + 0) * P.Lz + (size_t)f * P.frame_jump;
-  for (int i = threadIdx.x; i < FFT_N; i += 256) { re[i] = 0.f; im[i] = 0.f; }
-  __syncthreads();
-  for (int j = threadIdx.x; j < P.frame_size; j += 256) re[brev13(j)] = x[j] * hann[j];
-  __syncthreads();
-  fft8192(re, im, tw);
+  const int first = fft8192_load_padded(re, im, P.frame_size, [&](int j) { return x[j] * hann[j]; });
+  fft8192_from(re, im, tw, first);
   float part = 0.f;
   for (int k = P.nl_lo + threadIdx.x; k < P.nl_hi; k += 256) part += hypotf(re[k], im[k]);
   const float tot = block_sum256(part, red);
@@ -234,26 +278,16 @@ __global__ void __launch_bounds__(256) yaapt_spec_kernel(const float* __restrict
     return;
   }
   const float* x = filt + ((size_t)b * 2 + 1) * P.Lz + (size_t)f * P.frame_jump;
-  for (int i = tid; i < FFT_N; i += 256) { re[i] = 0.f; im[i] = 0.f; }
   // windowed slice and its mean (nframe_size <= 5*256)
-  float xv[5];
   float part = 0.f;
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int j = tid + 256 * k;
-    float v = 0.f;
-    if (j < P.nframe_size) v = x[j] * kaiser[j];
-    xv[k] = v;
-    part += v;
+    if (j < P.nframe_size) part += x[j] * kaiser[j];
   }
   const float mean = block_sum256(part, red) / (float)P.nframe_size;
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int j = tid + 256 * k;
-    if (j < P.nframe_size) re[brev13(j)] = xv[k] - mean;
-  }
-  __syncthreads();
-  fft8192(re, im, tw);
+  const int first = fft8192_load_padded(re, im, P.nframe_size, [&](int j) { return x[j] * kaiser[j] - mean; });
+  fft8192_from(re, im, tw, first);
   // magnitude[i] = i < half_wl ? 0 : |X[i - half_wl]| ; written over the front of `im` is unsafe
   // (both are inputs), so it goes to a separate region: reuse re[] after reading (two passes).
   const int n_mag = P.min_shc * (P.nharm + 1) + (P.max_shc - P.min_shc) * (P.nharm + 1) + P.wl;  // exclusive bound
