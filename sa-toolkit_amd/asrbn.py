@@ -94,7 +94,9 @@ class _TdnnfBase(nn.Module):
             assert kin == ctx * feat
             # unfold window = ctx consecutive frames of `feat` values: column j*feat + c
             sub = int(lay.subsampling_factor)
-            c.modeB = 1 if (split and sub == 1 and ctx in (1, 2, 3)) else 0
+            # split-f16 kernels are stride 1: a subsampling layer without context (ctx 1, sub > 1) is a 1x1 conv on
+            # every sub-th frame, run on a decimated copy of its input
+            c.modeB = 1 if (split and ctx in (1, 2, 3) and (sub == 1 or ctx == 1)) else 0
             c.wB = (pack if c.modeB else packing.pack_conv_weight)(wB.reshape(bott, ctx, feat).permute(0, 2, 1).contiguous())
             c.bB = lay.tdnn.linearB.inner_nat.bias.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
             wA = lay.tdnn.linearA.weight.detach().to(device=device, dtype=torch.float32)
@@ -121,7 +123,7 @@ class _TdnnfBase(nn.Module):
         f32 tensor stays for the bypass connection.  Returns (y, planes of y or None)."""
         ctx, sub = lay.context_len, int(lay.subsampling_factor)
         B = x.shape[0]
-        planes_in = c.modeB == 1 and xs is not None and x.shape[1] % 16 == 0
+        planes_in = c.modeB == 1 and sub == 1 and xs is not None and x.shape[1] % 16 == 0
         need_z = c.codebook is not None or return_bottleneck
         zs = None
         if planes_in and not need_z and lay.bottleneck_dim % 16 == 0:
@@ -129,6 +131,8 @@ class _TdnnfBase(nn.Module):
             zs = ops.split_like(B, lay.bottleneck_dim, t_q, x.device)
             z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, pad_left=0, pad_right=0, mode=1,
                            x_split=xs, y_split=zs, y_split_slope=1.0, no_y=True)     # z: shape carrier only
+        elif c.modeB == 1 and sub > 1:
+            z = ops.conv1d(x[:, :, ::sub].contiguous(), c.wB, lay.bottleneck_dim, 1, bias=c.bB, pad_left=0, pad_right=0, mode=1)
         else:
             z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, stride=sub, pad_left=0, pad_right=0, mode=c.modeB,
                            x_split=xs if planes_in else None)

@@ -14,16 +14,23 @@ constexpr int VQ_MAX_CODES = 64;
 // The codebook sits transposed in LDS ([d][code]) and is read as a broadcast.
 // Arithmetic follows the reference formula and association exactly:
 //   dist[e] = (sum_d x_d^2 + sum_d e_d^2) - 2 * (x . e)      all f32, first minimum wins.
+// Block = 64 frames x 4 code groups (one wave per group): every (frame, code) distance is still one thread's
+// d-ordered fma chain, the groups only share the work of a frame; the arg-min is combined in code order with
+// a strict '<', i.e. the first minimum wins as in torch.argmin.
 template <int NC>
-__global__ void __launch_bounds__(64) vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
-                                                float* __restrict__ q, int* __restrict__ idx_out,
-                                                float* __restrict__ dist_out, int D, int T, int n_codes) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [D][NC] codebook^T, then [NC] norms
+__global__ void __launch_bounds__(256) vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                 float* __restrict__ q, int* __restrict__ idx_out,
+                                                 float* __restrict__ dist_out, int D, int T, int n_codes) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [D][NC] codebook^T, then [NC] norms, then [4][64] (d, idx)
+  constexpr int G = 4, CPG = NC / G;
   float* et = lds;
   float* ee = lds + (size_t)D * NC;
+  float* bd = ee + NC;               // [G][64] best distance of the group
+  int* bi = (int*)(bd + G * 64);     // [G][64] its code
   const int b = blockIdx.y;
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  for (int i = threadIdx.x; i < D * NC; i += 64) {
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  for (int i = threadIdx.x; i < D * NC; i += 256) {
     const int d = i / NC, e = i - d * NC;
     et[i] = e < n_codes ? cb[(size_t)e * D + d] : 0.f;
   }
@@ -37,35 +44,51 @@ __global__ void __launch_bounds__(64) vq_kernel(const float* __restrict__ z, con
     ee[threadIdx.x] = s;
   }
   __syncthreads();
-  if (t >= T) return;
-  const float* zb = z + (size_t)b * D * T + t;
-  float dot[NC];
+  const bool live = t < T;
+  const float* zb = z + (size_t)b * D * T + (live ? t : 0);
+  float dot[CPG];
 #pragma unroll
-  for (int e = 0; e < NC; ++e) dot[e] = 0.f;
+  for (int e = 0; e < CPG; ++e) dot[e] = 0.f;
   float xx = 0.f;
+  const int e0 = grp * CPG;
   for (int d = 0; d < D; ++d) {
     const float x = zb[(size_t)d * T];
     xx += x * x;
-    const float* er = et + d * NC;
+    const float* er = et + d * NC + e0;
 #pragma unroll
-    for (int e = 0; e < NC; ++e) dot[e] = fmaf(x, er[e], dot[e]);
+    for (int e = 0; e < CPG; ++e) dot[e] = fmaf(x, er[e], dot[e]);
   }
-  int best = 0;
+  int best = -1;
   float bestd = 0.f;
 #pragma unroll
-  for (int e = 0; e < NC; ++e) {
-    if (e < n_codes) {
-      const float dd = (xx + ee[e]) - 2.f * dot[e];
-      if (dist_out) dist_out[((size_t)b * T + t) * n_codes + e] = dd;
-      if (e == 0 || dd < bestd) {
+  for (int e = 0; e < CPG; ++e) {
+    if (e0 + e < n_codes) {
+      const float dd = (xx + ee[e0 + e]) - 2.f * dot[e];
+      if (dist_out && live) dist_out[((size_t)b * T + t) * n_codes + e0 + e] = dd;
+      if (best < 0 || dd < bestd) {
         bestd = dd;
-        best = e;
+        best = e0 + e;
       }
     }
   }
-  idx_out[(size_t)b * T + t] = best;
+  bd[grp * 64 + lane] = bestd;
+  bi[grp * 64 + lane] = best;
+  __syncthreads();
+  best = bi[lane];
+  bestd = bd[lane];
+#pragma unroll
+  for (int g = 1; g < G; ++g) {
+    const int cand = bi[g * 64 + lane];
+    const float cd = bd[g * 64 + lane];
+    if (cand >= 0 && cd < bestd) {
+      bestd = cd;
+      best = cand;
+    }
+  }
+  if (!live) return;
+  if (grp == 0) idx_out[(size_t)b * T + t] = best;
   float* qb = q + (size_t)b * D * T + t;
-  for (int d = 0; d < D; ++d) {
+  for (int d = grp; d < D; d += G) {
     const float x = zb[(size_t)d * T];
     const float e = et[d * NC + best];
     qb[(size_t)d * T] = x + (e - x);  // `inputs + (quantized - inputs)` (chain/nn.py:459)
@@ -181,17 +204,17 @@ extern "C" int sat_vq_argmin_gather_f32(const float* z, const float* codebook, f
               VQ_MAX_CODES);
   dim3 grid(ceil_div(T, 64), B);
   if (n_codes <= 48) {
-    const size_t lds = ((size_t)D * 48 + 48) * sizeof(float);
+    const size_t lds = ((size_t)D * 48 + 48 + 512) * sizeof(float);
     SAT_REQUIRE(lds <= 160 * 1024, "vq: codebook does not fit LDS");
     if (lds > 64 * 1024)
       SAT_HIP(hipFuncSetAttribute((const void*)vq_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(vq_kernel<48>, grid, dim3(64), lds, (hipStream_t)stream, z, codebook, q, idx, dist, D, T, n_codes);
+    hipLaunchKernelGGL(vq_kernel<48>, grid, dim3(256), lds, (hipStream_t)stream, z, codebook, q, idx, dist, D, T, n_codes);
   } else {
-    const size_t lds = ((size_t)D * 64 + 64) * sizeof(float);
+    const size_t lds = ((size_t)D * 64 + 64 + 512) * sizeof(float);
     SAT_REQUIRE(lds <= 160 * 1024, "vq: codebook does not fit LDS");
     if (lds > 64 * 1024)
       SAT_HIP(hipFuncSetAttribute((const void*)vq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(vq_kernel<64>, grid, dim3(64), lds, (hipStream_t)stream, z, codebook, q, idx, dist, D, T, n_codes);
+    hipLaunchKernelGGL(vq_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, z, codebook, q, idx, dist, D, T, n_codes);
   }
   SAT_LAUNCH_CHECK("vq_kernel");
   return SAT_OK;
