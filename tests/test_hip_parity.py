@@ -482,6 +482,31 @@ def test_convert_matches_golden(model, gold):
     assert model.f0 is None                                          # set_f0 is consumed once
 
 
+@pytest.mark.parametrize("shape", [(1, 4800), (3, 16123), (2, 31999), (5, 9600)], ids=lambda s: f"B{s[0]}xn{s[1]}")
+def test_convert_ragged_sizes_match_oracle(model, fbank_tag_state, shape):
+    """sizes off the 5 s / batch-of-32 grid (odd sample counts, sub-second utterances, odd batches): the whole
+    convert() with YAAPT on path against the CPU oracle run on the same input"""
+    from oracle import convert as oconv
+    from oracle import yaapt as oyaapt
+    from satools_amd import synthetic
+    B, n = shape
+    state, _ = fbank_tag_state
+    wav = synthetic.harm_batch(list(range(B)), n)
+    tg = synthetic.targets(model.spk, list(range(B)))
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)          # the reference's own YAAPT setting (frame 0 is thread-count dependent in torch)
+    try:
+        f0 = oyaapt.yaapt(wav, {"frame_length": 35.0, "frame_space": 20.0, "nccf_thresh1": 0.25, "tda_frame_length": 25.0})
+    finally:
+        torch.set_num_threads(nt)
+    ref = oconv.convert_fbank(state["base_model_state_dict"], model.spk, wav, tg if B > 1 else tg[0], f0)
+    y = model.convert(wav.to(DEV), target=tg if B > 1 else tg[0])
+    assert y.shape == ref.shape
+    err = rms(y.cpu().numpy() - ref.numpy())
+    print(f"B={B} n={n}: out {tuple(y.shape)}, RMS error vs oracle {err:.2e}")
+    assert err < 1e-5
+
+
 def test_convert_errors_like_the_reference(model):
     from satools_amd import synthetic
     wav = synthetic.harm_batch([0], 8000).to(DEV)
