@@ -65,6 +65,7 @@ struct ConvArgs {
   const void* res16;     // residual as SAT_SPLIT_F16 planes of lrelu(r, res16_slope) (inverted on the fly), or null
   float res16_inv;       // 1 / slope
   int f8;                // planes kernels: cross terms hi*lo + lo*hi on the block-scaled e4m3 MFMA
+  int poly_planes;       // up > 1, planes only: the LDS-transposed polyphase epilogue
   int y16_f8;            // output planes carry (hi f16 | e4m3(hi) | e4m3(lo * 2^10)) instead of (hi f16 | lo f16)
 #ifdef SAT_STAMPS
   long long* dbg;        // diagnostic build (tools/stamp_conv.hip): per-block, per-chunk phase time stamps
@@ -726,6 +727,58 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) 
 // un-pipelined form spent 1.7-2.7k cycles per chunk waiting on loads and 22-32k cycles in the epilogue
 // against a 4.2k-cycle MFMA phase (k = 11).
 // ------------------------------------------------------------------------------------------------
+// ---- polyphase (transposed-conv) output straight to split planes.  The accumulator rows are (channel, phase)
+// pairs and a lane holds a column q of them, but a plane unit is 8 CHANNELS at one output time t = q*up + phase:
+// the tile goes through LDS once (f32, pitch +1 against bank conflicts between phases) and is read back in
+// plane order — 16-byte stores, consecutive lanes on consecutive times.  Replaces the f32 store of the
+// upsampled tensor and the separate split pass (12 bytes per element of HBM traffic).
+// Needs 32*MT % (8*up) == 0 (a block's rows are whole 8-channel groups).
+template <int MT, int NT>
+__device__ __forceinline__ void polyphase_planes_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NT], float* tile, int b,
+                                                          int co_w, int q_b, int wave, int l31, int lh) {
+  constexpr int CO_B = 32 * MT, T_B = 128 * NT, PITCH = T_B + 1;
+  const int up = p.up;
+  __syncthreads();                                   // every wave is done with the operand tiles
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int grow = co_w + row;
+        const float bias = (p.bias && grow < p.rows_g) ? p.bias[grow / up] : 0.f;
+        tile[row * PITCH + wave * (32 * NT) + n * 32 + l31] = acc[m][n][r] + bias;
+      }
+  __syncthreads();
+  const int T_out = p.T_q * up;
+  uint4* yb = (uint4*)p.y16 + (long long)b * (p.cout_g / 4) * T_out;     // cout_g * T_out * 4 bytes per utterance
+  const int n_tt = T_B * up;                            // output times of the block
+  const int n_cg = CO_B / (8 * up);                     // 8-channel groups of the block
+  for (int it = threadIdx.x; it < n_cg * n_tt; it += 256) {
+    const int cg = it / n_tt, tt = it - cg * n_tt;
+    const int ql = tt / up, ph = tt - ql * up;
+    const int t = q_b * up + tt;
+    const int c0 = co_w / up + cg * 8;                  // first channel of the group
+    if (t >= T_out || c0 >= p.cout_g) continue;
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x0 = tile[((cg * 8 + 2 * j) * up + ph) * PITCH + ql];
+      float x1 = tile[((cg * 8 + 2 * j + 1) * up + ph) * PITCH + ql];
+      x0 = x0 > 0.f ? x0 : x0 * p.y16_slope;
+      x1 = x1 > 0.f ? x1 : x1 * p.y16_slope;
+      const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+      const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+      hi[j] = __builtin_bit_cast(unsigned, h);
+      lo[j] = __builtin_bit_cast(unsigned, l);
+    }
+    const long long u = ((long long)((c0 >> 4) * 4 + ((c0 >> 3) & 1))) * T_out + t;
+    yb[u] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    yb[u + 2LL * T_out] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 // S: 16-channel sub-chunks per pipeline stage.  With few taps the matrix work of a 16-channel chunk (1152
 // cycles at 3 taps) is dwarfed by the ~2800 cycles of barriers, LDS stores and load issue around it: S = 2
 // halves the number of stages.
@@ -913,6 +966,10 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvA
   __builtin_amdgcn_sched_barrier(0);
   mfma_phase();
   SAT_STAMP(4);
+  if (p.poly_planes) {                                  // wave-uniform: polyphase upsampler writing planes only
+    polyphase_planes_epilogue<MT, NT>(p, acc, (float*)lds4, b, co_w, q_b, wave, l31, lh);
+    return;
+  }
   conv_epilogue<MT, NT, true>(p, acc, b, 0, co_w, q_w, l31, lh, 32, 0x7fffffff, rpre);
   SAT_STAMP(5);
   SAT_STAMP_BLOCK(14, __builtin_amdgcn_s_memrealtime());
@@ -956,6 +1013,7 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
       set_error("conv1d(split planes): %d taps not instantiated", KS);
       return SAT_ERR_INVALID;
     }
+    if (p.poly_planes) lds_bytes = std::max(lds_bytes, (size_t)CO_B * (T_B + 1) * 4);   // the f32 tile of the transposed epilogue
   }
   if (lds_bytes > 64 * 1024)
     SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1774,7 +1832,16 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
       a.res16 = d->res_split;
       a.res16_inv = 1.0f / d->res_split_slope;
     }
-    if (a.y16 || a.no_y) {
+    if (d->up > 1 && (a.y16 || a.no_y)) {
+      // polyphase upsampler straight to planes (LDS-transposed epilogue)
+      const int co_b = a.rows_g > 32 ? 64 : 32;
+      SAT_REQUIRE(a.x16 && a.y16 && a.no_y && !a.f8 && !a.y16_f8 && d->groups == 1 && co_b % (8 * d->up) == 0 && a.cout_g % 16 == 0 &&
+                      !d->res && !d->res_split && !d->accum && !d->relu && !d->gelu && !d->ch_scale &&
+                      (long long)a.rows_g * a.T_q * 4 < (1LL << 31),
+                  "conv1d(f16x3): up > 1 with y_split needs split-plane input, no_y, up in {2, 4}, C_out %% 16 == 0, a plain epilogue");
+      a.poly_planes = 1;
+      a.y = (float*)a.y16;
+    } else if (a.y16 || a.no_y) {
       SAT_REQUIRE(a.fast_epi && d->groups == 1 && a.rows_g % 16 == 0 && (long long)a.rows_g * a.T_q * 4 < (1LL << 31),
                   "conv1d(f16x3): y_split / no_y need up 1, groups 1, C_out %% 16 == 0 and a slab below 2 GiB");
       if (a.no_y) a.y = (float*)a.y16, a.accum = 0;   // descriptor base only; nothing is loaded or stored through it

@@ -357,11 +357,23 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         d.bias = h->convs[h->id_up(i)].bias;
         d.mode = cmode;
         d.x_split = XS;
-        int s = sat_conv1d_f32(&d, nullptr, h->convs[h->id_up(i)].w, Hf, stream);
-        if (s != SAT_OK) return s;
-        // the polyphase epilogue scatters rows over time phases: split in a streaming pass
-        s = sat_act_split_f32(Hf, Hs, B, Cn, Tn, 0.1f, cmode == SAT_CONV_F16F8 ? SAT_SPLIT_F8 : SAT_SPLIT_F16, stream);
-        if (s != SAT_OK) return s;
+        // rates 2 and 4: the transposed conv writes the split planes itself (LDS-transposed epilogue); other
+        // rates (5: a block's 64 rows are not whole channel groups) store f32 and split in a streaming pass
+        const int co_b = Cn * u > 32 ? 64 : 32;
+        const bool direct = cmode == SAT_CONV_F16X3 && h->planes_residual && co_b % (8 * u) == 0;
+        int s;
+        if (direct) {
+          d.y_split = Hs;
+          d.y_split_slope = 0.1f;
+          d.no_y = 1;
+          s = sat_conv1d_f32(&d, nullptr, h->convs[h->id_up(i)].w, nullptr, stream);
+          if (s != SAT_OK) return s;
+        } else {
+          s = sat_conv1d_f32(&d, nullptr, h->convs[h->id_up(i)].w, Hf, stream);
+          if (s != SAT_OK) return s;
+          s = sat_act_split_f32(Hf, Hs, B, Cn, Tn, 0.1f, cmode == SAT_CONV_F16F8 ? SAT_SPLIT_F8 : SAT_SPLIT_F16, stream);
+          if (s != SAT_OK) return s;
+        }
       }
       if (side && i < h->branch_streams) {
         SAT_HIP(hipEventRecord(side->fork, (hipStream_t)stream));

@@ -156,6 +156,28 @@ def test_convtranspose_as_polyphase_conv(cfg):
     assert (y.cpu() - ref).abs().max() < 3e-5
 
 
+@pytest.mark.parametrize("cfg", [(128, 64, 8, 4, 50), (256, 128, 8, 4, 333), (64, 32, 4, 2, 700), (32, 16, 4, 2, 1301)])
+def test_polyphase_conv_writes_split_planes(cfg):
+    """transposed conv (rates 2 and 4) from split planes straight to split planes through the LDS-transposed
+    epilogue: bit-identical to the f32 output of the same kernel put through the split pass"""
+    ops, packing = _ops()
+    cin, cout, k, u, T = cfg
+    x = _rand(2, cin, T, seed=1).to(DEV)
+    w = _rand(cin, cout, k, seed=2, scale=1.0 / np.sqrt(cin * k / u)).to(DEV)
+    b = _rand(cout, seed=3).to(DEV)
+    wc, kp, pl = packing.convtranspose_as_phase_conv(w, u, (k - u) // 2)
+    wp = packing.pack_conv_weight_f16x3(wc, up=u)
+    xs = ops.act_split(x, 0.1)
+    y = ops.conv1d(x, wp, cout, kp, bias=b, pad_left=pl, up=u, mode=1, x_split=xs)
+    ref = F.conv_transpose1d(F.leaky_relu(x.cpu(), 0.1), w.cpu(), b.cpu(), stride=u, padding=(k - u) // 2)
+    assert (y.cpu() - ref).abs().max() < 3e-5
+    ys = torch.zeros(2, cout // 16, 2, 2, T * u, 8, dtype=torch.float16, device=DEV)
+    guard = torch.full_like(y, 7.0)
+    ops.conv1d(x, wp, cout, kp, bias=b, pad_left=pl, up=u, mode=1, x_split=xs, y_split=ys, y_split_slope=0.1, no_y=True, out=guard)
+    assert (guard == 7.0).all()
+    assert torch.equal(ys, ops.act_split(y, 0.1))
+
+
 def test_convpost_matches_oracle():
     ops, _ = _ops()
     x, w, b = _rand(2, 16, 2500, seed=1), _rand(1, 16, 7, seed=2, scale=0.1), _rand(1, seed=3, scale=0.1)
