@@ -230,24 +230,34 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         x = ops.layernorm_ch(x, W["ln"]["g"], W["ln"]["beta"])
         G = B * heads
         tp = ((T + 63) // 64) * 64   # row pitch of the per-head tensors = the packed-weight co_pad for T rows
+        planes = mm == _lib.CONV_F16X3        # Linear layers read their input as split planes (16-byte staging,
+        #                                        two 16-channel sub-chunks per pipeline stage): 182 -> ~60 us per layer
+        sp = (lambda t: ops.act_split(t, 1.0)) if planes else (lambda t: None)
         for L in W["layers"]:
             h = ops.layernorm_ch(x, *L["ln1"])
+            hs = sp(h)
             q = torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device)
             k = torch.empty_like(q)
             v = torch.empty_like(q)
-            ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], out=q[:, :, :T], mode=mm)
-            ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], out=k[:, :, :T], mode=mm)
-            ops.conv1d(h, L["v_w"], 1024, 1, bias=L["v_b"], out=v[:, :, :T], mode=mm)
+            ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], out=q[:, :, :T], mode=mm, x_split=hs)
+            ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], out=k[:, :, :T], mode=mm, x_split=hs)
+            ops.conv1d(h, L["v_w"], 1024, 1, bias=L["v_b"], out=v[:, :, :T], mode=mm, x_split=hs)
             # S^T[j][q] = sum_c K[c][j] Q[c][q]  per (utterance, head): K as packed weights, Q as input
             st = torch.empty(G * T, tp, dtype=torch.float32, device=x.device)
             ops.attention_scores(q, k, st, B, heads, hd, T)
             ops.softmax_cols(st, G, T, scale=hd ** -0.5)
             vt = ops.transpose_heads(v, B, heads, hd, T)                           # [G][jpad][64]
             o = ops.attention_apply(st, vt, B, heads, hd, T)                        # [B, 1024, T]
-            x = ops.conv1d(o, L["o_w"], 1024, 1, bias=L["o_b"], res=x, mode=mm)
+            x = ops.conv1d(o, L["o_w"], 1024, 1, bias=L["o_b"], res=x, mode=mm, x_split=sp(o))
             h = ops.layernorm_ch(x, *L["ln2"])
-            h = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True, mode=mm)
-            x = ops.conv1d(h, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm)
+            if planes:
+                fs = ops.split_like(B, 4096, T, x.device)
+                f = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True, mode=mm, x_split=sp(h), y_split=fs,
+                               y_split_slope=1.0, no_y=True)                        # f: shape carrier only
+                x = ops.conv1d(f, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm, x_split=fs)
+            else:
+                h = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True, mode=mm)
+                x = ops.conv1d(h, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm)
         return x
 
     def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
