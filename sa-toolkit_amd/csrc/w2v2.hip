@@ -41,19 +41,31 @@ __global__ void __launch_bounds__(256) w2v2_conv0_kernel(const float* __restrict
 // channels (frames of a channel are contiguous, so every access is a coalesced 256-B row piece) and the
 // partial sums meet in LDS.  Two-pass mean / variance like torch's CPU kernel.
 constexpr int LN_SLICES = 16;
-__global__ void __launch_bounds__(64 * LN_SLICES) layernorm_ch_kernel(
+constexpr int LN_FR = 16;          // frames per block
+constexpr int LN_MAXPT = 64;       // channels per thread kept in registers: C <= 16 * 64
+// Block = 16 frames x 16 channel slices (256 threads, 512 blocks at B = 32, T = 249): a thread reads its 64
+// channels of one frame ONCE into registers and both statistics passes and the output pass run from there.
+// Slice c = sl, sl + 16, ... and the slice-ordered total are the summation order of the 64-frame version.
+__global__ void __launch_bounds__(LN_FR * LN_SLICES) layernorm_ch_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
     int C, int T, long long x_bs, long long x_cs, long long y_bs, long long y_cs, int gelu, int split) {
-  __shared__ float part[LN_SLICES][64];
-  __shared__ float s_mean[64], s_rstd[64];
+  __shared__ float part[LN_SLICES][LN_FR];
+  __shared__ float s_mean[LN_FR], s_rstd[LN_FR];
   const int b = blockIdx.y;
-  const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int t = blockIdx.x * 64 + tx;
+  const int tx = threadIdx.x & (LN_FR - 1), sl = threadIdx.x / LN_FR;
+  const int t = blockIdx.x * LN_FR + tx;
   const bool ok = t < T;
   const float* xb = x + (size_t)b * x_bs + (ok ? t : 0);
+  float v[LN_MAXPT];
   float s = 0.f;
-  if (ok)
-    for (int c = sl; c < C; c += LN_SLICES) s += xb[(size_t)c * x_cs];
+#pragma unroll
+  for (int k = 0; k < LN_MAXPT; ++k) {
+    const int c = sl + k * LN_SLICES;
+    v[k] = (ok && c < C) ? xb[(size_t)c * x_cs] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < LN_MAXPT; ++k)
+    if (sl + k * LN_SLICES < C) s += v[k];
   part[sl][tx] = s;
   __syncthreads();
   if (sl == 0) {
@@ -65,11 +77,13 @@ __global__ void __launch_bounds__(64 * LN_SLICES) layernorm_ch_kernel(
   __syncthreads();
   const float mean = s_mean[tx];
   float q = 0.f;
-  if (ok)
-    for (int c = sl; c < C; c += LN_SLICES) {
-      const float d = xb[(size_t)c * x_cs] - mean;
+#pragma unroll
+  for (int k = 0; k < LN_MAXPT; ++k)
+    if (sl + k * LN_SLICES < C) {
+      const float d = v[k] - mean;
       q = fmaf(d, d, q);
     }
+  __syncthreads();
   part[sl][tx] = q;
   __syncthreads();
   if (sl == 0) {
@@ -85,11 +99,15 @@ __global__ void __launch_bounds__(64 * LN_SLICES) layernorm_ch_kernel(
   const int ph = split ? (t & 1) : 0;
   const int u = split ? (t >> 1) : t;
   const bool tail = split && (T & 1) && t == T - 1;   // odd length: the odd phase's last slot is zero padding
-  for (int c = sl; c < C; c += LN_SLICES) {
-    float v = (xb[(size_t)c * x_cs] - mean) * rstd * gamma[c] + beta[c];
-    if (gelu) v = gelu_erf(v);
-    yb[(size_t)(ph * C + c) * y_cs + u] = v;
-    if (tail) yb[(size_t)(C + c) * y_cs + u] = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXPT; ++k) {
+    const int c = sl + k * LN_SLICES;
+    if (c < C) {
+      float o = (v[k] - mean) * rstd * gamma[c] + beta[c];
+      if (gelu) o = gelu_erf(o);
+      yb[(size_t)(ph * C + c) * y_cs + u] = o;
+      if (tail) yb[(size_t)(C + c) * y_cs + u] = 0.f;
+    }
   }
 }
 
@@ -179,8 +197,9 @@ extern "C" int sat_layernorm_channels_f32(const float* x, const float* gamma, co
                                           int64_t y_cstride, int gelu, int split_phases, void* stream) {
   SAT_REQUIRE(x && gamma && beta && y, "layernorm_channels: null pointer");
   SAT_REQUIRE(B > 0 && C > 0 && T > 0, "layernorm_channels: empty shape");
-  dim3 grid(ceil_div(T, 64), B);
-  hipLaunchKernelGGL(layernorm_ch_kernel, grid, dim3(64 * LN_SLICES), 0, (hipStream_t)stream, x, gamma, beta, y, C, T,
+  SAT_REQUIRE(C <= LN_SLICES * LN_MAXPT, "layernorm_channels: at most %d channels", LN_SLICES * LN_MAXPT);
+  dim3 grid(ceil_div(T, LN_FR), B);
+  hipLaunchKernelGGL(layernorm_ch_kernel, grid, dim3(LN_FR * LN_SLICES), 0, (hipStream_t)stream, x, gamma, beta, y, C, T,
                      (long long)x_bstride, (long long)x_cstride, (long long)y_bstride, (long long)y_cstride, gelu,
                      split_phases);
   SAT_LAUNCH_CHECK("layernorm_ch_kernel");
