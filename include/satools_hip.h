@@ -258,6 +258,14 @@ size_t sat_yaapt_workspace_bytes(const sat_yaapt_plan* plan, int B);
 int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float* f0, int32_t* status,
                   const float* hann, const float* kaiser, const float* twiddle, void* workspace,
                   size_t workspace_bytes, int B, void* stream);
+/* Ragged batch: zero-padded utterances [B][plan->n] tracked at their OWN lengths in one launch sequence — what
+ * the reference's data loader does one utterance at a time (bin/pipeline.py:35-41: get_f0 per utterance, tracks
+ * zero-padded by the collate).  `plan` is the plan of the LONGEST utterance (buffer strides, launch grids);
+ * utt_dims [B][4] (device int32) = {samples, padded length L, frames, tda frames} of every utterance, computed
+ * by the host with the same derivations as the plan.  f0 [B][plan->nframes], zero past an utterance's frames. */
+int sat_yaapt_ragged_f32(const sat_yaapt_plan* plan, const float* wav, const int32_t* utt_dims, float* f0,
+                         int32_t* status, const float* hann, const float* kaiser, const float* twiddle,
+                         void* workspace, size_t workspace_bytes, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * wav2vec2 support (torchaudio.models.wav2vec2 as configured by tdnnf_wav2vec2_vq.py:39-56; third

@@ -91,6 +91,39 @@ def build(args):
             out = f0_hip.yaapt(self._to_device(wav), self.f0_yaapt_opts)
             return out.to(wav.device)
 
+        def get_f0_ragged(self, wav, lengths):
+            """F0 of zero-padded utterances at their own lengths: [B, n_max] + lengths -> [B, T_max] zero-padded,
+            on the device — the reference's data loader semantics (bin/pipeline.py:35-41, :52-62: `get_f0` per
+            utterance, tracks zero-padded by the collate) in one launch sequence (sat_yaapt_ragged_f32)."""
+            from . import f0 as f0_hip
+            xd = self._to_device(wav.detach())
+            return f0_hip.yaapt_ragged(xd, lengths, self.f0_yaapt_opts)
+
+        def convert_padded(self, x, lengths, target):
+            """convert() of a zero-padded batch whose F0 tracks are taken per utterance at its own length — the
+            result of the reference's batch job (`set_f0` of the data loader's zero-padded per-utterance tracks,
+            then `convert`; bin/pipeline.py:35-62, :107-149) — with the ragged YAAPT launch on the F0 side stream
+            next to the bottleneck extractor and its status checked after the generator is enqueued."""
+            from . import f0 as f0_hip
+            xd = self._to_device(x.detach())
+            cur = torch.cuda.current_stream(xd.device)
+            if self._f0_stream is None:
+                self._f0_stream = {}
+            side = self._f0_stream.get(cur.cuda_stream)
+            if side is None:
+                side = self._f0_stream[cur.cuda_stream] = torch.cuda.Stream(device=xd.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                f0, st = f0_hip.yaapt_ragged(xd, lengths, self.f0_yaapt_opts, defer_status=True)
+                f0 = f0.unsqueeze(0)
+            xd.record_stream(side)
+            bn = self.get_bn(x)
+            cur.wait_stream(side)
+            f0.record_stream(cur)
+            y = self._forward(f0, bn, self.get_spk_id(x, target)).squeeze(0)
+            st.check()
+            return y
+
         def get_spk_id(self, wavinfo, target=None):
             if not target:
                 target = [self.utt2spk[wavinfo.name]]

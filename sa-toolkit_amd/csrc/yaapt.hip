@@ -62,6 +62,10 @@ __device__ __forceinline__ float block_max256(float v, float* red) {
 __device__ __forceinline__ float tmax(float a, float b) { return (a != a || b != b) ? NAN : fmaxf(a, b); }
 __device__ __forceinline__ float tmin(float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); }
 
+// ragged batches: U[b] = {samples, padded length L, frames, tda frames} of utterance b (host-computed with the
+// plan's formulas); null = every utterance has the plan's length.  Row strides stay the plan's (the longest).
+__device__ __forceinline__ int ulen(const int* __restrict__ U, int b, int k, int dflt) { return U ? U[b * 4 + k] : dflt; }
+
 // ------------------------------------------------------------------------------------------------
 // prefilter: zero-pad, (square), low-pass biquad -> clamp -> high-pass biquad -> clamp.
 // The FIR halves are lane-parallel on 64-sample chunks; the two IIR recursions are inherently
@@ -93,7 +97,7 @@ __device__ __forceinline__ float iir_chunk(const float* __restrict__ f, float c1
 }
 
 __global__ void __launch_bounds__(128) yaapt_prefilter_kernel(const float* __restrict__ wav, float* __restrict__ filt,
-                                                              const Plan P) {
+                                                              const int* __restrict__ U, const Plan P) {
   __shared__ __attribute__((aligned(16))) float s_f[2][64];   // per-wave FIR outputs feeding the recursion
   __shared__ __attribute__((aligned(16))) float s_u[2][64];   // clamped low-pass chunks handed to wave 1
   const int lane = threadIdx.x & 63;
@@ -105,11 +109,12 @@ __global__ void __launch_bounds__(128) yaapt_prefilter_kernel(const float* __res
   const float b0 = k[0], b1 = k[1], b2 = k[2], a0 = k[3], c1 = k[4], c2 = k[5];
   float h1 = 0.f, h2 = 0.f;   // last two inputs of the previous chunk
   float y1 = 0.f, y2 = 0.f;
-  const int nchunks = (P.L + 63) / 64;
+  const int n_b = ulen(U, b, 0, P.n), L_b = ulen(U, b, 1, P.L);
+  const int nchunks = (L_b + 63) / 64;
   auto load_x = [&](int c) {   // padded (and squared) input sample of chunk c for this lane
     float x = 0.f;
     const int src = c * 64 + lane - P.pad;
-    if (c < nchunks && src >= 0 && src < P.n) x = w[src];
+    if (c < nchunks && src >= 0 && src < n_b) x = w[src];
     return sig ? x * x : x;
   };
   float x_next = wave == 0 ? load_x(0) : 0.f;
@@ -137,11 +142,11 @@ __global__ void __launch_bounds__(128) yaapt_prefilter_kernel(const float* __res
       const float v = iir_chunk(s_f[wave], c1, c2, y1, y2, lane);
       const float u = fminf(fmaxf(v, -1.f), 1.f);
       if (wave == 0) s_u[c & 1][lane] = u;
-      else if (t < P.L) out[t] = u;
+      else if (t < L_b) out[t] = u;
     }
     __syncthreads();
   }
-  for (int t = P.L + (int)threadIdx.x; t < P.Lz; t += 128) out[t] = 0.f;  // zero extension read by spec_track
+  for (int t = L_b + (int)threadIdx.x; t < P.Lz; t += 128) out[t] = 0.f;  // zero extension read by spec_track
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -226,12 +231,13 @@ __device__ __forceinline__ int fft8192_load_padded(float* re, float* im, int L, 
 // nlfer: frame (560 samples) x hann -> FFT -> sum |X[nl_lo:nl_hi]|
 __global__ void __launch_bounds__(256) yaapt_nlfer_kernel(const float* __restrict__ filt, const float* __restrict__ hann,
                                                          const float2* __restrict__ tw, float* __restrict__ e_raw,
-                                                         const Plan P) {
+                                                         const int* __restrict__ U, const Plan P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* re = lds;
   float* im = lds + FFT_N;
   __shared__ float red[8];
   const int f = blockIdx.x, b = blockIdx.y;
+  if (f >= ulen(U, b, 2, P.nframes)) return;
   const float* x = filt + ((size_t)b * 2 + 0) * P.Lz + (size_t)f * P.frame_jump;
   const int first = fft8192_load_padded(re, im, P.frame_size, [&](int j) { return x[j] * hann[j]; });
   fft8192_from(re, im, tw, first);
@@ -243,17 +249,18 @@ __global__ void __launch_bounds__(256) yaapt_nlfer_kernel(const float* __restric
 
 // energy / mean(energy), vuv = energy > nlfer_thresh1   (one block per utterance)
 __global__ void __launch_bounds__(256) yaapt_energy_norm_kernel(const float* __restrict__ e_raw, float* __restrict__ energy,
-                                                               int* __restrict__ vuv, const Plan P) {
+                                                               int* __restrict__ vuv, const int* __restrict__ U, const Plan P) {
   __shared__ float red[8];
   const int b = blockIdx.x;
+  const int nf = ulen(U, b, 2, P.nframes);
   const float* e = e_raw + (size_t)b * P.nframes;
   float part = 0.f;
-  for (int f = threadIdx.x; f < P.nframes; f += 256) part += e[f];
-  const float mean = block_sum256(part, red) / (float)P.nframes;
+  for (int f = threadIdx.x; f < nf; f += 256) part += e[f];
+  const float mean = block_sum256(part, red) / (float)nf;
   for (int f = threadIdx.x; f < P.nframes; f += 256) {
-    const float v = e[f] / mean;
+    const float v = f < nf ? e[f] / mean : 0.f;
     energy[(size_t)b * P.nframes + f] = v;
-    vuv[(size_t)b * P.nframes + f] = v > P.nlfer_thresh1 ? 1 : 0;
+    vuv[(size_t)b * P.nframes + f] = (f < nf && v > P.nlfer_thresh1) ? 1 : 0;
   }
 }
 
@@ -261,7 +268,7 @@ __global__ void __launch_bounds__(256) yaapt_energy_norm_kernel(const float* __r
 // cand layout: [b][8][nframes] = pitch[0..3], merit[0..3]
 __global__ void __launch_bounds__(256) yaapt_spec_kernel(const float* __restrict__ filt, const float* __restrict__ kaiser,
                                                         const float2* __restrict__ tw, const int* __restrict__ vuv,
-                                                        float* __restrict__ cand, const Plan P) {
+                                                        float* __restrict__ cand, const int* __restrict__ U, const Plan P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* re = lds;
   float* im = lds + FFT_N;
@@ -270,7 +277,8 @@ __global__ void __launch_bounds__(256) yaapt_spec_kernel(const float* __restrict
   __shared__ unsigned char s_flag[256];
   const int tid = threadIdx.x;
   const int f = blockIdx.x, b = blockIdx.y;
-  const int nf = P.nframes;
+  const int nf = P.nframes;                       // row stride
+  if (f >= ulen(U, b, 2, nf)) return;
   float* cp = cand + (size_t)b * 8 * nf;
   float* cm = cp + 4 * (size_t)nf;
   if (!vuv[(size_t)b * nf + f]) {
@@ -489,10 +497,11 @@ __device__ int compact_frames(int nf, Pred flag, short* idx) {
 // LDS (floats): vcp[4*nf] vcm[4*nf] a[nf] b[nf] spec[nf]; shorts: vidx[nf], index[nf]; bytes pred[4*nf] path[nf]
 __global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __restrict__ cand, float* __restrict__ spec_out,
                                                             float* __restrict__ scal, int* __restrict__ status,
-                                                            const Plan P) {
+                                                            const int* __restrict__ U, const Plan P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int nf = P.nframes;
   const int b = blockIdx.x;
+  const int nfs = P.nframes;                      // row stride of the per-frame arrays in global memory
+  const int nf = ulen(U, b, 2, nfs);              // frames of this utterance (also the LDS row pitch)
   const int lane = threadIdx.x;
   float* vcp = lds;
   float* vcm = vcp + 4 * (size_t)nf;
@@ -503,14 +512,14 @@ __global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __rest
   short* index = vidx + nf;
   unsigned char* pred = (unsigned char*)(index + nf);
   unsigned char* path = pred + 4 * (size_t)nf;
-  const float* cp = cand + (size_t)b * 8 * nf;
-  const float* cm = cp + 4 * (size_t)nf;
+  const float* cp = cand + (size_t)b * 8 * nfs;
+  const float* cm = cp + 4 * (size_t)nfs;
   for (int f = lane; f < nf; f += 64) spec[f] = cp[f];
   const int nv = compact_frames(nf, [&](int f) { return cp[f] > 0.f; }, vidx);
   __syncthreads();
   for (int i = lane; i < nv; i += 64) {
     const int f = vidx[i];
-    for (int c = 0; c < 4; ++c) { vcp[c * nf + i] = cp[(size_t)c * nf + f]; vcm[c * nf + i] = cm[(size_t)c * nf + f]; }
+    for (int c = 0; c < 4; ++c) { vcp[c * nf + i] = cp[(size_t)c * nfs + f]; vcm[c * nf + i] = cm[(size_t)c * nfs + f]; }
   }
   __syncthreads();
   float pitch_avg, pitch_std;
@@ -594,7 +603,7 @@ __global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __rest
   __syncthreads();
   if (lane == 0 && nf >= 4) { ta[0] = ta[2]; ta[1] = ta[3]; }
   __syncthreads();
-  float* out = spec_out + (size_t)b * nf;
+  float* out = spec_out + (size_t)b * nfs;
   for (int f = lane; f < nf; f += 64) out[f] = ta[f];
   if (lane == 0) scal[b * 4 + 0] = pitch_std;
 }
@@ -605,14 +614,14 @@ __global__ void __launch_bounds__(64) yaapt_spec_post_kernel(const float* __rest
 // frame (LDS), then wave 0 walks the frames with only the `ov`-sample head on the critical path
 // (next frame's head prefetched).
 __global__ void __launch_bounds__(256) yaapt_frame_means_kernel(const float* __restrict__ filt, float* __restrict__ fmean,
-                                                               const Plan P) {
+                                                               const int* __restrict__ U, const Plan P) {
   __shared__ float s_tail[2048];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x, sig = blockIdx.y;
   const float* x = filt + ((size_t)b * 2 + sig) * P.Lz;
   float* m = fmean + ((size_t)b * 2 + sig) * P.nframes;
   const int ov = P.tda_len - P.frame_jump;
-  const int T = P.tda_nframes;
+  const int T = ulen(U, b, 3, P.tda_nframes);
   for (int k = wave; k < T; k += 4) {
     float part = 0.f;
     for (int j = ov + lane; j < P.tda_len; j += 64) part += x[(size_t)k * P.frame_jump + j];
@@ -643,14 +652,15 @@ __global__ void __launch_bounds__(256) yaapt_frame_means_kernel(const float* __r
 __global__ void __launch_bounds__(256) yaapt_nccf_kernel(const float* __restrict__ filt, const float* __restrict__ fmean,
                                                         const float* __restrict__ spec, const float* __restrict__ scal,
                                                         float* __restrict__ tp, float* __restrict__ tm,
-                                                        int* __restrict__ status, const Plan P) {
+                                                        int* __restrict__ status, const int* __restrict__ U, const Plan P) {
   __shared__ float d[1024];
   __shared__ float phi[1024];
   __shared__ float red[8];
   __shared__ int s_first;
   const int tid = threadIdx.x;
   const int k = blockIdx.x, sig = blockIdx.y, b = blockIdx.z;
-  const int nf = P.nframes;
+  const int nf = P.nframes;                       // row stride
+  if (k >= ulen(U, b, 2, nf)) return;
   const size_t oidx = ((size_t)b * 2 + sig) * nf + k;
   const float sp = spec[(size_t)b * nf + k];
   const float pstd = scal[b * 4 + 0];
@@ -746,28 +756,29 @@ __global__ void __launch_bounds__(256) yaapt_nccf_kernel(const float* __restrict
 __global__ void __launch_bounds__(64) yaapt_refine_dp_kernel(const float* __restrict__ tp, const float* __restrict__ tm,
                                                             const float* __restrict__ spec, const float* __restrict__ energy,
                                                             const int* __restrict__ vuv, float* __restrict__ f0,
-                                                            const Plan P) {
+                                                            const int* __restrict__ U, const Plan P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
-  const int nf = P.nframes;
   const int b = blockIdx.x;
+  const int nfs = P.nframes;                      // row stride in global memory
+  const int nf = ulen(U, b, 2, nfs);              // frames of this utterance (also the LDS row pitch)
   float* rp = lds;
   float* rm = rp + NC * (size_t)nf;
   float* ta = rm + NC * (size_t)nf;
   float* en = ta + nf;
   unsigned char* pred = (unsigned char*)(en + nf);
   unsigned char* path = pred + NC * (size_t)nf;
-  const float* tp1 = tp + ((size_t)b * 2 + 0) * nf;
-  const float* tp2 = tp + ((size_t)b * 2 + 1) * nf;
-  const float* tm1 = tm + ((size_t)b * 2 + 0) * nf;
-  const float* tm2 = tm + ((size_t)b * 2 + 1) * nf;
-  const float* sp = spec + (size_t)b * nf;
-  const int* vv = vuv + (size_t)b * nf;
-  const int nt = P.tda_nframes;
+  const float* tp1 = tp + ((size_t)b * 2 + 0) * nfs;
+  const float* tp2 = tp + ((size_t)b * 2 + 1) * nfs;
+  const float* tm1 = tm + ((size_t)b * 2 + 0) * nfs;
+  const float* tm2 = tm + ((size_t)b * 2 + 1) * nfs;
+  const float* sp = spec + (size_t)b * nfs;
+  const int* vv = vuv + (size_t)b * nfs;
+  const int nt = ulen(U, b, 3, P.tda_nframes);
   // concatenate the two tracks (rows 0 and 3 carry the single NCCF candidate), order by merit
   // descending with a stable sort (torch CPU argsort keeps equal keys in index order)
   for (int k = lane; k < nf; k += 64) {
-    en[k] = energy[(size_t)b * nf + k];
+    en[k] = energy[(size_t)b * nfs + k];
     float p[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, m[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (k < nt) { p[0] = tp1[k]; m[0] = tm1[k]; p[3] = tp2[k]; m[3] = tm2[k]; }
     int ord[NC];
@@ -847,8 +858,9 @@ __global__ void __launch_bounds__(64) yaapt_refine_dp_kernel(const float* __rest
     return v / w4;
   };
   path1_wave<NC>(rm, nf, nf, tr, pred, path);
-  float* out = f0 + (size_t)b * nf;
+  float* out = f0 + (size_t)b * nfs;
   for (int k = lane; k < nf; k += 64) out[k] = rp[path[k] * nf + k];
+  for (int k = nf + lane; k < nfs; k += 64) out[k] = 0.f;     // shorter utterance of a ragged batch: zero-padded track
 }
 
 }  // namespace sat
@@ -866,9 +878,9 @@ extern "C" size_t sat_yaapt_workspace_bytes(const sat_yaapt_plan* plan, int B) {
   return align_up(yaapt_ws_floats(*plan, B) * sizeof(float), 256);
 }
 
-extern "C" int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float* f0, int32_t* status,
-                             const float* hann, const float* kaiser, const float* twiddle, void* workspace,
-                             size_t workspace_bytes, int B, void* stream) {
+static int yaapt_run(const sat_yaapt_plan* plan, const float* wav, const int32_t* U, float* f0, int32_t* status,
+                     const float* hann, const float* kaiser, const float* twiddle, void* workspace,
+                     size_t workspace_bytes, int B, void* stream) {
   SAT_REQUIRE(plan && wav && f0 && status && hann && kaiser && twiddle && workspace, "yaapt: null pointer");
   const Plan& P = *plan;
   SAT_REQUIRE(B > 0 && P.n > 0, "yaapt: empty batch");
@@ -905,7 +917,7 @@ extern "C" int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float
   const float2* tw = (const float2*)twiddle;
   SAT_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
 
-  hipLaunchKernelGGL(yaapt_prefilter_kernel, dim3(B, 2), dim3(128), 0, s, wav, filt, P);
+  hipLaunchKernelGGL(yaapt_prefilter_kernel, dim3(B, 2), dim3(128), 0, s, wav, filt, U, P);
   SAT_LAUNCH_CHECK("yaapt_prefilter_kernel");
   const size_t fft_lds = 2 * FFT_N * sizeof(float);
   static bool attr_set = false;
@@ -916,21 +928,34 @@ extern "C" int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float
     SAT_HIP(hipFuncSetAttribute((const void*)yaapt_refine_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(yaapt_nlfer_kernel, dim3(P.nframes, B), dim3(256), fft_lds, s, filt, hann, tw, e_raw, P);
+  hipLaunchKernelGGL(yaapt_nlfer_kernel, dim3(P.nframes, B), dim3(256), fft_lds, s, filt, hann, tw, e_raw, U, P);
   SAT_LAUNCH_CHECK("yaapt_nlfer_kernel");
-  hipLaunchKernelGGL(yaapt_energy_norm_kernel, dim3(B), dim3(256), 0, s, e_raw, energy, vuv, P);
+  hipLaunchKernelGGL(yaapt_energy_norm_kernel, dim3(B), dim3(256), 0, s, e_raw, energy, vuv, U, P);
   SAT_LAUNCH_CHECK("yaapt_energy_norm_kernel");
-  hipLaunchKernelGGL(yaapt_spec_kernel, dim3(P.nframes, B), dim3(256), fft_lds, s, filt, kaiser, tw, vuv, cand, P);
+  hipLaunchKernelGGL(yaapt_spec_kernel, dim3(P.nframes, B), dim3(256), fft_lds, s, filt, kaiser, tw, vuv, cand, U, P);
   SAT_LAUNCH_CHECK("yaapt_spec_kernel");
   const size_t post_lds = (size_t)nf * (4 + 4 + 3) * sizeof(float) + nf * 2 * sizeof(short) + nf * 5;
-  hipLaunchKernelGGL(yaapt_spec_post_kernel, dim3(B), dim3(64), post_lds, s, cand, spec, scal, status, P);
+  hipLaunchKernelGGL(yaapt_spec_post_kernel, dim3(B), dim3(64), post_lds, s, cand, spec, scal, status, U, P);
   SAT_LAUNCH_CHECK("yaapt_spec_post_kernel");
-  hipLaunchKernelGGL(yaapt_frame_means_kernel, dim3(B, 2), dim3(256), 0, s, filt, fmean, P);
+  hipLaunchKernelGGL(yaapt_frame_means_kernel, dim3(B, 2), dim3(256), 0, s, filt, fmean, U, P);
   SAT_LAUNCH_CHECK("yaapt_frame_means_kernel");
-  hipLaunchKernelGGL(yaapt_nccf_kernel, dim3(P.nframes, 2, B), dim3(256), 0, s, filt, fmean, spec, scal, tp, tm, status, P);
+  hipLaunchKernelGGL(yaapt_nccf_kernel, dim3(P.nframes, 2, B), dim3(256), 0, s, filt, fmean, spec, scal, tp, tm, status, U, P);
   SAT_LAUNCH_CHECK("yaapt_nccf_kernel");
   const size_t dp_lds = (size_t)nf * (2 * NC + 2) * sizeof(float) + nf * (NC + 1);
-  hipLaunchKernelGGL(yaapt_refine_dp_kernel, dim3(B), dim3(64), dp_lds, s, tp, tm, spec, energy, vuv, f0, P);
+  hipLaunchKernelGGL(yaapt_refine_dp_kernel, dim3(B), dim3(64), dp_lds, s, tp, tm, spec, energy, vuv, f0, U, P);
   SAT_LAUNCH_CHECK("yaapt_refine_dp_kernel");
   return SAT_OK;
+}
+
+extern "C" int sat_yaapt_f32(const sat_yaapt_plan* plan, const float* wav, float* f0, int32_t* status,
+                             const float* hann, const float* kaiser, const float* twiddle, void* workspace,
+                             size_t workspace_bytes, int B, void* stream) {
+  return yaapt_run(plan, wav, nullptr, f0, status, hann, kaiser, twiddle, workspace, workspace_bytes, B, stream);
+}
+
+extern "C" int sat_yaapt_ragged_f32(const sat_yaapt_plan* plan, const float* wav, const int32_t* utt_dims, float* f0,
+                                    int32_t* status, const float* hann, const float* kaiser, const float* twiddle,
+                                    void* workspace, size_t workspace_bytes, int B, void* stream) {
+  SAT_REQUIRE(utt_dims, "yaapt_ragged: null utt_dims");
+  return yaapt_run(plan, wav, utt_dims, f0, status, hann, kaiser, twiddle, workspace, workspace_bytes, B, stream);
 }

@@ -158,6 +158,42 @@ def workspace_views(ws, P, B):
     return out
 
 
+def yaapt_ragged(wav, lengths, opts, defer_status=False):
+    """wav [B, n_max] zero-padded on the HIP device, lengths [B] -> F0 [B, nframes(n_max)]: every utterance tracked
+    at its own length (zero past its frames), all in one launch sequence"""
+    if not wav.is_cuda or wav.dim() != 2:
+        raise _lib.SatError("yaapt_ragged expects [B, samples] on the HIP device")
+    wav = wav.to(torch.float32).contiguous()
+    B, n_max = wav.shape
+    lens = [int(v) for v in lengths]
+    if len(lens) != B or max(lens) > n_max or min(lens) <= 0:
+        raise _lib.SatError("yaapt_ragged: lengths do not fit the batch")
+    P = make_plan(n_max, dict(opts))
+    dims, cache = [], {}
+    for n in lens:
+        if n not in cache:
+            q = make_plan(n, dict(opts))
+            if q.pad != P.pad or q.frame_jump != P.frame_jump:
+                raise _lib.SatError("yaapt_ragged: plan constants depend on the length")
+            cache[n] = [q.n, q.L, q.nframes, q.tda_nframes]
+        dims.append(cache[n])
+    if max(d[2] for d in dims) > P.nframes or max(d[1] for d in dims) > P.Lz:
+        raise _lib.SatError("yaapt_ragged: an utterance exceeds the batch plan")
+    hann, kaiser, tw = _get_tables(P, wav.device)
+    ws_bytes = lib().sat_yaapt_workspace_bytes(C.byref(P), B)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=wav.device)
+    f0 = torch.empty(B, P.nframes, dtype=torch.float32, device=wav.device)
+    status = torch.empty(B, dtype=torch.int32, device=wav.device)
+    ud = torch.tensor(dims, dtype=torch.int32).pin_memory().to(wav.device, non_blocking=True)
+    check(lib().sat_yaapt_ragged_f32(C.byref(P), ptr(wav), ptr(ud), ptr(f0), ptr(status), ptr(hann), ptr(kaiser), ptr(tw),
+                                     ptr(ws), ws_bytes, B, stream()), "sat_yaapt_ragged_f32")
+    st = F0Status(status, B)
+    if defer_status:
+        return f0, st
+    st.check()
+    return f0
+
+
 def yaapt(wav, opts, defer_status=False, return_aux=False):
     """wav [B, n] on the HIP device -> F0 [B, nframes] on the same device"""
     if not wav.is_cuda:

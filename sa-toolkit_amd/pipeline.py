@@ -282,22 +282,26 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
                         x = pin.to(device, non_blocking=True)
                     else:
                         x = audio.to(device)
-                    if f0_mode == "per_utterance":
-                        tracks = [None] * len(utid)
-                        by_len = {}
-                        for i, n in enumerate(original_len.tolist()):
-                            by_len.setdefault(n, []).append(i)
-                        for n, idx in by_len.items():
-                            f0g = model.get_f0(x[idx, :n])
-                            for j, i in enumerate(idx):
-                                tracks[i] = f0g[j]
-                        f0 = torch.zeros(len(utid), max(t.shape[-1] for t in tracks), dtype=torch.float32, device=tracks[0].device)
-                        for i, t in enumerate(tracks):
-                            f0[i, :t.shape[-1]] = t.reshape(-1)
+                    fused = f0_mode == "per_utterance" and hasattr(model, "convert_padded") and len(targets) != 0
+                    if f0_mode == "per_utterance" and not fused:
+                        if hasattr(model, "get_f0_ragged"):
+                            f0 = model.get_f0_ragged(x, original_len)
+                        else:
+                            tracks = [None] * len(utid)
+                            by_len = {}
+                            for i, n in enumerate(original_len.tolist()):
+                                by_len.setdefault(n, []).append(i)
+                            for n, idx in by_len.items():
+                                f0g = model.get_f0(x[idx, :n])
+                                for j, i in enumerate(idx):
+                                    tracks[i] = f0g[j]
+                            f0 = torch.zeros(len(utid), max(t.shape[-1] for t in tracks), dtype=torch.float32, device=tracks[0].device)
+                            for i, t in enumerate(tracks):
+                                f0[i, :t.shape[-1]] = t.reshape(-1)
                         model.set_f0(f0.to(device))
-                    elif f0_mode != "batch":
+                    elif f0_mode not in ("per_utterance", "batch"):
                         raise ValueError(f"unknown f0_mode {f0_mode!r}")
-                    wav_conv = model.convert(x, **kw)
+                    wav_conv = model.convert_padded(x, original_len.tolist(), targets) if fused else model.convert(x, **kw)
                     if use_streams:
                         if slot["out"] is None or slot["out"].numel() < wav_conv.numel():
                             slot["out"] = torch.empty(wav_conv.numel(), dtype=wav_conv.dtype, pin_memory=True)

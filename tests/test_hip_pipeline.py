@@ -86,3 +86,27 @@ data_loader_nj = 2
         pcm, sr = read_wav(path)
         assert sr == 16000 and pcm.shape == (16000,) and np.abs(pcm).max() > 0
     assert os.path.exists(os.path.join(out, "utt2spk")) and not [f for f in os.listdir(out) if f.startswith(".wav.scp.part")]
+
+
+def test_convert_padded_is_the_batch_jobs_set_f0_then_convert(tmp_path):
+    """ragged batch: convert_padded(x, lengths, targets) == convert() after set_f0 of the per-utterance tracks
+    (each from a one-utterance get_f0 at its own length, zero-padded like the reference's collate)"""
+    import satools_amd
+    from satools_amd import synthetic
+    model = satools_amd.load_model("synthetic:" + TAG)
+    model.to("cuda")
+    model.eval()
+    lens = [16000, 12800, 9600, 16000]
+    x = torch.zeros(len(lens), max(lens))
+    for i, n in enumerate(lens):
+        x[i, :n] = synthetic.harm_batch([i], n)[0]
+    x = x.to("cuda")
+    tg = synthetic.targets(model.spk, list(range(len(lens))))
+    tracks = [model.get_f0(x[i:i + 1, :n].contiguous())[0] for i, n in enumerate(lens)]
+    f0 = torch.zeros(len(lens), max(t.shape[0] for t in tracks), device="cuda")
+    for i, t in enumerate(tracks):
+        f0[i, :t.shape[0]] = t
+    model.set_f0(f0)
+    ref = model.convert(x, target=tg)
+    got = model.convert_padded(x, lens, tg)
+    assert torch.equal(got, ref)

@@ -96,3 +96,25 @@ def test_convert_quant_awgn_option_matches_golden(gold):
     err = rms(y.cpu().numpy() - fx["harm01_16000_quant16_awgn2_seed1234"])
     print("convert quant_16_awgn_2 RMS error vs reference:", err)
     assert err < 1e-4
+
+
+def test_ragged_batch_equals_per_utterance_tracks():
+    """sat_yaapt_ragged_f32: zero-padded utterances of different lengths tracked in one launch sequence give, bit
+    for bit, the tracks of the one-utterance calls (what the reference's data loader computes), zero-padded"""
+    import satools_amd  # noqa: F401
+    from satools_amd import f0 as f0_hip, synthetic
+    opts = {"frame_length": 35.0, "frame_space": 20.0, "nccf_thresh1": 0.25, "tda_frame_length": 25.0}
+    lens = [80000, 16000, 47999, 32123, 80000, 9600]
+    wav = torch.zeros(len(lens), max(lens))
+    for i, n in enumerate(lens):
+        wav[i, :n] = synthetic.harm_batch([i], n)[0]
+    wav = wav.to("cuda")
+    got = f0_hip.yaapt_ragged(wav, lens, opts).cpu()
+    assert got.shape == (len(lens), 250)
+    for i, n in enumerate(lens):
+        one = f0_hip.yaapt(wav[i:i + 1, :n].contiguous(), opts).cpu()[0]
+        assert torch.equal(got[i, :one.shape[0]], one), f"utterance {i} (n = {n})"
+        assert (got[i, one.shape[0]:] == 0).all()
+    # uniform lengths through the ragged entry point = the batch entry point
+    u = synthetic.harm_batch([0, 1, 2], 32000).to("cuda")
+    assert torch.equal(f0_hip.yaapt_ragged(u, [32000] * 3, opts), f0_hip.yaapt(u, opts))

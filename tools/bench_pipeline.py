@@ -19,6 +19,7 @@ from pipeline_toy import write_wav
 n_utts = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 jobs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+ragged = len(sys.argv) > 4 and sys.argv[4] == "ragged"     # utterance lengths 3.0 .. 5.0 s, all different
 TAG = "hifigan_bn_tdnnf_600h_vq_48_v1"
 with tempfile.TemporaryDirectory() as tmp:
     data = os.path.join(tmp, "data", "bench")
@@ -27,7 +28,8 @@ with tempfile.TemporaryDirectory() as tmp:
     base = [synthetic.harm_batch([i], 80000)[0].numpy().astype(np.float64) for i in range(32)]
     for i in range(n_utts):
         path = os.path.join(data, "clear", f"utt{i:05d}.wav")
-        write_wav(path, base[i % 32])
+        x = base[i % 32]
+        write_wav(path, x[:80000 - (i * 997) % 32000] if ragged else x)
         scp.append(f"utt{i:05d} {path}\n")
         u2s.append(f"utt{i:05d} src{i % 40}\n")
     open(os.path.join(data, "wav.scp"), "w").writelines(scp)
@@ -47,5 +49,8 @@ with tempfile.TemporaryDirectory() as tmp:
     n = pl.process_data(data, "random_per_spk", pl.split_dict(wavscp, jobs), settings, model=model)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    secs = sum((80000 - (i * 997) % 32000) if ragged else 80000 for i in range(n_utts)) / 16000.0
+    if ragged:
+        print(f"ragged lengths (3-5 s): {secs:.0f} s of audio -> {secs / dt:.0f} x real-time")
     print(f"{n} utterances x 5 s, batch {batch}, {jobs} jobs on one GPU: {dt:.2f} s wall = {n * 5.0 / dt:.0f} x real-time "
           f"(files in -> PCM16 files out; {dt / (n / batch) * 1e3:.1f} ms per batch)")
