@@ -46,14 +46,14 @@ __device__ __forceinline__ int wmin_i(int v) {
 __device__ __forceinline__ float block_sum256(float v, float* red) {
   v = wsum(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = v;   // waves past the fourth (FFT helpers) only read
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 __device__ __forceinline__ float block_max256(float v, float* red) {
   v = wmax(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = v;
   __syncthreads();
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(128) yaapt_prefilter_kernel(const float* __res
 // 8192-point complex FFT in LDS, radix-2 decimation in time, 256 threads.  Input already stored in
 // bit-reversed order.  tw[k] = exp(-2*pi*i*k/8192), k < 4096 (host table, f64 -> f32).
 // ------------------------------------------------------------------------------------------------
+constexpr int FFT_THREADS = 1024;
 __device__ __forceinline__ int brev13(int j) { return (int)(__brev((unsigned)j) >> (32 - FFT_LOG)); }
 
 // One pass = NST consecutive radix-2 stages (s .. s+NST-1) done in registers on groups of 2^NST elements
@@ -163,9 +164,12 @@ template <int NST>
 __device__ __forceinline__ void fft8192_pass(float* re, float* im, const float2* __restrict__ tw, int s) {
   constexpr int R = 1 << NST;
   const int h = 1 << (s - 1);
+  // FFT_THREADS threads: the FFT kernels run 1024 (16 waves; LDS holds two such blocks per CU, so the waves of
+  // a block are what hides the LDS round trips of a pass); what follows the FFT keeps its 256-thread shape
 #pragma unroll 2
-  for (int k = 0; k < FFT_N / R / 256; ++k) {
-    const int i = threadIdx.x + 256 * k;
+  for (int k = 0; k < (FFT_N / R + FFT_THREADS - 1) / FFT_THREADS; ++k) {
+    const int i = threadIdx.x + FFT_THREADS * k;
+    if (FFT_N / R < FFT_THREADS && i >= FFT_N / R) break;
     const int pos = i & (h - 1);
     const int base = ((i >> (s - 1)) << (s - 1 + NST)) + pos;
     float xr[R], xi[R];
@@ -217,9 +221,9 @@ template <typename Get>
 __device__ __forceinline__ int fft8192_load_padded(float* re, float* im, int L, Get get) {
   const int z = L <= 1024 ? 3 : (L <= 2048 ? 2 : (L <= 4096 ? 1 : 0));
   const int rep = 1 << z;
-  for (int i = threadIdx.x; i < FFT_N; i += 256) im[i] = 0.f;
+  for (int i = threadIdx.x; i < FFT_N; i += FFT_THREADS) im[i] = 0.f;
   const int nblk = FFT_N >> z;                             // sample j lands on block brev13(j) >> z
-  for (int j = threadIdx.x; j < nblk; j += 256) {
+  for (int j = threadIdx.x; j < nblk; j += FFT_THREADS) {
     const float v = j < L ? get(j) : 0.f;
     const int b0 = brev13(j);
     for (int r = 0; r < rep; ++r) re[b0 + r] = v;
@@ -229,7 +233,7 @@ __device__ __forceinline__ int fft8192_load_padded(float* re, float* im, int L, 
 }
 
 // nlfer: frame (560 samples) x hann -> FFT -> sum |X[nl_lo:nl_hi]|
-__global__ void __launch_bounds__(256) yaapt_nlfer_kernel(const float* __restrict__ filt, const float* __restrict__ hann,
+__global__ void __launch_bounds__(FFT_THREADS) yaapt_nlfer_kernel(const float* __restrict__ filt, const float* __restrict__ hann,
                                                          const float2* __restrict__ tw, float* __restrict__ e_raw,
                                                          const int* __restrict__ U, const Plan P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -241,6 +245,7 @@ __global__ void __launch_bounds__(256) yaapt_nlfer_kernel(const float* __restric
   const float* x = filt + ((size_t)b * 2 + 0) * P.Lz + (size_t)f * P.frame_jump;
   const int first = fft8192_load_padded(re, im, P.frame_size, [&](int j) { return x[j] * hann[j]; });
   fft8192_from(re, im, tw, first);
+  if (threadIdx.x >= 256) return;          // whole waves: the reduction keeps its 256-thread order
   float part = 0.f;
   for (int k = P.nl_lo + threadIdx.x; k < P.nl_hi; k += 256) part += hypotf(re[k], im[k]);
   const float tot = block_sum256(part, red);
@@ -266,7 +271,7 @@ __global__ void __launch_bounds__(256) yaapt_energy_norm_kernel(const float* __r
 
 // spectral track, per voiced frame: 1120 samples x kaiser, minus mean -> FFT -> |X| -> SHC -> peaks
 // cand layout: [b][8][nframes] = pitch[0..3], merit[0..3]
-__global__ void __launch_bounds__(256) yaapt_spec_kernel(const float* __restrict__ filt, const float* __restrict__ kaiser,
+__global__ void __launch_bounds__(FFT_THREADS) yaapt_spec_kernel(const float* __restrict__ filt, const float* __restrict__ kaiser,
                                                         const float2* __restrict__ tw, const int* __restrict__ vuv,
                                                         float* __restrict__ cand, const int* __restrict__ U, const Plan P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -291,11 +296,12 @@ __global__ void __launch_bounds__(256) yaapt_spec_kernel(const float* __restrict
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int j = tid + 256 * k;
-    if (j < P.nframe_size) part += x[j] * kaiser[j];
+    if (tid < 256 && j < P.nframe_size) part += x[j] * kaiser[j];
   }
   const float mean = block_sum256(part, red) / (float)P.nframe_size;
   const int first = fft8192_load_padded(re, im, P.nframe_size, [&](int j) { return x[j] * kaiser[j] - mean; });
   fft8192_from(re, im, tw, first);
+  if (tid >= 256) return;                  // whole waves: everything after the FFT keeps its 256-thread shape
   // magnitude[i] = i < half_wl ? 0 : |X[i - half_wl]| ; written over the front of `im` is unsafe
   // (both are inputs), so it goes to a separate region: reuse re[] after reading (two passes).
   const int n_mag = P.min_shc * (P.nharm + 1) + (P.max_shc - P.min_shc) * (P.nharm + 1) + P.wl;  // exclusive bound
@@ -928,11 +934,11 @@ static int yaapt_run(const sat_yaapt_plan* plan, const float* wav, const int32_t
     SAT_HIP(hipFuncSetAttribute((const void*)yaapt_refine_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(yaapt_nlfer_kernel, dim3(P.nframes, B), dim3(256), fft_lds, s, filt, hann, tw, e_raw, U, P);
+  hipLaunchKernelGGL(yaapt_nlfer_kernel, dim3(P.nframes, B), dim3(FFT_THREADS), fft_lds, s, filt, hann, tw, e_raw, U, P);
   SAT_LAUNCH_CHECK("yaapt_nlfer_kernel");
   hipLaunchKernelGGL(yaapt_energy_norm_kernel, dim3(B), dim3(256), 0, s, e_raw, energy, vuv, U, P);
   SAT_LAUNCH_CHECK("yaapt_energy_norm_kernel");
-  hipLaunchKernelGGL(yaapt_spec_kernel, dim3(P.nframes, B), dim3(256), fft_lds, s, filt, kaiser, tw, vuv, cand, U, P);
+  hipLaunchKernelGGL(yaapt_spec_kernel, dim3(P.nframes, B), dim3(FFT_THREADS), fft_lds, s, filt, kaiser, tw, vuv, cand, U, P);
   SAT_LAUNCH_CHECK("yaapt_spec_kernel");
   const size_t post_lds = (size_t)nf * (4 + 4 + 3) * sizeof(float) + nf * 2 * sizeof(short) + nf * 5;
   hipLaunchKernelGGL(yaapt_spec_post_kernel, dim3(B), dim3(64), post_lds, s, cand, spec, scal, status, U, P);
