@@ -197,3 +197,27 @@ def rand_batch(seed, B, n=80000):
 def targets(spk, idx):
     """target speaker of utterance i: spk[(7*i) mod len(spk)]"""
     return [spk[(7 * i) % len(spk)] for i in idx]
+
+
+def xvector_state(seed=0, num_speakers=10):
+    """seeded state dict of the x-vector extractor (reference key names): conv / linear weights N(0, 1.5/fan_in),
+    BatchNorm statistics and affine terms away from the identity so that every term of the arithmetic is exercised"""
+    from . import xvector
+    net = xvector.build()(num_speakers=num_speakers)
+    sd = {}
+    for i, (k, v) in enumerate(net.state_dict().items()):
+        g = torch.Generator().manual_seed(int(seed) * 100003 + i)
+        if k.endswith("num_batches_tracked") or k.startswith("preprocessor."):
+            sd[k] = v.clone()
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(v.shape, generator=g)
+        elif k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(v.shape, generator=g)
+        elif ".bn" in k and k.endswith("weight"):
+            sd[k] = 0.8 + 0.4 * torch.rand(v.shape, generator=g)
+        elif k.endswith("bias"):
+            sd[k] = 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            fan_in = v[0].numel() if v.dim() > 1 else v.numel()
+            sd[k] = torch.randn(v.shape, generator=g) * math.sqrt(1.5 / fan_in)
+    return sd
