@@ -124,6 +124,7 @@ typedef struct {
   float res_split_slope;
   int32_t y_split_format;  /* 0 = the format this mode reads (F16X3: SAT_SPLIT_F16, F16F8: SAT_SPLIT_F8),
                               1 = SAT_SPLIT_F16, 2 = SAT_SPLIT_F8 */
+  int32_t relu_first;      /* apply the ReLU BEFORE ch_scale / ch_shift (conv -> relu -> BatchNorm, ECAPA-TDNN) */
 } sat_conv1d_desc;
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
@@ -286,6 +287,34 @@ int sat_layernorm_channels_f32(const float* x, const float* gamma, const float* 
                                int64_t y_cstride, int gelu, int split_phases, void* stream);
 int sat_softmax_columns_f32(float* st, int G, int T, int pitch, float scale, void* stream);
 int sat_transpose_heads_f32(const float* v, float* vt, int G, int D, int T, int pitch, int jpad, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * x-vector extractor (ECAPA-TDNN; egs/asv/voxceleb/local/tuning/ecapa_tdnn.py:18-81).  Every Conv1d / Linear goes
+ * through sat_conv1d_f32 (relu_first: ReLU before the folded BatchNorm, sidekit/nn.py:106-118); these are the rest.
+ *   sat_melspec_logmel_f32   pre-emphasis (augmentation.py:219-244) + torchaudio MelSpectrogram(n_fft 1024, win 400,
+ *                            hop 160, center/reflect, power 2) + 1e-6 + log  (sidekit/preprocessor.py:223-232):
+ *                            wav [B][n] -> out [B][n_mel][1 + n/160]; window [400]; fb [n_mel][513] with the non-zero
+ *                            range [fb_lo, fb_hi) of every filter (host tables)
+ *   sat_instnorm_rows_f32    InstanceNorm1d over time (preprocessor.py:233): rows of [R][T]
+ *   sat_row_mean_f32         mean over time of [R][T] rows (SE_Connect, sidekit/nn.py:132)
+ *   sat_add3_f32             y = a + b (+ c) on channel slices [B][C][T] (Res2Net partial sums nn.py:99-101,
+ *                            block inputs archi.py:183-185)
+ *   sat_se_gate_add_f32      y = z * sigmoid(g[b][c]) + s1 + s2 + s3 (SE gate nn.py:133-136 + skip connections)
+ *   sat_tanh_inplace_f32, sat_attentive_stats_f32   AttentiveStatsPool (sidekit/pooling.py:148-155): softmax over time
+ *                            of `logits`, weighted mean and std of x -> out [B][2C]
+ *   sat_l2norm_rows_f32      F.normalize(x, dim=1) (ecapa_tdnn.py:76)
+ * ------------------------------------------------------------------------------------------ */
+int sat_melspec_logmel_f32(const float* wav, float* out, const float* window, const float* fb, const int32_t* fb_lo,
+                           const int32_t* fb_hi, int B, int n, int n_mel, float coef, void* stream);
+int sat_instnorm_rows_f32(const float* x, float* y, int R, int T, float eps, void* stream);
+int sat_row_mean_f32(const float* x, float* y, int R, int T, void* stream);
+int sat_add3_f32(const float* a, const float* b, const float* c, float* y, int B, int C, int T, int64_t a_bs, int64_t a_cs,
+                 int64_t b_bs, int64_t b_cs, int64_t c_bs, int64_t c_cs, int64_t y_bs, int64_t y_cs, void* stream);
+int sat_se_gate_add_f32(const float* z, const float* gate_logits, const float* s1, const float* s2, const float* s3,
+                        float* y, int B, int C, int T, int64_t y_bs, int64_t y_cs, void* stream);
+int sat_tanh_inplace_f32(float* x, size_t n, void* stream);
+int sat_attentive_stats_f32(const float* x, const float* logits, float* out, int B, int C, int T, void* stream);
+int sat_l2norm_rows_f32(const float* x, float* y, int R, int D, void* stream);
 
 #ifdef __cplusplus
 }

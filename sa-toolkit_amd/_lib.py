@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ch_scale", C.c_void_p), ("ch_shift", C.c_void_p),
         ("x_split", C.c_void_p), ("y_split", C.c_void_p), ("y_split_slope", C.c_float), ("no_y", C.c_int32),
         ("res_split", C.c_void_p), ("res_split_slope", C.c_float), ("y_split_format", C.c_int32),
+        ("relu_first", C.c_int32),
     ]
 
 
@@ -77,6 +78,15 @@ _PROTOS = {
                                 C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "sat_yaapt_ragged_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "sat_melspec_logmel_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_int, C.c_float, C.c_void_p]),
+    "sat_instnorm_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "sat_row_mean_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sat_add3_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_int64] * 8 + [C.c_void_p]),
+    "sat_se_gate_add_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_int64] * 2 + [C.c_void_p]),
+    "sat_tanh_inplace_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sat_attentive_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sat_l2norm_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sat_w2v2_conv0_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p]),
     "sat_layernorm_channels_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

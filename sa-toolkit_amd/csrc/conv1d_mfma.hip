@@ -52,7 +52,7 @@ struct ConvArgs {
   int cin_g, T_in, rows_g, cout_g, T_q;
   int ksize, dil, stride, pad_left, up;
   int cin_pad, co_pad, xw, co_tiles_g;
-  int in_lrelu, relu, accum, gelu, res_after;
+  int in_lrelu, relu, accum, gelu, res_after, relu_first;
   float in_slope, accum_div, res_scale;
   int res_toff, res_tstride;
   const void* w2;        // fused pair: packed split-f16 weights of the second conv
@@ -263,11 +263,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] += p.res_scale * rv[r];
         }
+        if (p.relu && p.relu_first) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
         if (p.ch_scale) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = v[r] * sc[r] + sh[r];
         }
-        if (p.relu) {
+        if (p.relu && !p.relu_first) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
@@ -369,8 +373,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         const int t = q * up + ph;
         float v = acc[m][n][r] + bias;
         if (rrow && !p.res_after) v += p.res_scale * rrow[(long long)t * p.res_tstride + p.res_toff];
+        if (p.relu && p.relu_first) v = v > 0.f ? v : 0.f;
         if (p.ch_scale) v = v * sc + sh;
-        if (p.relu) v = v > 0.f ? v : 0.f;
+        if (p.relu && !p.relu_first) v = v > 0.f ? v : 0.f;
         if (p.gelu) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
         if (rrow && p.res_after) v += p.res_scale * rrow[(long long)t * p.res_tstride + p.res_toff];
         if (p.accum) v = yrow[t] + v;
@@ -1798,6 +1803,7 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
   a.in_lrelu = d->in_lrelu;
   a.in_slope = d->in_slope;
   a.relu = d->relu;
+  a.relu_first = d->relu_first;
   a.gelu = d->gelu;
   a.res_after = d->res_after_act;
   a.accum = d->accum;

@@ -26,7 +26,7 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
            up=1, in_lrelu=None, res=None, res_scale=1.0, res_toff=0, res_tstride=1, ch_scale=None, ch_shift=None,
            relu=False, gelu=False, post_res=None, out=None, accum=False, accum_div=0.0, mode=0, t_out=None,
            x_split=None, y_split=None, y_split_slope=1.0, no_y=False, y_split_format=0, res_split=None,
-           res_split_slope=1.0):
+           res_split_slope=1.0, relu_first=False):
     """Fused conv (see include/satools_hip.h sat_conv1d_f32).  `pad_right` defaults to the
     'same'-style value implied by pad_left for stride 1; T_q is derived like torch does:
     T_q = (T_in + pad_left + pad_right - dilation*(ksize-1) - 1)//stride + 1 (`t_out` caps it).
@@ -73,6 +73,7 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
     d.x_split, d.y_split = ptr(x_split), ptr(y_split)
     d.y_split_slope, d.no_y, d.y_split_format = float(y_split_slope), int(no_y), int(y_split_format)
     d.res_split, d.res_split_slope = ptr(res_split), float(res_split_slope)
+    d.relu_first = int(relu_first)
     check(lib().sat_conv1d_f32(C.byref(d), ptr(x, strided=True), ptr(w_packed), ptr(out, strided=True), stream()),
           "sat_conv1d_f32")
     return out
@@ -251,3 +252,82 @@ def resblock_pair(x, w1, b1, w2, b2, ksize, dilation, slope=0.1, out=None, accum
     check(lib().sat_resblock_pair_f16x3(C.byref(d), None if planes_residual else ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(out), stream()),
           "sat_resblock_pair_f16x3")
     return out
+
+
+# ---- x-vector extractor (csrc/xvector.hip) -------------------------------------------------------
+def melspec_logmel(wav, window, fb, coef=0.97):
+    """wav [B, n] -> log-mel [B, n_mel, 1 + n // 160]; fb [n_mel, 513] (rows = filters)"""
+    wav = _f32c(wav)
+    B, n = wav.shape
+    n_mel = fb.shape[0]
+    nz = fb > 0
+    lo = torch.where(nz.any(1), nz.float().argmax(1), torch.zeros(n_mel, dtype=torch.long, device=fb.device)).to(torch.int32)
+    hi = torch.where(nz.any(1), fb.shape[1] - torch.flip(nz, [1]).float().argmax(1),
+                     torch.zeros(n_mel, dtype=torch.long, device=fb.device)).to(torch.int32)
+    out = torch.empty(B, n_mel, 1 + n // 160, dtype=torch.float32, device=wav.device)
+    check(lib().sat_melspec_logmel_f32(ptr(wav), ptr(out), ptr(window), ptr(fb), ptr(lo.contiguous()), ptr(hi.contiguous()), B, n,
+                                       n_mel, float(coef), stream()), "sat_melspec_logmel_f32")
+    return out
+
+
+def instnorm_rows(x, eps=1e-5):
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    check(lib().sat_instnorm_rows_f32(ptr(x), ptr(y), x.shape[0] * x.shape[1], x.shape[2], float(eps), stream()), "sat_instnorm_rows_f32")
+    return y
+
+
+def row_mean(x):
+    """[B, C, T] -> [B, C, 1]: mean over time"""
+    x = _f32c(x)
+    B, c, t = x.shape
+    y = torch.empty(B, c, 1, dtype=torch.float32, device=x.device)
+    check(lib().sat_row_mean_f32(ptr(x), ptr(y), B * c, t, stream()), "sat_row_mean_f32")
+    return y
+
+
+def add3(a, b, c=None, out=None):
+    """a + b (+ c) on [B, C, T] channel slices (views with T contiguous are fine)"""
+    a, b = _strided3(a), _strided3(b)
+    c = _strided3(c) if c is not None else None
+    B, ch, t = a.shape
+    if out is None:
+        out = torch.empty(B, ch, t, dtype=torch.float32, device=a.device)
+    check(lib().sat_add3_f32(ptr(a, strided=True), ptr(b, strided=True), ptr(c, strided=True), ptr(out, strided=True), B, ch, t,
+                             a.stride(0), a.stride(1), b.stride(0), b.stride(1), c.stride(0) if c is not None else 0,
+                             c.stride(1) if c is not None else 0, out.stride(0), out.stride(1), stream()), "sat_add3_f32")
+    return out
+
+
+def se_gate_add(z, gate_logits, skips, out=None):
+    """z * sigmoid(gate_logits[b, c]) + skips[0] + skips[1] + ...  (up to three skips, added left to right)"""
+    z = _f32c(z)
+    B, c, t = z.shape
+    g = _f32c(gate_logits.reshape(B, c))
+    sk = [_f32c(s) for s in skips] + [None] * (3 - len(skips))
+    if out is None:
+        out = torch.empty_like(z)
+    check(lib().sat_se_gate_add_f32(ptr(z), ptr(g), ptr(sk[0]), ptr(sk[1]), ptr(sk[2]), ptr(out, strided=True), B, c, t,
+                                    out.stride(0), out.stride(1), stream()), "sat_se_gate_add_f32")
+    return out
+
+
+def tanh_(x):
+    check(lib().sat_tanh_inplace_f32(ptr(x), x.numel(), stream()), "sat_tanh_inplace_f32")
+    return x
+
+
+def attentive_stats(x, logits):
+    """[B, C, T] x 2 -> [B, 2C, 1]: softmax-weighted mean and std over time"""
+    x, logits = _f32c(x), _f32c(logits)
+    B, c, t = x.shape
+    out = torch.empty(B, 2 * c, 1, dtype=torch.float32, device=x.device)
+    check(lib().sat_attentive_stats_f32(ptr(x), ptr(logits), ptr(out), B, c, t, stream()), "sat_attentive_stats_f32")
+    return out
+
+
+def l2norm_rows(x):
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    check(lib().sat_l2norm_rows_f32(ptr(x), ptr(y), x.shape[0], x.shape[1], stream()), "sat_l2norm_rows_f32")
+    return y

@@ -1,0 +1,76 @@
+"""x-vector extractor (ECAPA-TDNN, SURVEY row aX / §8 f3) on the HIP device against outputs of the reference's own
+Net (tests/golden/fx_xvector.npz) and the CPU oracle.  Needs a real MI355X: run with `-m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def net():
+    import satools_amd  # noqa: F401
+    from satools_amd import synthetic, xvector
+    m = xvector.build()(num_speakers=10)
+    m.load_state_dict(synthetic.xvector_state(0, 10), strict=True)
+    return m.to(DEV)
+
+
+def test_conv_relu_then_batchnorm_epilogue():
+    """relu_first: conv -> ReLU -> folded BatchNorm (sidekit/nn.py:106-118), the order ECAPA-TDNN uses"""
+    import satools_amd  # noqa: F401
+    from satools_amd import ops, packing
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 77, generator=g)
+    w = torch.randn(48, 64, 3, generator=g) * 0.1
+    sc, sh = 0.5 + torch.rand(48, generator=g), torch.randn(48, generator=g) * 0.2
+    ref = F.relu(F.conv1d(x, w, None, padding=2, dilation=2)) * sc[None, :, None] + sh[None, :, None]
+    y = ops.conv1d(x.to(DEV), packing.pack_conv_weight(w.to(DEV)), 48, 3, pad_left=2, dilation=2, ch_scale=sc.to(DEV),
+                   ch_shift=sh.to(DEV), relu=True, relu_first=True)
+    assert (y.cpu() - ref).abs().max() < 2e-5
+
+
+def test_front_end_matches_reference(net):
+    from satools_amd import synthetic
+    fx = np.load(os.path.join(GOLD, "fx_xvector.npz"))
+    for tag, seed, n in (("harm0_16000", 0, 16000), ("harm7_24123", 7, 24123)):
+        feats = net.features(synthetic.harm_batch([seed], n).to(DEV)).cpu().numpy()
+        ref = fx[tag + "/feats"]
+        assert feats.shape == ref.shape
+        err = np.abs(feats - ref).max()
+        print(tag, "log-mel + InstanceNorm max abs error vs reference:", err)
+        assert err < 5e-3          # torch.stft (pocketfft) vs the in-LDS radix-2 FFT, through log and the normalisation
+
+
+def test_xvector_matches_reference_and_oracle(net):
+    from satools_amd import synthetic
+    from oracle import xvector as ox
+    fx = np.load(os.path.join(GOLD, "fx_xvector.npz"))
+    sd = synthetic.xvector_state(0, 10)
+    for tag, seed, n in (("harm0_16000", 0, 16000), ("harm3_48000", 3, 48000), ("harm7_24123", 7, 24123)):
+        wav = synthetic.harm_batch([seed], n)
+        (loss, logits), xv = net(wav[0].to(DEV))
+        assert xv.shape == (1, 192) and torch.isnan(loss) and logits is None
+        got = xv.cpu().numpy()
+        ref = fx[tag + "/xvector"]
+        cos = float((got * ref).sum())
+        err = np.abs(got - ref).max()
+        print(f"{tag}: max abs error vs reference {err:.2e}, cosine {cos:.7f}; vs oracle {np.abs(got - ox.xvector(sd, wav).numpy()).max():.2e}")
+        assert err < 2e-4 and cos > 0.99999
+        assert abs(float(np.linalg.norm(got)) - 1.0) < 1e-5
+    # a batch of equal-length utterances = the one-utterance calls (the reference extracts with batch size 1)
+    wav = synthetic.harm_batch([1, 2], 16000).to(DEV)
+    both = net(wav)[1]
+    one = net(wav[1])[1]
+    assert torch.allclose(both[1], one[0], atol=1e-6)
+
+
+def test_cpu_input_is_refused(net):
+    from satools_amd._lib import SatError
+    with pytest.raises(SatError):
+        net(torch.zeros(16000))
