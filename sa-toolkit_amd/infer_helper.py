@@ -19,6 +19,7 @@ _CONFIGS = {
     "local/tuning/hifigan.py": "anonymizer",
     "local/chain/tuning/tdnnf_vq.py": "tdnnf_vq",
     "local/chain/tuning/tdnnf_wav2vec2_vq.py": "tdnnf_wav2vec2_vq",
+    "local/tuning/ecapa_tdnn.py": "xvector",          # egs/asv/voxceleb: the ASV x-vector extractor
 }
 
 
@@ -31,6 +32,9 @@ def _builder(base_model_path):
     if kind == "anonymizer":
         from . import anonymizer
         return anonymizer.build
+    if kind == "xvector":
+        from . import xvector
+        return xvector.build
     from . import asrbn
 
     def build(args):
