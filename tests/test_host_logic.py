@@ -164,3 +164,39 @@ print("rank", rank, "ok")
     assert r.returncode == 0, r.stdout + r.stderr
     from satools_amd import dist as sdist
     assert [sdist.shard_bounds(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+
+
+def test_anonymize_config_parsing(tmp_path):
+    """the reference's config file format ([cmd] / [<pipeline>] sections, ${:name} variables from [var] or the
+    environment, satools/satools/bin/anonymize:22-79, script_utils.py:244-290)"""
+    import configparser
+    from satools_amd import anonymize as A
+    cfg = configparser.ConfigParser()
+    cfg.read_string("""
+[var]
+root = /data
+[cmd]
+device = cuda
+ngpu = 0,2
+jobs_per_compute_device = 2
+pipeline = mypipe
+[mypipe]
+model = synthetic:hifigan_bn_tdnnf_600h_vq_48_v1
+batch_size = 16
+results_dir = ${:root}/wav
+f0_modification =
+target_selection_algorithm = constant
+target_constant_spkid = 6081
+""")
+    s = A.vartoml(cfg)
+    c = A.load_into(A.Cmd(), s["cmd"])
+    p = A.load_into(A.Pipeline(), s[c.pipeline])
+    assert c.ngpu == ["0", "2"] and c.jobs_per_compute_device == 2 and c.pipeline == "mypipe"
+    assert p.batch_size == 16 and p.results_dir == "/data/wav" and p.f0_modification == "" and p.target_constant_spkid == "6081"
+    assert p.data_loader_nj == 5 and p.new_datadir_suffix == "_anon"          # reference defaults
+    os.environ["SAT_TEST_ROOT"] = "/env"
+    try:
+        cfg.read_string("[other]\nresults_dir = ${:SAT_TEST_ROOT}/x\n")
+        assert A.vartoml(cfg)["other"]["results_dir"] == "/env/x"
+    finally:
+        del os.environ["SAT_TEST_ROOT"]
