@@ -5,7 +5,7 @@ run in, on the golden generator input: how far is each from the exact-f32-operan
   f16+f6b : cross terms in fp6 e2m3 with one power-of-two scale per 32 K-elements (MX block scale)
   f16x2   : hi*hi + lo*hi  (activations rounded to f16)
   f16x1   : hi*hi
-Diagnostic only (imports the oracle): run as `python tools/precision_emulation.py`."""
+Diagnostic only (imports the oracle): run from the repo root as `python tests/diagnostics/precision_emulation.py`."""
 import os
 import sys
 
@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import convert as oconv, hifigan as ohg   # noqa: E402
 import satools_amd                                        # noqa: E402
