@@ -208,6 +208,15 @@ int sat_vq_argmin_gather_f32(const float* z, const float* codebook, float* q, in
 int sat_pad_replicate_f32(const float* x, float* y, int B, int C, int T, int left, int right,
                           int interleave_right, void* stream);
 
+/* ASR half of the bottleneck net (Net.forward, tdnnf_vq.py:259-284).
+ *   sat_tdnnf_unfold15_f32: the input windows and the bypass of a TDNNF layer with subsampling_factor 1.5
+ *     (chain/nn.py:267-304: `unfold` of the flattened [T*D] input with step int(1.5*D), so every other window
+ *     straddles two frames; add_padd).  x [B][D][T] -> win, byp [B][D][Tq], Tq = (2(T-1))/3 + 1; the layer is a
+ *     1x1 sat_conv1d_f32 on `win` with `byp` as residual (res_scale = bypass_scale).
+ *   sat_log_softmax_channels_f32: in place over C of x [B][C][T] (F.log_softmax(xent_out, dim=2)). */
+int sat_tdnnf_unfold15_f32(const float* x, float* win, float* byp, int B, int D, int T, void* stream);
+int sat_log_softmax_channels_f32(float* x, int B, int C, int T, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Generator input assembly (Net._forward, hifigan.py:83-97): F0 normalisation statistics are
  * batch-coupled (UttCMVN(var_norm=True, keep_zeros=True), cmvn.py:143-155), so the mean/std

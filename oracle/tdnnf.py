@@ -39,7 +39,7 @@ def vq(z, codebook):
 def tdnnf_layer(sd, prefix, x, ctx, sub, bypass, return_bottleneck=False, aux=None):
     """one TDNNFBatchNorm; x [N, T, D].  prefix e.g. 'tdnnfs.0.'"""
     N, T, D = x.shape
-    win = x.reshape(N, -1).unfold(1, D * ctx, D * sub).contiguous()
+    win = x.reshape(N, -1).unfold(1, D * ctx, int(D * sub)).contiguous()      # sub = 1.5: every other window straddles two frames
     wB, bB = sd[prefix + "tdnn.linearB.inner_nat.weight"], sd[prefix + "tdnn.linearB.inner_nat.bias"]
     z = win.matmul(wB.t())
     z = z + bB
@@ -52,7 +52,17 @@ def tdnnf_layer(sd, prefix, x, ctx, sub, bypass, return_bottleneck=False, aux=No
     if return_bottleneck:
         return z
     y = F.linear(z, sd[prefix + "tdnn.linearA.weight"], sd[prefix + "tdnn.linearA.bias"])
-    if bypass:
+    if bypass and sub == 1.5:
+        # add_padd (chain/nn.py:294-304): frames 0, 1, 3, 4, 6, 7, ... of the input, the first int(T / 1.5) of them,
+        # zero-padded at the end to the length of y
+        idx = torch.arange(0, 16000 * 100, 1.5).long()[:int(T / 1.5)]
+        byp = torch.index_select(x, 1, idx) * 0.66
+        if y.shape[1] < byp.shape[1]:
+            y = F.pad(y, [0, 0, 0, byp.shape[1] - y.shape[1], 0, 0])
+        else:
+            byp = F.pad(byp, [0, 0, 0, y.shape[1] - byp.shape[1], 0, 0])
+        y = y + byp
+    elif bypass:
         l = ctx // 2 if ctx > 1 else 0
         r = -l if (ctx > 1 and ctx % 2 == 1) else None
         y = y + x[:, l:r:sub, :] * 0.66
@@ -92,6 +102,40 @@ def extract_bn_fbank(sd, wav, aux=None, hook=None):
     x = x - x.mean(dim=1).unsqueeze(1)          # UttCMVN(): mean over frames
     x = pad_input(x, 19)
     return run_stack(sd, x, FBANK_KS, FBANK_SUB, aux=aux, hook=hook)
+
+
+AFTER_KS = [1, 3, 3, 3]
+AFTER_SUB = [1.5, 1, 1, 1]
+
+
+def forward_fbank(sd, wav, hook=None):
+    """the ASR half of the fbank-tag net, `Net.forward` (tdnnf_vq.py:259-284): wav [N, n] ->
+    (chain_out [N, T', output_dim], log_softmax(xent_out) [N, T', output_dim]).  Eval mode (dropout = identity)."""
+    x = wav.detach().clone() * 32768
+    x = fb.fbank(x, 80)
+    x = x - x.mean(dim=1).unsqueeze(1)
+    x = pad_input(x, 19)
+    ks, subs = FBANK_KS, FBANK_SUB
+    x = tdnnf_layer(sd, "tdnn1.", x, ks[0], subs[0], bypass=False)
+    for i in range(1, len(ks) - 1):
+        x = tdnnf_layer(sd, f"tdnnfs.{2 * (i - 1)}.", x, ks[i], subs[i], bypass=True)
+    x = tdnnf_layer(sd, f"tdnnfs.{2 * (len(ks) - 2)}.", x, ks[-1], subs[-1], bypass=False)      # VQ layer, all of it
+    if hook:
+        hook("vq_layer", x)
+    pad, g = 0.0, 1.0
+    for k, s_ in zip(AFTER_KS, AFTER_SUB):                      # ChainE2EModel.get_padding (chain/model.py:466-473)
+        pad += (k - 1) * g
+        g *= s_
+    x = pad_input(x, int(pad) // 2)
+    for i, (k, s_) in enumerate(zip(AFTER_KS, AFTER_SUB)):
+        x = tdnnf_layer(sd, f"tdnnfs_after.{2 * i}.", x, k, s_, bypass=True)
+        if hook:
+            hook(f"after{2 * i}", x)
+    pc = tdnnf_layer(sd, "prefinal_chain.", x, 1, 1, bypass=True)
+    px = tdnnf_layer(sd, "prefinal_xent.", x, 1, 1, bypass=True)
+    chain = pc.matmul(sd["chain_output.weight"].t()) + sd["chain_output.bias"]
+    xent = px.matmul(sd["xent_output.weight"].t()) + sd["xent_output.bias"]
+    return chain, F.log_softmax(xent, dim=2)
 
 
 def extract_bn_w2v2(sd, wav, aux=None, hook=None, model=None):

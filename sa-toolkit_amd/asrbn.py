@@ -79,41 +79,42 @@ class _TdnnfBase(nn.Module):
     def _param_key(self):
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in list(self.parameters()) + list(self.buffers()))
 
+    def _layer_cache(self, lay, device, split):
+        pack = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight
+        c = _LayerCache()
+        wB = lay.tdnn.linearB.inner_nat.weight.detach().to(device=device, dtype=torch.float32)
+        bott, kin = wB.shape
+        ctx, feat = lay.context_len, lay.feat_dim
+        assert kin == ctx * feat
+        # unfold window = ctx consecutive frames of `feat` values: column j*feat + c
+        sub = lay.subsampling_factor
+        # split-f16 kernels are stride 1: a subsampling layer without context (ctx 1, sub > 1) is a 1x1 conv on
+        # every sub-th frame (sub = 2), or on the half-frame-shifted windows of sub = 1.5, run on a gathered copy
+        c.modeB = 1 if (split and ctx in (1, 2, 3) and (sub == 1 or ctx == 1)) else 0
+        c.wB = (pack if c.modeB else packing.pack_conv_weight)(wB.reshape(bott, ctx, feat).permute(0, 2, 1).contiguous())
+        c.bB = lay.tdnn.linearB.inner_nat.bias.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+        wA = lay.tdnn.linearA.weight.detach().to(device=device, dtype=torch.float32)
+        c.modeA = 1 if split else 0
+        c.wA = pack(wA.unsqueeze(-1).contiguous())
+        c.bA = lay.tdnn.linearA.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        mean = lay.bn.running_mean.detach().to(device=device, dtype=torch.float32)
+        var = lay.bn.running_var.detach().to(device=device, dtype=torch.float32)
+        # eval BatchNorm1d(affine=False): y = x*invstd + (-mean*invstd), eps = 1e-5
+        c.scale = (1.0 / torch.sqrt(var + 1e-5)).contiguous()
+        c.shift = (-mean * c.scale).contiguous()
+        c.codebook = None
+        if hasattr(lay, "bottleneck_func"):
+            c.codebook = lay.bottleneck_func.quant._embedding.weight.detach().to(
+                device=device, dtype=torch.float32).contiguous()
+        return c
+
     def _prepare(self, device):
         key = (self.precision,) + self._param_key()
         if self._cache_key == key:
             return
-        cache = []
         split = self.precision == "f16x3"
-        pack = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight
-        for lay in self._stack_layers():
-            c = _LayerCache()
-            wB = lay.tdnn.linearB.inner_nat.weight.detach().to(device=device, dtype=torch.float32)
-            bott, kin = wB.shape
-            ctx, feat = lay.context_len, lay.feat_dim
-            assert kin == ctx * feat
-            # unfold window = ctx consecutive frames of `feat` values: column j*feat + c
-            sub = int(lay.subsampling_factor)
-            # split-f16 kernels are stride 1: a subsampling layer without context (ctx 1, sub > 1) is a 1x1 conv on
-            # every sub-th frame, run on a decimated copy of its input
-            c.modeB = 1 if (split and ctx in (1, 2, 3) and (sub == 1 or ctx == 1)) else 0
-            c.wB = (pack if c.modeB else packing.pack_conv_weight)(wB.reshape(bott, ctx, feat).permute(0, 2, 1).contiguous())
-            c.bB = lay.tdnn.linearB.inner_nat.bias.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
-            wA = lay.tdnn.linearA.weight.detach().to(device=device, dtype=torch.float32)
-            c.modeA = 1 if split else 0
-            c.wA = pack(wA.unsqueeze(-1).contiguous())
-            c.bA = lay.tdnn.linearA.bias.detach().to(device=device, dtype=torch.float32).contiguous()
-            mean = lay.bn.running_mean.detach().to(device=device, dtype=torch.float32)
-            var = lay.bn.running_var.detach().to(device=device, dtype=torch.float32)
-            # eval BatchNorm1d(affine=False): y = x*invstd + (-mean*invstd), eps = 1e-5
-            c.scale = (1.0 / torch.sqrt(var + 1e-5)).contiguous()
-            c.shift = (-mean * c.scale).contiguous()
-            c.codebook = None
-            if hasattr(lay, "bottleneck_func"):
-                c.codebook = lay.bottleneck_func.quant._embedding.weight.detach().to(
-                    device=device, dtype=torch.float32).contiguous()
-            cache.append(c)
-        self._cache = cache
+        self._cache = [self._layer_cache(lay, device, split) for lay in self._stack_layers()]
+        self._cache_full = None
         self._cache_key = key
 
     def _tdnnf_layer(self, lay, c, x, xs=None, return_bottleneck=False, want_aux=False):
@@ -123,6 +124,16 @@ class _TdnnfBase(nn.Module):
         f32 tensor stays for the bypass connection.  Returns (y, planes of y or None)."""
         ctx, sub = lay.context_len, int(lay.subsampling_factor)
         B = x.shape[0]
+        if lay.subsampling_factor == 1.5:
+            # chain/nn.py:267-304: windows of the flattened input every 1.5 frames + the add_padd bypass
+            assert ctx == 1 and not return_bottleneck and c.codebook is None
+            win, byp = ops.tdnnf_unfold15(x)
+            z = ops.conv1d(win, c.wB, lay.bottleneck_dim, 1, bias=c.bB, pad_left=0, pad_right=0, mode=c.modeB)
+            kw = dict(res=byp, res_scale=lay.bypass_scale) if lay.use_bypass else {}
+            ys = ops.split_like(B, lay.out_dim, z.shape[2], x.device) if (c.modeA == 1 and lay.out_dim % 16 == 0) else None
+            y = ops.conv1d(z, c.wA, lay.out_dim, 1, bias=c.bA, ch_scale=c.scale, ch_shift=c.shift, relu=True, mode=c.modeA,
+                           y_split=ys, y_split_slope=1.0, **kw)
+            return y, ys
         planes_in = c.modeB == 1 and sub == 1 and xs is not None and x.shape[1] % 16 == 0
         need_z = c.codebook is not None or return_bottleneck
         zs = None
@@ -164,6 +175,38 @@ class _TdnnfBase(nn.Module):
         for lay, c in zip(layers[:-1], self._cache[:-1]):
             x, xs = self._tdnnf_layer(lay, c, x, xs)
         return self._tdnnf_layer(layers[-1], self._cache[-1], x, xs, return_bottleneck=True, want_aux=want_aux)
+
+    # ---- the ASR half: Net.forward up to the chain / xent outputs --------------------------
+    def _prepare_full(self, device):
+        self._prepare(device)
+        if self._cache_full is None:
+            split = self.precision == "f16x3"
+            f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+            after = [m for m in self.tdnnfs_after if isinstance(m, TDNNFBatchNormParams)]
+            full = {"after": [(m, self._layer_cache(m, device, split)) for m in after],
+                    "prefinal": [(m, self._layer_cache(m, device, split)) for m in (self.prefinal_chain, self.prefinal_xent)],
+                    "out": [((packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight)(f32(o.weight).unsqueeze(-1)),
+                             f32(o.bias).reshape(-1), o.weight.shape[0]) for o in (self.chain_output, self.xent_output)]}
+            self._cache_full = full
+        return self._cache_full
+
+    def _asr_outputs(self, x):
+        """x [B, C, T] (features, padded) -> (chain_out, log_softmax(xent_out)) as [B, T', output_dim] views"""
+        full = self._prepare_full(x.device)
+        layers = self._stack_layers()
+        xs = None
+        for lay, c in zip(layers, self._cache):          # the VQ layer runs through (quantised bottleneck -> linearA, BN, ReLU)
+            x, xs = self._tdnnf_layer(lay, c, x, xs)
+        x = ops.pad_replicate(x, self.padding_after, self.padding_after, interleave_right=True)
+        xs = None
+        for lay, c in full["after"]:
+            x, xs = self._tdnnf_layer(lay, c, x, xs)
+        outs = []
+        for (lay, c), (w, b, odim) in zip(full["prefinal"], full["out"]):
+            h, hs = self._tdnnf_layer(lay, c, x, xs)
+            outs.append(ops.conv1d(h, w, odim, 1, bias=b, mode=c.modeA, x_split=hs))
+        ops.log_softmax_channels_(outs[1])
+        return outs[0].permute(0, 2, 1), outs[1].permute(0, 2, 1)
 
 
 class _AsrHead(nn.Module):
@@ -233,5 +276,12 @@ class TdnnfVqNet(_TdnnfBase):
         return out.permute(0, 2, 1)
 
     def forward(self, x):
-        raise NotImplementedError("the ASR output head (chain/xent log-likelihoods) is outside the anonymization "
-                                  "hot path (SURVEY §8 f4); only extract_bn is implemented")
+        """waveforms [N, n] in [-1, 1] -> (chain_out, log_softmax(xent_out)), each [N, T', output_dim]
+        (tdnnf_vq.py:259-284, eval mode).  Like the reference this scales its argument in
+        place by 32768."""
+        if not x.is_cuda:
+            raise _lib.SatError("forward runs on the HIP device only (no CPU fallback); move the input to 'cuda'")
+        if x.dim() != 2:
+            raise _lib.SatError("forward expects a 2-dimensional tensor [N, samples]")
+        x *= 32768
+        return self._asr_outputs(self.features(x.to(torch.float32)))

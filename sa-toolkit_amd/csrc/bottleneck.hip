@@ -95,6 +95,57 @@ __global__ void __launch_bounds__(256) vq_kernel(const float* __restrict__ z, co
   }
 }
 
+// ---- TDNNF layer with subsampling_factor 1.5 (chain/nn.py:267-304): the reference unfolds the FLATTENED [T*D] input
+// with window D and step int(1.5*D), so window k starts at frame floor(1.5k) and, for odd k, half a frame in:
+// channels D/2..D-1 of that frame followed by channels 0..D/2-1 of the next.  The bypass (add_padd) adds frames
+// 0, 1, 3, 4, 6, 7, ... (the first int(T/1.5) of them), zero past that.  x [B][D][T] -> win, byp [B][D][Tq],
+// Tq = (2(T-1))/3 + 1; the layer is then a 1x1 conv on `win` with `byp` as its residual.
+__global__ void __launch_bounds__(256) tdnnf_unfold15_kernel(const float* __restrict__ x, float* __restrict__ win,
+                                                             float* __restrict__ byp, int D, int T, int Tq) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (k >= Tq) return;
+  const float* xb = x + (size_t)b * D * T;
+  const int f0 = (3 * k) / 2;
+  int f = f0, ch = c;
+  if (k & 1) {
+    if (c < D / 2) ch = c + D / 2;
+    else { ch = c - D / 2; f = f0 + 1; }
+  }
+  const size_t o = ((size_t)b * D + c) * Tq + k;
+  win[o] = xb[(size_t)ch * T + f];
+  byp[o] = k < (2 * T) / 3 ? xb[(size_t)c * T + f0] : 0.f;
+}
+
+// log_softmax over the channel axis of x [B][C][T], in place (F.log_softmax(xent_out, dim=2) of the reference's
+// [N, T, C] output, tdnnf_vq.py:283).  A block owns 16 consecutive frames; its 16 channel lanes per frame each
+// keep a running (max, sum of exp) over every 16th channel, merged through LDS; a second pass subtracts.
+__global__ void __launch_bounds__(256) log_softmax_channels_kernel(float* __restrict__ x, int C, int T) {
+  __shared__ float sm[16][17], ss[16][17];
+  const int ft = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + ft;
+  const int b = blockIdx.y;
+  float* xb = x + (size_t)b * C * T + t;
+  float mx = -INFINITY, s = 0.f;
+  if (t < T) {
+    for (int c = cl; c < C; c += 16) {
+      const float v = xb[(size_t)c * T];
+      if (v > mx) { s = s * expf(mx - v) + 1.f; mx = v; }
+      else s += expf(v - mx);
+    }
+  }
+  sm[cl][ft] = mx;
+  ss[cl][ft] = s;
+  __syncthreads();
+  float m = -INFINITY;
+  for (int k = 0; k < 16; ++k) m = fmaxf(m, sm[k][ft]);
+  float tot = 0.f;
+  for (int k = 0; k < 16; ++k) tot += ss[k][ft] > 0.f ? ss[k][ft] * expf(sm[k][ft] - m) : 0.f;
+  const float lse = m + logf(tot);
+  if (t < T)
+    for (int c = cl; c < C; c += 16) xb[(size_t)c * T] -= lse;
+}
+
 // ---- F0 statistics over the voiced (non-zero) entries of the whole batch ----
 __global__ void __launch_bounds__(1024) f0_stats_kernel(const float* __restrict__ f0, int n, float* __restrict__ stats) {
   __shared__ float s_a[16];
@@ -243,5 +294,20 @@ extern "C" int sat_assemble_input_f32(const float* bn, const float* f0, const fl
   dim3 grid(ceil_div(T, 256), C_bn + 1 + n_spk, B);
   hipLaunchKernelGGL(assemble_kernel, grid, dim3(256), 0, (hipStream_t)stream, bn, f0, spk, x, C_bn, T, T_f0, n_spk);
   SAT_LAUNCH_CHECK("assemble_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_tdnnf_unfold15_f32(const float* x, float* win, float* byp, int B, int D, int T, void* stream) {
+  SAT_REQUIRE(x && win && byp && B > 0 && D > 0 && D % 2 == 0 && T > 0 && B < 65536 && D < 65536, "tdnnf_unfold15: bad arguments");
+  const int Tq = (2 * (T - 1)) / 3 + 1;
+  hipLaunchKernelGGL(tdnnf_unfold15_kernel, dim3(ceil_div(Tq, 256), D, B), dim3(256), 0, (hipStream_t)stream, x, win, byp, D, T, Tq);
+  SAT_LAUNCH_CHECK("tdnnf_unfold15_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_log_softmax_channels_f32(float* x, int B, int C, int T, void* stream) {
+  SAT_REQUIRE(x && B > 0 && C > 0 && T > 0, "log_softmax_channels: bad arguments");
+  hipLaunchKernelGGL(log_softmax_channels_kernel, dim3(ceil_div(T, 16), B), dim3(256), 0, (hipStream_t)stream, x, C, T);
+  SAT_LAUNCH_CHECK("log_softmax_channels_kernel");
   return SAT_OK;
 }

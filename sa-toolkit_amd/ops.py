@@ -331,3 +331,22 @@ def l2norm_rows(x):
     y = torch.empty_like(x)
     check(lib().sat_l2norm_rows_f32(ptr(x), ptr(y), x.shape[0], x.shape[1], stream()), "sat_l2norm_rows_f32")
     return y
+
+
+# ---- ASR half of the bottleneck net ------------------------------------------------------
+def tdnnf_unfold15(x):
+    """x [B, D, T] -> (windows, bypass) [B, D, (2(T-1))//3 + 1] of a TDNNF layer with subsampling_factor 1.5"""
+    x = _f32c(x)
+    B, d, t = x.shape
+    tq = (2 * (t - 1)) // 3 + 1
+    win = torch.empty(B, d, tq, dtype=torch.float32, device=x.device)
+    byp = torch.empty_like(win)
+    check(lib().sat_tdnnf_unfold15_f32(ptr(x), ptr(win), ptr(byp), B, d, t, stream()), "sat_tdnnf_unfold15_f32")
+    return win, byp
+
+
+def log_softmax_channels_(x):
+    x_ = x
+    B, c, t = x_.shape
+    check(lib().sat_log_softmax_channels_f32(ptr(x_), B, c, t, stream()), "sat_log_softmax_channels_f32")
+    return x_

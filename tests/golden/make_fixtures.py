@@ -202,6 +202,28 @@ def main():
         out["harm01_80000/bn_sub"] = bn[:, ::8, :].numpy()
         np.savez_compressed(os.path.join(GOLD, "fx_tdnnf.npz"), **out)
 
+    if want("asr"):
+        # the ASR half: Net.forward up to the chain / xent outputs (tdnnf_vq.py:259-284)
+        out = {}
+        bx = net.bn_extractor
+        for name, wav in [("harm0_16000", synthetic.harm_batch([0], 16000)), ("harm01_32000", synthetic.harm_batch([0, 1], 32000))]:
+            acts = {}
+            hk = [bx.tdnnfs_after[0].register_forward_hook(lambda m, i, o: acts.__setitem__("after0", o.detach())),
+                  bx.tdnnfs_after[6].register_forward_hook(lambda m, i, o: acts.__setitem__("after6", o.detach())),
+                  bx.tdnnfs[20].register_forward_hook(lambda m, i, o: acts.__setitem__("vq_layer", o.detach()))]
+            with torch.no_grad():
+                chain, xent = bx(wav.clone())
+            for h in hk:
+                h.remove()
+            out[f"{name}/chain_sub"] = chain[..., ::8].numpy()
+            out[f"{name}/xent_sub"] = xent[..., ::8].numpy()
+            out[f"{name}/xent_lse"] = torch.logsumexp(xent, dim=2).numpy()
+            out[f"{name}/after0_sub"] = acts["after0"][..., ::16].numpy()
+            out[f"{name}/after6_sub"] = acts["after6"][..., ::16].numpy()
+            out[f"{name}/vq_layer_sub"] = acts["vq_layer"][..., ::16].numpy()
+        np.savez_compressed(os.path.join(GOLD, "fx_asr.npz"), **out)
+        print({k: v.shape for k, v in out.items()})
+
     if want("f0"):
         out = {}
         for n in (8000, 16384, 80000):

@@ -539,3 +539,52 @@ def test_convert_errors_like_the_reference(model):
     with pytest.raises(AssertionError):
         model.convert(wav, target=[model.spk[0], model.spk[1]])     # len(target) != len(input_wav)
     assert model.eval() is None                                      # reference quirk: train() returns None
+
+
+# ---- the ASR half of the fbank-tag net ------------------------------------------------------
+@pytest.mark.parametrize("t,d", [(4, 64), (5, 64), (6, 128), (7, 64), (58, 1024)])
+def test_tdnnf_unfold15_matches_reference_unfold(t, d):
+    """windows / bypass of a subsampling-1.5 TDNNF layer against the reference's formulation
+    (chain/nn.py:267-304): F.unfold of the flattened [T*D] input with step int(1.5*D); add_padd"""
+    ops, _ = _ops()
+    x = torch.randn(2, t, d, generator=torch.Generator().manual_seed(t))
+    win, byp = ops.tdnnf_unfold15(x.permute(0, 2, 1).contiguous().cuda())
+    want = F.unfold(x.reshape(2, 1, t * d, 1), (d, 1), stride=(int(d * 1.5), 1)).permute(0, 2, 1)     # [B, T', D]
+    assert torch.equal(win.cpu().permute(0, 2, 1), want)
+    idx = torch.arange(0, 1.6e6, 1.5).long()[:int(t / 1.5)]
+    bw = torch.zeros_like(want)
+    bw[:, :len(idx)] = x[:, idx]
+    assert torch.equal(byp.cpu().permute(0, 2, 1), bw)
+
+
+def test_log_softmax_channels():
+    ops, _ = _ops()
+    x = torch.randn(3, 3280, 37, generator=torch.Generator().manual_seed(0)) * 4
+    got = ops.log_softmax_channels_(x.cuda().clone()).cpu()
+    assert (got - torch.log_softmax(x, dim=1)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("name,ids,n", [("harm0_16000", [0], 16000), ("harm01_32000", [0, 1], 32000)])
+def test_asr_forward_matches_reference(fbank_tag_state, name, ids, n, precision):
+    """Net.forward (tdnnf_vq.py:259-284) on the HIP path against outputs of the reference itself"""
+    import os
+    from conftest import GOLD
+    from satools_amd import synthetic
+    fx = np.load(os.path.join(GOLD, "fx_asr.npz"))
+    state, model = fbank_tag_state
+    model.load_state_dict(state["base_model_state_dict"])
+    bx = model.bn_extractor.cuda()
+    old = bx.precision
+    bx.precision = precision
+    try:
+        wav = synthetic.harm_batch(ids, n)
+        chain, xent = bx(wav.clone().cuda())
+    finally:
+        bx.precision = old
+    assert chain.shape == xent.shape and chain.shape[2] == 3280
+    for got, key in ((chain, "chain_sub"), (xent, "xent_sub")):
+        want = fx[f"{name}/{key}"]
+        assert got.shape[:2] == want.shape[:2]
+        assert rms(got.cpu().numpy()[..., ::8] - want) <= 1e-4 * max(1.0, rms(want)), key
+    assert np.allclose(torch.logsumexp(xent, dim=2).cpu().numpy(), fx[f"{name}/xent_lse"], atol=1e-4)

@@ -26,3 +26,4 @@ def timed(f, n=10):
 
 print("get_bn  %.3f ms" % timed(lambda: model.get_bn(wav)))
 print("get_f0  %.3f ms" % timed(lambda: model.get_f0(wav)))
+print("ASR forward (chain + xent log-likelihoods, 3280 pdfs)  %.3f ms" % timed(lambda: model.bn_extractor(wav.clone())))
