@@ -95,7 +95,10 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # SAT_BENCH_FORCE_PG=1: take the RCCL path (process group, all-gather per step) with one rank too, to check it on a
+    # 1-GPU box (launch under torch.distributed.run --nproc-per-node 1)
+    use_pg = world > 1 or os.environ.get("SAT_BENCH_FORCE_PG") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -111,7 +114,7 @@ def main():
     f0 = analytic_f0(seeds).to(dev)
     targets = synthetic.targets(model.spk, seeds)
     gathered = ([torch.empty(world * BATCH, 1, N_SAMPLES + 1, dtype=torch.float32, device=dev)
-                 for _ in range(max(1, a.jobs))] if world > 1 else None)   # indexed modulo the job count
+                 for _ in range(max(1, a.jobs))] if use_pg else None)   # indexed modulo the job count
 
     # every job stream owns its workspaces: never more streams than warmup steps, so that each one has run
     # (and allocated) before the timed region starts
@@ -128,23 +131,23 @@ def main():
         step_no[0] += 1
         with torch.cuda.stream(s):
             y = model.convert(wav, target=targets)
-            if world > 1:
+            if use_pg:
                 dist.all_gather_into_tensor(gathered[step_no[0] % jobs], y.contiguous())
         return y
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -252,7 +255,7 @@ def main():
             sample = list(range(4))
             out["cpu_baseline"] = cpu_baseline(state, model.spk, sample)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 
