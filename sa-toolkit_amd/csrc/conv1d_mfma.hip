@@ -67,6 +67,7 @@ struct ConvArgs {
   int f8;                // planes kernels: cross terms hi*lo + lo*hi on the block-scaled e4m3 MFMA
   int poly_planes;       // up > 1, planes only: the LDS-transposed polyphase epilogue
   int y16_f8;            // output planes carry (hi f16 | e4m3(hi) | e4m3(lo * 2^10)) instead of (hi f16 | lo f16)
+  int pp_tiles_t, pp_total, pp_per_xcd, pp_nslots;   // persistent pair kernel: tiles per utterance / in all / per XCD, blocks per XCD
 #ifdef SAT_STAMPS
   long long* dbg;        // diagnostic build (tools/stamp_conv.hip): per-block, per-chunk phase time stamps
 #endif
@@ -1267,26 +1268,22 @@ static int launch_pair(const ConvArgs& a, int B, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // ResBlock1 step for the C = 16 stage on the 16x16x32 MFMA shape: 16 rows = the 16 channels exactly
 // (the 32x32 tile pads them to 32 and wastes half the matrix work), K = 32 = a PAIR of taps x 16
-// channels.  Split planes in, split planes out; both weight tiles (2 x 12 KB at k = 11), the input
-// tile and the intermediate t1 live in LDS at once, so a block issues ONE round of global loads
-// (11 x 16 B per lane) and the residual comes from the input tile it already holds.
+// channels.  Split planes in, split planes out.  Persistent blocks: both convs' A fragments stay in
+// registers (every wave holds all 16 rows), the input tile and the intermediate t1 live in LDS (36 KB,
+// 3-4 blocks per CU), the next tile's input is prefetched into registers under this tile's matrix
+// work, and the residual comes from the input tile the block already holds.
 //   lanes: A[row l&15][k = 8(l>>4)..], B[k = 8(l>>4)..][col l&15], D col = l&15, rows 4(l>>4) + r
 //   k-group g = l>>4: tap (g>>1) of the pair, channel half (g&1) -> the same 16-byte units as before
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int KS>
-__global__ void __launch_bounds__(256, 2) resblock_pair16_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   constexpr int XWI = 5, XWP = 64 * XWI;
   constexpr int NTP = (KS + 1) / 2;         // tap pairs; an odd tap count gets a zero phantom tap
-  constexpr int W_REAL = KS * 64;           // 16-byte units of one conv's weights: [tap][hi|lo][half][16 rows]
-  constexpr int WU = 2 * NTP * 64;
-  constexpr int W_IT = (W_REAL + 255) / 256;
   uint4* ldsx = lds4;                       // [4][XWP]
-  uint4* ldsw1 = ldsx + 4 * XWP;            // [2*NTP][4][16]
-  uint4* ldsw2 = ldsw1 + WU;
-  uint4* ldst = ldsw2 + WU;                 // [4][FP_W1]
+  uint4* ldst = ldsx + 4 * XWP;             // [4][FP_W1]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1294,45 +1291,49 @@ __global__ void __launch_bounds__(256, 2) resblock_pair16_kernel(const ConvArgs 
   const int j16 = lane & 15;
   const int g = lane >> 4;
   const int gh = g & 1, gt = g >> 1;        // channel half / tap of the pair
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.x * FP_TO;
   const int h2 = (KS - 1) / 2;
-  const int xi0 = t0 - FP_OFF - p.pad_left;
   const unsigned OOB = 0x80000000u;
 
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)p.x16 + (long long)b * 16 * p.T_in * 4), 0, (unsigned)(16 * p.T_in * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
   const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)p.w_gs, 0x00020000);
   const int seg_bytes = p.co_pad * 16;
+  const int pl = __builtin_amdgcn_readfirstlane(wave);
 
-  // ---- the block's only round of input loads ----
-  {
-    uint4 xst[XWI], w1st[W_IT], w2st[W_IT];
-    const int pl = __builtin_amdgcn_readfirstlane(wave);
+  // persistent walk: workgroups go round-robin to the 8 XCDs, so XCD x (= blockIdx.x & 7) owns the contiguous tile
+  // range [x, x+1) * pp_per_xcd and its pp_nslots blocks take consecutive tiles of it at the same time — neighbouring
+  // tiles share their 96-column halo through that XCD's L2.  Weights are staged once per block; the input tile of
+  // the next step is loaded into registers while this one computes.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_end = min((xcd + 1) * p.pp_per_xcd, p.pp_total);
+  int tile = xcd * p.pp_per_xcd + slot;
+  if (tile >= tile_end) return;
+
+  uint4 xst[XWI];
+  auto issue_x = [&](int tl) {
+    const int ub = tl / p.pp_tiles_t;
+    const int xi_0 = (tl - ub * p.pp_tiles_t) * FP_TO - FP_OFF - p.pad_left;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.x16 + (long long)ub * 16 * p.T_in * 4), 0, (unsigned)(16 * p.T_in * 4), 0x00020000);
 #pragma unroll
     for (int it = 0; it < XWI; ++it) {
-      const int xi = xi0 + lane + 64 * it;
+      const int xi = xi_0 + lane + 64 * it;
       const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((pl * p.T_in + xi) * 16) : OOB;
       xst[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0));
     }
+  };
+  issue_x(tile);
+  // both convs' A fragments live in registers for the block's whole walk (the 16 rows are all the channels, so every
+  // wave holds the same ones): packed units [tap][hi|lo][half][16 rows], the phantom tap of an odd count reads zeros
+  h8 w1h[NTP], w1l[NTP], w2h[NTP], w2l[NTP];
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int u = tid + 256 * i;
-      const unsigned voff = u < W_REAL ? (unsigned)((u & 15) * 16 + (u >> 4) * seg_bytes) : OOB;
-      w1st[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w1rs, voff, 0, 0));
-      w2st[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w2rs, voff, 0, 0));
-    }
-#pragma unroll
-    for (int it = 0; it < XWI; ++it) ldsx[pl * XWP + lane + 64 * it] = xst[it];
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int u = tid + 256 * i;
-      if (u < WU) {            // units past W_REAL (the phantom tap) were loaded out of range: zeros
-        ldsw1[u] = w1st[i];
-        ldsw2[u] = w2st[i];
-      }
-    }
+  for (int tp = 0; tp < NTP; ++tp) {
+    const int tap = 2 * tp + gt;
+    const unsigned vh = tap < KS ? (unsigned)(j16 * 16 + (tap * 4 + 0 + gh) * seg_bytes) : OOB;
+    const unsigned vl = tap < KS ? (unsigned)(j16 * 16 + (tap * 4 + 2 + gh) * seg_bytes) : OOB;
+    w1h[tp] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w1rs, vh, 0, 0));
+    w1l[tp] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w1rs, vl, 0, 0));
+    w2h[tp] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, vh, 0, 0));
+    w2l[tp] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, vl, 0, 0));
   }
   float bias1[4], bias2[4];
 #pragma unroll
@@ -1340,20 +1341,28 @@ __global__ void __launch_bounds__(256, 2) resblock_pair16_kernel(const ConvArgs 
     bias1[k] = p.bias1[4 * g + k];
     bias2[k] = p.bias[4 * g + k];
   }
+  for (;;) {
+  const int b = tile / p.pp_tiles_t;
+  const int t0 = (tile - b * p.pp_tiles_t) * FP_TO;
+  __syncthreads();            // the previous step's readers of the input tile and of t1 are done
+#pragma unroll
+  for (int it = 0; it < XWI; ++it) ldsx[pl * XWP + lane + 64 * it] = xst[it];
   __syncthreads();
+  const int next = tile + p.pp_nslots;
+  const bool more = next < tile_end;
+  if (more) issue_x(next);
+  __builtin_amdgcn_sched_barrier(0);
 
   // ================= phase 1: t1 = lrelu(conv1(x planes) + b1) on the 256-column window =================
   f32x4v acc[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) acc[s] = f32x4v{0.f, 0.f, 0.f, 0.f};
   {
-    const uint4* wl = ldsw1 + gh * 16 + j16;
     const uint4* xl = ldsx + gh * XWP + wave * 64 + j16;
 #pragma unroll
     for (int tp = 0; tp < NTP; ++tp) {
       const int tap = 2 * tp + gt;
-      const h8 a_hi = __builtin_bit_cast(h8, wl[(tap * 4 + 0) * 16]);
-      const h8 a_lo = __builtin_bit_cast(h8, wl[(tap * 4 + 2) * 16]);
+      const h8 a_hi = w1h[tp], a_lo = w1l[tp];
       const uint4* xt = xl + tap * p.dil;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -1392,13 +1401,11 @@ __global__ void __launch_bounds__(256, 2) resblock_pair16_kernel(const ConvArgs 
 #pragma unroll
   for (int s = 0; s < 4; ++s) acc[s] = f32x4v{0.f, 0.f, 0.f, 0.f};
   {
-    const uint4* wl = ldsw2 + gh * 16 + j16;
     const uint4* tl = ldst + gh * FP_W1 + wave * 64 + j16 + FP_OFF - h2;
 #pragma unroll
     for (int tp = 0; tp < NTP; ++tp) {
       const int tap = 2 * tp + gt;
-      const h8 a_hi = __builtin_bit_cast(h8, wl[(tap * 4 + 0) * 16]);
-      const h8 a_lo = __builtin_bit_cast(h8, wl[(tap * 4 + 2) * 16]);
+      const h8 a_hi = w2h[tp], a_lo = w2l[tp];
       const uint4* xt = tl + tap;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -1466,6 +1473,9 @@ __global__ void __launch_bounds__(256, 2) resblock_pair16_kernel(const ConvArgs 
       __builtin_amdgcn_raw_buffer_store_b64(lv, y16rs, off, 2 * p.T_q * 16, 0);
     }
   }
+  if (!more) break;
+  tile = next;
+  }
 }
 
 template <int KS>
@@ -1475,12 +1485,17 @@ static int launch_pair16(const ConvArgs& a, int B, hipStream_t s) {
     set_error("resblock_pair: dilation %d too large", p.dil);
     return SAT_ERR_INVALID;
   }
-  constexpr int WU = 2 * ((KS + 1) / 2) * 64;
-  const size_t lds_bytes = ((size_t)4 * 320 + 2 * WU + 4 * FP_W1) * 16;
+  const size_t lds_bytes = ((size_t)4 * 320 + 4 * FP_W1) * 16;
   auto kern = resblock_pair16_kernel<KS>;
   if (lds_bytes > 64 * 1024)
     SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  dim3 grid(ceil_div(p.T_q, FP_TO), 1, B);
+  // persistent: as many blocks as fit the chip at once (LDS-limited), a multiple of the 8 XCDs
+  const int per_cu = KS == 11 ? 2 : KS == 7 ? 3 : 4;    // register-limited: 16 B x 4 x ceil(KS/2) weight fragments per lane
+  p.pp_tiles_t = ceil_div(p.T_q, FP_TO);
+  p.pp_total = p.pp_tiles_t * B;
+  p.pp_per_xcd = ceil_div(p.pp_total, 8);
+  p.pp_nslots = std::max(1, std::min(32 * per_cu, p.pp_per_xcd));
+  dim3 grid(8 * p.pp_nslots, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
   SAT_LAUNCH_CHECK("resblock_pair16_kernel");
   return SAT_OK;
