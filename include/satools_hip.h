@@ -286,6 +286,9 @@ int sat_yaapt_ragged_f32(const sat_yaapt_plan* plan, const float* wav, const int
  *   sat_layernorm_channels_f32: LayerNorm over C of x[B][C][T] (eps 1e-5), optional erf-GELU; with
  *                              split_phases the output is [B][2C][ceil(T/2)] = even | odd time phases,
  *                              which turns the next stride-2 conv into a stride-1 conv
+ *   sat_layernorm_channels_planes_f32: the same, writing the result as SAT_SPLIT_F16 planes `y_split` (C % 16 == 0;
+ *                              [2C or C channels][ceil(T/2) or T frames]) for a following split-f16 conv, and as
+ *                              f32 `y` too unless `y` is null
  *   sat_softmax_columns_f32:   in place on S^T [G*T keys][pitch]: softmax over keys of scale*s per query
  *   sat_transpose_heads_f32:   v [G][D][pitch] -> vt [G][jpad][D], rows >= T zero (packed-weight layout)
  * ------------------------------------------------------------------------------------------ */
@@ -294,6 +297,9 @@ int sat_w2v2_conv0_f32(const float* x, const float* w, const float* bias, float*
 int sat_layernorm_channels_f32(const float* x, const float* gamma, const float* beta, float* y, int B,
                                int C, int T, int64_t x_bstride, int64_t x_cstride, int64_t y_bstride,
                                int64_t y_cstride, int gelu, int split_phases, void* stream);
+int sat_layernorm_channels_planes_f32(const float* x, const float* gamma, const float* beta, float* y, void* y_split,
+                                      int B, int C, int T, int64_t x_bstride, int64_t x_cstride, int64_t y_bstride,
+                                      int64_t y_cstride, int gelu, int split_phases, void* stream);
 int sat_softmax_columns_f32(float* st, int G, int T, int pitch, float scale, void* stream);
 int sat_transpose_heads_f32(const float* v, float* vt, int G, int D, int T, int pitch, int jpad, void* stream);
 

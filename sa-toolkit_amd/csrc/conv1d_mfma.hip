@@ -1002,17 +1002,18 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
   void (*kern)(const ConvArgs) = conv1d_f16x3_kernel<MT, NT, KS, XWI>;
   if (p.x16) {
     kern = nullptr;
-    // split-plane input: the tap counts of the generator (3, 7, 11) and of the TDNNF stack (1, 3)
+    // split-plane input: the tap counts of the generator (3, 7, 11), of the TDNNF stack (1, 3) and of the wav2vec2
+    // feature extractor's polyphase stride-2 convs (2, 1)
     if constexpr (KS == 3 || KS == 7 || KS == 11)
       kern = p.f8 ? conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, true, 1> : conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 1>;
-    if constexpr ((KS == 1 || KS == 3) && MT == 2) {
+    if constexpr ((KS == 1 || KS == 2 || KS == 3) && MT == 2) {
       // few taps: two 16-channel sub-chunks per pipeline stage
       if (!p.f8 && (p.cin_pad / CI_CHUNK) % 2 == 0) {
         kern = conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 2>;
         lds_bytes *= 2;
       }
     }
-    if constexpr (KS == 1) {
+    if constexpr (KS == 1 || KS == 2) {
       if (!kern && !p.f8) kern = conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 1>;
     }
     if (!kern) {

@@ -40,46 +40,46 @@ __global__ void __launch_bounds__(256) w2v2_conv0_kernel(const float* __restrict
 // A block owns 64 consecutive frames of one utterance; its 16 waves each reduce a 1/16 slice of the
 // channels (frames of a channel are contiguous, so every access is a coalesced 256-B row piece) and the
 // partial sums meet in LDS.  Two-pass mean / variance like torch's CPU kernel.
-constexpr int LN_SLICES = 16;
-constexpr int LN_FR = 16;          // frames per block
-constexpr int LN_MAXPT = 64;       // channels per thread kept in registers: C <= 16 * 64
-// Block = 16 frames x 16 channel slices (256 threads, 512 blocks at B = 32, T = 249): a thread reads its 64
-// channels of one frame ONCE into registers and both statistics passes and the output pass run from there.
-// Slice c = sl, sl + 16, ... and the slice-ordered total are the summation order of the 64-frame version.
-__global__ void __launch_bounds__(LN_FR * LN_SLICES) layernorm_ch_kernel(
+constexpr int LN_FR = 32;          // frames per block: a wave's load covers two whole 128-byte lines
+// Block = 32 frames x SLICES channel slices: a thread reads its (up to) MAXPT consecutive channels sl*MAXPT .. of one
+// frame ONCE into registers — all loads in flight at once — and both statistics passes and the output pass run
+// from there; the frame's totals are added in slice order.  32 channels per thread keep it at ~90 VGPRs (5 waves
+// per SIMD); <16, 32> serves C <= 512 (feature extractor) and <32, 32> C <= 1024 (transformer: 249 frames are 256
+// blocks in all, so each one brings 16 waves to hide its own load latency).  Outputs: f32 `y` and / or split planes
+// `y16` (satools_hip.h: hi | lo f16 of the value, 16-byte units of 8 channels) — a thread's channels are whole units.
+template <int SLICES, int MAXPT>
+__global__ void __launch_bounds__(LN_FR * SLICES) layernorm_ch_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-    int C, int T, long long x_bs, long long x_cs, long long y_bs, long long y_cs, int gelu, int split) {
-  __shared__ float part[LN_SLICES][LN_FR];
+    uint4* __restrict__ y16, int C, int T, long long x_bs, long long x_cs, long long y_bs, long long y_cs, int gelu, int split) {
+  __shared__ float part[SLICES][LN_FR];
   __shared__ float s_mean[LN_FR], s_rstd[LN_FR];
   const int b = blockIdx.y;
   const int tx = threadIdx.x & (LN_FR - 1), sl = threadIdx.x / LN_FR;
   const int t = blockIdx.x * LN_FR + tx;
   const bool ok = t < T;
+  const int cb = sl * MAXPT;
   const float* xb = x + (size_t)b * x_bs + (ok ? t : 0);
-  float v[LN_MAXPT];
+  float v[MAXPT];
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXPT; ++k) {
-    const int c = sl + k * LN_SLICES;
-    v[k] = (ok && c < C) ? xb[(size_t)c * x_cs] : 0.f;
-  }
+  for (int k = 0; k < MAXPT; ++k) v[k] = (ok && cb + k < C) ? xb[(size_t)(cb + k) * x_cs] : 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXPT; ++k)
-    if (sl + k * LN_SLICES < C) s += v[k];
+  for (int k = 0; k < MAXPT; ++k)
+    if (cb + k < C) s += v[k];
   part[sl][tx] = s;
   __syncthreads();
   if (sl == 0) {
     float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_SLICES; ++i) tot += part[i][tx];
+    for (int i = 0; i < SLICES; ++i) tot += part[i][tx];
     s_mean[tx] = tot / (float)C;
   }
   __syncthreads();
   const float mean = s_mean[tx];
   float q = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXPT; ++k)
-    if (sl + k * LN_SLICES < C) {
+  for (int k = 0; k < MAXPT; ++k)
+    if (cb + k < C) {
       const float d = v[k] - mean;
       q = fmaf(d, d, q);
     }
@@ -89,24 +89,68 @@ __global__ void __launch_bounds__(LN_FR * LN_SLICES) layernorm_ch_kernel(
   if (sl == 0) {
     float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_SLICES; ++i) tot += part[i][tx];
+    for (int i = 0; i < SLICES; ++i) tot += part[i][tx];
     s_rstd[tx] = 1.0f / sqrtf(tot / (float)C + 1e-5f);
   }
   __syncthreads();
   if (!ok) return;
   const float rstd = s_rstd[tx];
-  float* yb = y + (size_t)b * y_bs;
   const int ph = split ? (t & 1) : 0;
   const int u = split ? (t >> 1) : t;
   const bool tail = split && (T & 1) && t == T - 1;   // odd length: the odd phase's last slot is zero padding
+  // output in groups of 8 channels (= one 16-byte unit of the planes): gamma / beta as two float4 loads each
+  float* yf = y ? y + (size_t)b * y_bs : nullptr;
+  const int Co = split ? 2 * C : C, Tp = split ? (T + 1) / 2 : T;
+  uint4* yp = y16 ? y16 + (size_t)b * (Co / 4) * Tp : nullptr;             // Co * Tp * 4 bytes per utterance
 #pragma unroll
-  for (int k = 0; k < LN_MAXPT; ++k) {
-    const int c = sl + k * LN_SLICES;
-    if (c < C) {
-      float o = (v[k] - mean) * rstd * gamma[c] + beta[c];
-      if (gelu) o = gelu_erf(o);
-      yb[(size_t)(ph * C + c) * y_cs + u] = o;
-      if (tail) yb[(size_t)(C + c) * y_cs + u] = 0.f;
+  for (int g8 = 0; g8 < MAXPT / 8; ++g8) {
+    const int c0 = cb + 8 * g8;
+    if (c0 >= C) break;
+    float gm[8], bt[8], o[8];
+    if (c0 + 8 <= C) {
+      *(float4*)&gm[0] = *(const float4*)&gamma[c0];
+      *(float4*)&gm[4] = *(const float4*)&gamma[c0 + 4];
+      *(float4*)&bt[0] = *(const float4*)&beta[c0];
+      *(float4*)&bt[4] = *(const float4*)&beta[c0 + 4];
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        gm[jj] = c0 + jj < C ? gamma[c0 + jj] : 0.f;
+        bt[jj] = c0 + jj < C ? beta[c0 + jj] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      o[jj] = (v[8 * g8 + jj] - mean) * rstd * gm[jj] + bt[jj];
+      if (gelu) o[jj] = gelu_erf(o[jj]);
+    }
+    if (yf) {
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        if (c0 + jj < C) {
+          yf[(size_t)(ph * C + c0 + jj) * y_cs + u] = o[jj];
+          if (tail) yf[(size_t)(C + c0 + jj) * y_cs + u] = 0.f;
+        }
+    }
+    if (yp) {
+      unsigned hi[4], lo[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const auto h = __builtin_amdgcn_cvt_pkrtz(o[2 * jj], o[2 * jj + 1]);
+        const auto l = __builtin_amdgcn_cvt_pkrtz(o[2 * jj] - (float)h[0], o[2 * jj + 1] - (float)h[1]);
+        hi[jj] = __builtin_bit_cast(unsigned, h);
+        lo[jj] = __builtin_bit_cast(unsigned, l);
+      }
+      const int co = ph * C + c0;
+      const size_t un = (size_t)((co >> 4) * 4 + ((co >> 3) & 1)) * Tp + u;
+      yp[un] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      yp[un + 2 * (size_t)Tp] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      if (tail) {
+        const int c1 = C + c0;
+        const size_t u1 = (size_t)((c1 >> 4) * 4 + ((c1 >> 3) & 1)) * Tp + u;
+        yp[u1] = make_uint4(0, 0, 0, 0);
+        yp[u1 + 2 * (size_t)Tp] = make_uint4(0, 0, 0, 0);
+      }
     }
   }
 }
@@ -192,18 +236,35 @@ extern "C" int sat_w2v2_conv0_f32(const float* x, const float* w, const float* b
   return SAT_OK;
 }
 
-extern "C" int sat_layernorm_channels_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int C,
-                                          int T, int64_t x_bstride, int64_t x_cstride, int64_t y_bstride,
-                                          int64_t y_cstride, int gelu, int split_phases, void* stream) {
-  SAT_REQUIRE(x && gamma && beta && y, "layernorm_channels: null pointer");
+static int layernorm_launch(const float* x, const float* gamma, const float* beta, float* y, void* y_split, int B, int C, int T,
+                            int64_t x_bstride, int64_t x_cstride, int64_t y_bstride, int64_t y_cstride, int gelu,
+                            int split_phases, void* stream) {
+  SAT_REQUIRE(x && gamma && beta && (y || y_split), "layernorm_channels: null pointer");
   SAT_REQUIRE(B > 0 && C > 0 && T > 0, "layernorm_channels: empty shape");
-  SAT_REQUIRE(C <= LN_SLICES * LN_MAXPT, "layernorm_channels: at most %d channels", LN_SLICES * LN_MAXPT);
+  SAT_REQUIRE(C <= 1024, "layernorm_channels: at most %d channels", 1024);
+  SAT_REQUIRE(!y_split || C % 16 == 0, "layernorm_channels: split planes need a multiple of 16 channels (got %d)", C);
   dim3 grid(ceil_div(T, LN_FR), B);
-  hipLaunchKernelGGL(layernorm_ch_kernel, grid, dim3(LN_FR * LN_SLICES), 0, (hipStream_t)stream, x, gamma, beta, y, C, T,
+  const bool wide = C > 512;
+  auto kern = wide ? layernorm_ch_kernel<32, 32> : layernorm_ch_kernel<16, 32>;
+  hipLaunchKernelGGL(kern, grid, dim3(LN_FR * (wide ? 32 : 16)), 0, (hipStream_t)stream, x, gamma, beta, y, (uint4*)y_split, C, T,
                      (long long)x_bstride, (long long)x_cstride, (long long)y_bstride, (long long)y_cstride, gelu,
                      split_phases);
   SAT_LAUNCH_CHECK("layernorm_ch_kernel");
   return SAT_OK;
+}
+
+extern "C" int sat_layernorm_channels_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int C,
+                                          int T, int64_t x_bstride, int64_t x_cstride, int64_t y_bstride,
+                                          int64_t y_cstride, int gelu, int split_phases, void* stream) {
+  SAT_REQUIRE(y, "layernorm_channels: null pointer");
+  return layernorm_launch(x, gamma, beta, y, nullptr, B, C, T, x_bstride, x_cstride, y_bstride, y_cstride, gelu, split_phases, stream);
+}
+
+extern "C" int sat_layernorm_channels_planes_f32(const float* x, const float* gamma, const float* beta, float* y, void* y_split,
+                                                 int B, int C, int T, int64_t x_bstride, int64_t x_cstride, int64_t y_bstride,
+                                                 int64_t y_cstride, int gelu, int split_phases, void* stream) {
+  SAT_REQUIRE(y_split, "layernorm_channels_planes: null pointer");
+  return layernorm_launch(x, gamma, beta, y, y_split, B, C, T, x_bstride, x_cstride, y_bstride, y_cstride, gelu, split_phases, stream);
 }
 
 extern "C" int sat_softmax_columns_f32(float* st, int G, int T, int pitch, float scale, void* stream) {

@@ -161,15 +161,24 @@ def w2v2_conv0(wav, w, bias, stride=5):
     return y
 
 
-def layernorm_ch(x, gamma, beta, gelu=False, split_phases=False):
-    """LayerNorm over channels of [B, C, T]; split_phases -> [B, 2C, ceil(T/2)] (even | odd frames)"""
+def layernorm_ch(x, gamma, beta, gelu=False, split_phases=False, planes=False, want_f32=True):
+    """LayerNorm over channels of [B, C, T]; split_phases -> [B, 2C, ceil(T/2)] (even | odd frames).
+    planes: also (want_f32=False: only) write the result as split planes for a following split-f16 conv and
+    return (y, planes) — without want_f32 `y` is an unwritten tensor that only carries the shape."""
     x = _strided3(x)
     B, c, t = x.shape
     y = torch.empty((B, 2 * c, (t + 1) // 2) if split_phases else (B, c, t), dtype=torch.float32, device=x.device)
-    check(lib().sat_layernorm_channels_f32(ptr(x, strided=True), ptr(gamma), ptr(beta), ptr(y), B, c, t, x.stride(0),
-                                           x.stride(1), y.stride(0), y.stride(1), int(gelu), int(split_phases),
-                                           stream()), "sat_layernorm_channels_f32")
-    return y
+    if not planes:
+        check(lib().sat_layernorm_channels_f32(ptr(x, strided=True), ptr(gamma), ptr(beta), ptr(y), B, c, t, x.stride(0),
+                                               x.stride(1), y.stride(0), y.stride(1), int(gelu), int(split_phases),
+                                               stream()), "sat_layernorm_channels_f32")
+        return y
+    ys = split_like(B, y.shape[1], y.shape[2], x.device)
+    check(lib().sat_layernorm_channels_planes_f32(ptr(x, strided=True), ptr(gamma), ptr(beta), ptr(y) if want_f32 else None,
+                                                  ptr(ys), B, c, t, x.stride(0), x.stride(1), y.stride(0), y.stride(1),
+                                                  int(gelu), int(split_phases), stream()),
+          "sat_layernorm_channels_planes_f32")
+    return y, ys
 
 
 def attention_scores(q, k, st, B, heads, hd, T):

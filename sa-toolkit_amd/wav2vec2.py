@@ -211,31 +211,39 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         B, n = wav.shape
         heads, hd = 16, 64
         # conv feature extractor
+        planes = mm == _lib.CONV_F16X3        # split-f16: LayerNorm hands its result on as split planes (16-byte staging)
         x = ops.w2v2_conv0(wav, W["fe"][0]["w"], W["fe"][0]["b"])                   # [B, 512, T0]
         for i in range(7):
             e = W["fe"][i]
             last = i == 6
             # LayerNorm over channels + GELU; for a following stride-2 conv the output is phase-split
-            x = ops.layernorm_ch(x, e["g"], e["beta"], gelu=True, split_phases=not last)
+            if planes and not last:
+                x, xs = ops.layernorm_ch(x, e["g"], e["beta"], gelu=True, split_phases=True, planes=True, want_f32=False)
+            else:
+                x, xs = ops.layernorm_ch(x, e["g"], e["beta"], gelu=True, split_phases=not last), None
             if not last:
                 nxt = W["fe"][i + 1]
-                x = ops.conv1d(x, nxt["w"], 512, nxt["k"], bias=nxt["b"], pad_left=0, pad_right=0, t_out=self._fe_len[i + 1], mode=mm)
+                x = ops.conv1d(x, nxt["w"], 512, nxt["k"], bias=nxt["b"], pad_left=0, pad_right=0, t_out=self._fe_len[i + 1], mode=mm,
+                               x_split=xs)
         T = x.shape[2]
         # feature projection
-        x = ops.layernorm_ch(x, W["fp"]["g"], W["fp"]["beta"])
-        x = ops.conv1d(x, W["fp"]["w"], 1024, 1, bias=W["fp"]["b"], mode=mm)
+        if planes:
+            x, xs = ops.layernorm_ch(x, W["fp"]["g"], W["fp"]["beta"], planes=True, want_f32=False)
+        else:
+            x, xs = ops.layernorm_ch(x, W["fp"]["g"], W["fp"]["beta"]), None
+        x = ops.conv1d(x, W["fp"]["w"], 1024, 1, bias=W["fp"]["b"], mode=mm, x_split=xs)
         # positional conv (grouped, k = 128, pad 64, last sample dropped) + GELU, added to x
         x = ops.conv1d(x, W["pos"]["w"], 1024, 128, bias=W["pos"]["b"], pad_left=64, pad_right=63, groups=16,
                        gelu=True, post_res=x)
         x = ops.layernorm_ch(x, W["ln"]["g"], W["ln"]["beta"])
         G = B * heads
         tp = ((T + 63) // 64) * 64   # row pitch of the per-head tensors = the packed-weight co_pad for T rows
-        planes = mm == _lib.CONV_F16X3        # Linear layers read their input as split planes (16-byte staging,
-        #                                        two 16-channel sub-chunks per pipeline stage): 182 -> ~60 us per layer
+        # Linear layers read their input as split planes (16-byte staging, two 16-channel sub-chunks per pipeline
+        # stage): 182 -> ~60 us per layer
         sp = (lambda t: ops.act_split(t, 1.0)) if planes else (lambda t: None)
+        ln = (lambda t, p: ops.layernorm_ch(t, *p, planes=True, want_f32=False)) if planes else (lambda t, p: (ops.layernorm_ch(t, *p), None))
         for L in W["layers"]:
-            h = ops.layernorm_ch(x, *L["ln1"])
-            hs = sp(h)
+            h, hs = ln(x, L["ln1"])
             q = torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device)
             k = torch.empty_like(q)
             v = torch.empty_like(q)
@@ -249,10 +257,10 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             vt = ops.transpose_heads(v, B, heads, hd, T)                           # [G][jpad][64]
             o = ops.attention_apply(st, vt, B, heads, hd, T)                        # [B, 1024, T]
             x = ops.conv1d(o, L["o_w"], 1024, 1, bias=L["o_b"], res=x, mode=mm, x_split=sp(o))
-            h = ops.layernorm_ch(x, *L["ln2"])
+            h, hs = ln(x, L["ln2"])
             if planes:
                 fs = ops.split_like(B, 4096, T, x.device)
-                f = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True, mode=mm, x_split=sp(h), y_split=fs,
+                f = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True, mode=mm, x_split=hs, y_split=fs,
                                y_split_slope=1.0, no_y=True)                        # f: shape carrier only
                 x = ops.conv1d(f, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm, x_split=fs)
             else:

@@ -130,3 +130,25 @@ def test_convert_w2v2_tag_matches_fixture(model, gold):
     err = rms(y.cpu().numpy() - fx["harm0_16000/convert"])
     print("wav2vec2-tag convert RMS error vs reference run:", err)
     assert err < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,T,split", [(512, 999, True), (512, 1000, True), (1024, 249, False), (512, 249, False)])
+def test_layernorm_planes_equal_split_of_f32_output(C, T, split):
+    """sat_layernorm_channels_planes_f32: the f32 output equals the plain entry point's, and the planes are the
+    split (hi | lo f16, act_split with slope 1) of exactly those values, odd-length zero slot included"""
+    from satools_amd import ops
+    g = torch.Generator().manual_seed(C + T)
+    x = (torch.randn(2, C, T, generator=g) * 3 + 0.5).cuda()
+    gamma, beta = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    y0 = ops.layernorm_ch(x, gamma, beta, gelu=split, split_phases=split)
+    y1, ys = ops.layernorm_ch(x, gamma, beta, gelu=split, split_phases=split, planes=True)
+    assert torch.equal(y0, y1)
+    assert torch.equal(ys, ops.act_split(y0, 1.0))
+    _, ys2 = ops.layernorm_ch(x, gamma, beta, gelu=split, split_phases=split, planes=True, want_f32=False)
+    assert torch.equal(ys, ys2)
+    ref = torch.nn.functional.layer_norm(x.cpu().permute(0, 2, 1), (C,), gamma.cpu(), beta.cpu(), 1e-5).permute(0, 2, 1)
+    if split:
+        ref = torch.nn.functional.gelu(ref)
+        ref = torch.cat([ref[:, :, 0::2], torch.nn.functional.pad(ref[:, :, 1::2], (0, ref[:, :, 0::2].shape[2] - ref[:, :, 1::2].shape[2]))], 1)
+    assert (y0.cpu() - ref).abs().max() < 2e-5
