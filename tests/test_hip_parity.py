@@ -588,3 +588,39 @@ def test_asr_forward_matches_reference(fbank_tag_state, name, ids, n, precision)
         assert got.shape[:2] == want.shape[:2]
         assert rms(got.cpu().numpy()[..., ::8] - want) <= 1e-4 * max(1.0, rms(want)), key
     assert np.allclose(torch.logsumexp(xent, dim=2).cpu().numpy(), fx[f"{name}/xent_lse"], atol=1e-4)
+
+
+# ---- BASELINE.json's full size (configs[1]: 32 utterances x 5 s) through size-independent properties ----------
+def test_full_size_batch_properties(model, fbank_tag_state):
+    """32 x 5 s: (1) the generator treats utterances independently — any slice of the batch gives the same bits as
+    the full batch; (2) so does YAAPT; (3) one utterance of the full batch against the CPU oracle's generator
+    (teacher-forced on the HIP path's own generator input), 1e-4 RMS bar; (4) shape, range, determinism."""
+    from oracle import convert as oconv
+    from oracle import hifigan as ohg
+    from satools_amd import ops, synthetic
+    seeds = list(range(32))
+    wav = synthetic.harm_batch(seeds).to(DEV)
+    targets = synthetic.targets(model.spk, seeds)
+    y = model.convert(wav, target=targets)
+    assert y.shape == (32, 1, 80001) and bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 1.0
+    assert torch.equal(y, model.convert(wav, target=targets))
+    # generator input of the whole batch, as convert() builds it
+    f0 = model.get_f0(wav)
+    assert f0.shape == (32, 250)
+    for i in (0, 13, 31):
+        assert torch.equal(model.get_f0(wav[i:i + 1])[0], f0[i])
+    bn = model.get_bn(wav)
+    spk = model.get_spk_id(wav, targets).to(DEV, torch.float32).contiguous()
+    f0n = f0.to(DEV).clone()
+    ops.f0_norm_transform_(f0n)
+    x = ops.assemble_input(bn, f0n, spk, spk.shape[1])
+    assert x.shape == (32, 504, 250)
+    full = model.hifigan(x)[0].clone()
+    assert torch.equal(full.reshape(y.shape), y)
+    for sl in (slice(0, 1), slice(5, 9), slice(29, 32)):
+        assert torch.equal(model.hifigan(x[sl].contiguous())[0], full[sl])
+    _, gen_sd = oconv.split_state_dict(fbank_tag_state[0]["base_model_state_dict"])
+    ref = ohg.generator(gen_sd, x[17:18].cpu())
+    err = rms((full[17:18].cpu() - ref).numpy())
+    print("full-size batch, utterance 17 vs oracle generator: rms", err)
+    assert err < 1e-5
