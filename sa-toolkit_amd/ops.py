@@ -214,6 +214,17 @@ def attention_apply(st, vt, B, heads, hd, T):
     return o
 
 
+def attention_fused(qs, ks, v, B, heads, hd, T, scale, want_f32=False):
+    """fused self-attention on split planes of Q and K and f32 V [B, heads*hd, pitch >= T]: returns (o f32
+    [B, heads*hd, T] — unwritten shape carrier unless want_f32 — , o as split planes)"""
+    assert v.is_contiguous() and v.shape[1] == heads * hd
+    o = torch.empty(B, heads * hd, T, dtype=torch.float32, device=v.device)
+    os_ = split_like(B, heads * hd, T, v.device)
+    check(lib().sat_attention_f16x3(ptr(qs), ptr(ks), ptr(v), ptr(o) if want_f32 else None, ptr(os_), B, heads, hd, T,
+                                    v.shape[2], float(scale), stream()), "sat_attention_f16x3")
+    return o, os_
+
+
 def act_split(x, slope=1.0, out=None, fmt=0):
     """f32 [B][C][T] -> split planes S[b][c/16][hi|lo][(c/8)&1][t][c%8] f16 of lrelu(x, slope)
     (include/satools_hip.h, fmt = SPLIT_F16); fmt = SPLIT_F8 keeps the hi planes and stores e4m3(hi) and
