@@ -138,6 +138,9 @@ int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packe
 int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
                             const float* bias1, const void* w2_packed, float* y, void* stream);
 /* f32 [B][C][T] -> split planes of lrelu(x, slope) in `format` (SAT_SPLIT_*); C % 16 == 0 */
+/* process-wide switches of the conv dispatch (A/B measurements): "k1_gemm" (default 1) sends 1x1 convs on split
+ * planes with >= 128 output rows to the GEMM kernel (activation fragments straight from the planes). */
+int sat_conv_set_option(const char* name, int value);
 int sat_act_split_f32(const float* x, void* x_split, int B, int C, int T, float slope, int format, void* stream);
 /* cin_pad / co_pad the packed layout must use for this shape (host-side helper, no GPU needed) */
 int sat_conv1d_packed_dims(int C_in, int C_out, int up, int groups, int* cin_pad, int* co_pad);

@@ -13,6 +13,7 @@
 // Replaces (reference): torch Conv1d/ConvTranspose1d calls of hifigan/archi.py:77-91 and
 // hifigan/nn.py:179-186; unfold+matmul/addmm of chain/nn.py:267-292 + BatchNorm/ReLU :338-347.
 #include "common.h"
+#include <cstring>
 
 namespace sat {
 
@@ -39,6 +40,7 @@ __device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float
 
 constexpr int CI_CHUNK = 16;  // input channels staged per K-chunk (8 MFMA k-pairs)
 
+static int g_k1_gemm = 1;    // sat_conv_set_option("k1_gemm", 0/1): 1x1 convs on split planes through conv1d_f16x3_k1_kernel
 struct ConvArgs {
   const float* x;
   const float* w;   // exact-f32 packing, or (split-f16 mode) the f16 hi|lo packing reinterpreted
@@ -1030,6 +1032,131 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
   return SAT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution on split planes = a GEMM (TDNNF linearA/B, wav2vec2 Linear layers, ASR output affines).  With
+// one tap nothing is shared between columns, so the B operand (activations) never goes through LDS: a lane loads
+// its own two 16-byte fragments per 16-channel chunk straight from the planes (coalesced, 512 B per half wave).
+// Only the weight tile is shared (4 waves side by side in time): 128 rows x 64 channels per stage, double-buffered
+// in LDS (2 x 32 KB), ONE barrier per stage; the next stage's fragments and weights fly in registers during this
+// stage's 48 MFMAs per wave.  Block tile = 128 rows x 128 positions (wave: 128 x 32, 64 accumulator registers):
+// half the activation traffic per MFMA of the 64-row conv tile.  Blocks are numbered so that the co tiles of one
+// (utterance, time tile) land on the same XCD and share the activations through its L2.
+// ------------------------------------------------------------------------------------------------
+template <int SC>
+__global__ void __launch_bounds__(256, 2) conv1d_f16x3_k1_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  constexpr int CO_B = 128, T_B = 128, MT = 4;
+  constexpr int WST = SC * 4 * CO_B;        // 16-byte units of one stage's weight tile: [chunk][part*2 + half][row]
+  constexpr int W_IT = WST / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  // block -> (co tile, time tile, utterance): id = xcd + 8 * (co + n_co * (g >> 3)), g = 8 * (g >> 3) + xcd
+  const int n_co = p.co_tiles_g, n_tt = p.pp_tiles_t;
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int co_t = __builtin_amdgcn_readfirstlane(rest % n_co);
+  const int g = __builtin_amdgcn_readfirstlane((rest / n_co) * 8 + xcd);
+  if (g >= p.pp_total) return;
+  const int b = __builtin_amdgcn_readfirstlane(g / n_tt);     // (division runs on the vector ALU: keep the results scalar)
+  const int co_w = co_t * CO_B;
+  const int q_w = (g - b * n_tt) * T_B + wave * 32;
+  const int nst = p.cin_pad / CI_CHUNK / SC;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.x16 + (long long)b * p.cin_g * p.T_in * 4), 0, (unsigned)(p.cin_g * p.T_in * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
+  const int seg_bytes = p.co_pad * 16;
+  const int x_chunk_bytes = 4 * p.T_in * 16;
+  const int xi = q_w + l31 - p.pad_left;
+  const bool xok = xi >= 0 && xi < p.T_in;
+  const unsigned xo_hi = xok ? (unsigned)(((0 + lh) * p.T_in + xi) * 16) : 0x80000000u;
+  const unsigned xo_lo = xok ? (unsigned)(((2 + lh) * p.T_in + xi) * 16) : 0x80000000u;
+
+  f32x16 acc[MT][1];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
+
+  uint4 wst[W_IT], bst[SC][2], bcur[SC][2];
+  auto issue = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      // unit u = tid + 256 i of the stage tile [chunk][seg][128 rows]: chunk = i / 2 for every thread (a scalar offset)
+      const int cl = i >> 1, seg = (tid >> 7) + 2 * (i & 1), r = tid & 127;
+      wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (co_w + r) * 16 + seg * seg_bytes,
+                                                                                (st * SC + cl) * 4 * seg_bytes, 0));
+    }
+#pragma unroll
+    for (int cl = 0; cl < SC; ++cl) {
+      bst[cl][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo_hi, (st * SC + cl) * x_chunk_bytes, 0));
+      bst[cl][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo_lo, (st * SC + cl) * x_chunk_bytes, 0));
+    }
+  };
+  issue(0);
+  for (int st = 0; st < nst; ++st) {
+    uint4* wl = lds4 + (st & 1) * WST;
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) wl[tid + 256 * i] = wst[i];
+#pragma unroll
+    for (int cl = 0; cl < SC; ++cl) {
+      bcur[cl][0] = bst[cl][0];
+      bcur[cl][1] = bst[cl][1];
+    }
+    __syncthreads();       // this stage's weights are visible; every wave has left the stage before, whose buffer the next one overwrites
+    if (st + 1 < nst) issue(st + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4* wb = wl + lh * CO_B + l31;
+    // A fragments of chunk cl + 1 are read from LDS ahead of chunk cl's MFMAs (double-buffered registers): no
+    // MFMA waits on a read issued just before it
+    h8 af[2][MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      af[0][m][0] = __builtin_bit_cast(h8, wb[(0 * 4 + 0) * CO_B + m * 32]);
+      af[0][m][1] = __builtin_bit_cast(h8, wb[(0 * 4 + 2) * CO_B + m * 32]);
+    }
+#pragma unroll
+    for (int cl = 0; cl < SC; ++cl) {
+      const h8 b_hi = __builtin_bit_cast(h8, bcur[cl][0]);
+      const h8 b_lo = __builtin_bit_cast(h8, bcur[cl][1]);
+      if (cl + 1 < SC) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          af[(cl + 1) & 1][m][0] = __builtin_bit_cast(h8, wb[((cl + 1) * 4 + 0) * CO_B + m * 32]);
+          af[(cl + 1) & 1][m][1] = __builtin_bit_cast(h8, wb[((cl + 1) * 4 + 2) * CO_B + m * 32]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // the scheduler would sink those reads to their first use
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cl & 1][m][1], b_hi, acc[m][0], 0, 0, 0);
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cl & 1][m][0], b_lo, acc[m][0], 0, 0, 0);
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cl & 1][m][0], b_hi, acc[m][0], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  conv_epilogue<MT, 1>(p, acc, b, 0, co_w, q_w, l31, lh);
+}
+
+static int launch_f16x3_k1(const ConvArgs& a, int B, hipStream_t s) {
+  constexpr int SC = 4;
+  ConvArgs p = a;
+  p.xw = 128;
+  p.co_tiles_g = ceil_div(p.rows_g, 128);
+  p.pp_tiles_t = ceil_div(p.T_q, 128);
+  p.pp_total = p.pp_tiles_t * B;
+  const size_t lds_bytes = (size_t)2 * SC * 4 * 128 * 16;
+  auto kern = conv1d_f16x3_k1_kernel<SC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  dim3 grid(8 * p.co_tiles_g * ceil_div(p.pp_total, 8), 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
+  SAT_LAUNCH_CHECK("conv1d_f16x3_k1_kernel");
+  return SAT_OK;
+}
+
 template <int MT, int NT>
 static int launch_f16x3_ks(const ConvArgs& a, int B, int groups, hipStream_t s) {
   switch (a.ksize) {
@@ -1311,7 +1438,7 @@ __global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(
 
   uint4 xst[XWI];
   auto issue_x = [&](int tl) {
-    const int ub = tl / p.pp_tiles_t;
+    const int ub = __builtin_amdgcn_readfirstlane(tl / p.pp_tiles_t);
     const int xi_0 = (tl - ub * p.pp_tiles_t) * FP_TO - FP_OFF - p.pad_left;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)p.x16 + (long long)ub * 16 * p.T_in * 4), 0, (unsigned)(16 * p.T_in * 4), 0x00020000);
@@ -1343,7 +1470,7 @@ __global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(
     bias2[k] = p.bias[4 * g + k];
   }
   for (;;) {
-  const int b = tile / p.pp_tiles_t;
+  const int b = __builtin_amdgcn_readfirstlane(tile / p.pp_tiles_t);     // (division runs on the vector ALU: keep it scalar)
   const int t0 = (tile - b * p.pp_tiles_t) * FP_TO;
   __syncthreads();            // the previous step's readers of the input tile and of t1 are done
 #pragma unroll
@@ -1870,6 +1997,10 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
       SAT_REQUIRE(!(d->no_y && d->accum), "conv1d: no_y with accum");
     }
     a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;   // bytes per group
+    // 1x1 on split planes with enough rows: the GEMM kernel (activation fragments straight from the planes)
+    if (a.x16 && a.ksize == 1 && !a.f8 && !a.poly_planes && a.fast_epi && d->groups == 1 && a.rows_g >= 128 &&
+        (a.cin_pad / CI_CHUNK) % 4 == 0 && g_k1_gemm)
+      return launch_f16x3_k1(a, d->B, s);
     if (a.rows_g > 32) return launch_f16x3_ks<2, 2>(a, d->B, d->groups, s);   // 64 rows x 256 positions
     return launch_f16x3_ks<1, 4>(a, d->B, d->groups, s);                       // 32 rows x 512 positions
   }
@@ -1964,4 +2095,11 @@ extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, in
   hipLaunchKernelGGL(act_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (uint4*)x_split, C, T, slope, format == SAT_SPLIT_F8);
   SAT_LAUNCH_CHECK("act_split_kernel");
   return SAT_OK;
+}
+
+extern "C" int sat_conv_set_option(const char* name, int value) {
+  SAT_REQUIRE(name, "conv_set_option: null name");
+  if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value != 0; return SAT_OK; }
+  set_error("conv_set_option: unknown option '%s'", name);
+  return SAT_ERR_INVALID;
 }
