@@ -869,6 +869,41 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvA
   const int sc_a = lh ? F8_E_WHI : F8_E_WLO;
   const int sc_b = lh ? F8_E_XLO : F8_E_XHI;
   auto mfma_phase = [&]() {
+   if constexpr (!F8) {
+    // fragments of tap idx + 1 are read from LDS ahead of tap idx's MFMAs (double-buffered registers; the
+    // scheduler would otherwise sink the reads to their first use and every tap would start on an LDS round trip)
+    h8 fa[2][MT][2], fb[2][NT][2];
+    auto ld = [&](int buf, int sc, int t) {
+      const uint4* wb = wb0 + sc * W_UNITS;
+      const uint4* xt = xb0 + sc * 4 * XWP + t * p.dil;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        fa[buf][m][0] = __builtin_bit_cast(h8, wb[(t * 4 + 0) * CO_B + m * 32]);
+        fa[buf][m][1] = __builtin_bit_cast(h8, wb[(t * 4 + 2) * CO_B + m * 32]);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        fb[buf][n][0] = __builtin_bit_cast(h8, xt[n * 32]);
+        fb[buf][n][1] = __builtin_bit_cast(h8, xt[2 * XWP + n * 32]);
+      }
+    };
+    ld(0, 0, 0);
+#pragma unroll
+    for (int idx = 0; idx < S * KS; ++idx) {
+      if (idx + 1 < S * KS) ld((idx + 1) & 1, (idx + 1) / KS, (idx + 1) % KS);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[idx & 1][m][1], fb[idx & 1][n][0], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[idx & 1][m][0], fb[idx & 1][n][1], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[idx & 1][m][0], fb[idx & 1][n][0], acc[m][n], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+   }
 #pragma unroll
    for (int sc = 0; sc < S; ++sc) {
     const uint4* xb = xb0 + sc * 4 * XWP;
