@@ -13,6 +13,7 @@ L2-normalised 192-dim embedding — computed on the HIP kernels:
 The parameter tree carries the reference's state-dict keys (torchaudio's `MelSpec.spectrogram.window` /
 `mel_scale.fb` buffers included), so a reference checkpoint loads with `load_state_dict`.  No CPU fallback."""
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -110,6 +111,9 @@ def build(args=None):
     """same contract as the reference's model-config `build(args)`: returns the Net class"""
 
     class Net(nn.Module):
+        #: arithmetic of the wide 1x1 convs: "f16x3" (split-f16 on the f16 matrix cores) or "f32" (exact f32 MFMA)
+        precision = os.environ.get("SATOOLS_AMD_XVECTOR_PRECISION", "f16x3")
+
         def __init__(self, num_speakers=1):
             super().__init__()
             self.preprocessor = _MelSpecFrontEnd()
@@ -129,10 +133,15 @@ def build(args=None):
 
         # ---- kernel-ready weights ----------------------------------------------------------------
         def _prepare(self, device):
-            key = tuple((p.data_ptr(), p._version, str(p.device)) for p in list(self.parameters()) + list(self.buffers()))
+            key = (self.precision,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in list(self.parameters()) + list(self.buffers()))
             if self._cache_key == key:
                 return self._cache
             f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+            # the wide 1x1 convs (block in / out, the 1536 -> 1536 conv before pooling, the attention MLP) run as
+            # split-f16 products on the f16 matrix cores (~2^-21 per product) unless precision is "f32"
+            split = self.precision == "f16x3"
+            pack1 = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight
+            m1 = _lib.CONV_F16X3 if split else _lib.CONV_F32
 
             def bn_affine(bn):
                 s = f32(bn.weight) / torch.sqrt(f32(bn.running_var) + bn.eps)
@@ -140,8 +149,10 @@ def build(args=None):
 
             def crb(m):
                 sc, sh = bn_affine(m.bn)
-                return {"w": packing.pack_conv_weight(f32(m.conv.weight)), "k": m.conv.weight.shape[2], "scale": sc, "shift": sh,
-                        "cout": m.conv.weight.shape[0]}
+                k = m.conv.weight.shape[2]
+                wide = k == 1 and m.conv.weight.shape[1] % 16 == 0
+                return {"w": (pack1 if wide else packing.pack_conv_weight)(f32(m.conv.weight)), "k": k, "scale": sc, "shift": sh,
+                        "cout": m.conv.weight.shape[0], "mode": m1 if wide else _lib.CONV_F32}
 
             W = {"layer1": crb(self.sequence_network.layer1), "blocks": []}
             for lay in (self.sequence_network.layer2, self.sequence_network.layer3, self.sequence_network.layer4):
@@ -154,10 +165,11 @@ def build(args=None):
                     "se1_w": packing.pack_conv_weight(f32(lay[3].linear1.weight).unsqueeze(-1)), "se1_b": f32(lay[3].linear1.bias),
                     "se2_w": packing.pack_conv_weight(f32(lay[3].linear2.weight).unsqueeze(-1)), "se2_b": f32(lay[3].linear2.bias)})
             sn = self.sequence_network
-            W["cat"] = {"w": packing.pack_conv_weight(f32(sn.conv.weight)), "b": f32(sn.conv.bias)}
+            W["cat"] = {"w": pack1(f32(sn.conv.weight)), "b": f32(sn.conv.bias)}
+            W["mode1"] = m1
             sp = self.stat_pooling
-            W["asp1"] = {"w": packing.pack_conv_weight(f32(sp.linear1.weight)), "b": f32(sp.linear1.bias)}
-            W["asp2"] = {"w": packing.pack_conv_weight(f32(sp.linear2.weight)), "b": f32(sp.linear2.bias)}
+            W["asp1"] = {"w": pack1(f32(sp.linear1.weight)), "b": f32(sp.linear1.bias)}
+            W["asp2"] = {"w": pack1(f32(sp.linear2.weight)), "b": f32(sp.linear2.bias)}
             sc, sh = bn_affine(self.before_speaker_embedding.bn2)
             W["emb"] = {"w": packing.pack_conv_weight(f32(self.before_speaker_embedding.lin.weight).unsqueeze(-1)), "scale": sc, "shift": sh}
             W["window"] = f32(self.preprocessor.MelSpec.spectrogram.window)
@@ -174,7 +186,7 @@ def build(args=None):
 
         def _crb(self, x, e, pad=0, dil=1, out=None):
             return ops.conv1d(x, e["w"], e["cout"], e["k"], pad_left=pad, dilation=dil, ch_scale=e["scale"], ch_shift=e["shift"],
-                              relu=True, relu_first=True, out=out)
+                              relu=True, relu_first=True, out=out, mode=e["mode"])
 
         def _block(self, x, blk, dil, skips, out):
             """SE_Res2Block (sidekit/nn.py:142-154) + the skip connections of PreEcapaTDNN.forward; writes `out`"""
@@ -203,9 +215,9 @@ def build(args=None):
             out2 = self._block(out1, W["blocks"][0], 2, [out1], cat[:, :C])
             out3 = self._block(ops.add3(out1, out2), W["blocks"][1], 3, [out1, out2], cat[:, C:2 * C])
             self._block(ops.add3(out1, out2, out3), W["blocks"][2], 4, [out1, out2, out3], cat[:, 2 * C:])
-            h = ops.conv1d(cat, W["cat"]["w"], 3 * C, 1, bias=W["cat"]["b"], relu=True)
-            a = ops.tanh_(ops.conv1d(h, W["asp1"]["w"], 128, 1, bias=W["asp1"]["b"]))
-            logits = ops.conv1d(a, W["asp2"]["w"], 3 * C, 1, bias=W["asp2"]["b"])
+            h = ops.conv1d(cat, W["cat"]["w"], 3 * C, 1, bias=W["cat"]["b"], relu=True, mode=W["mode1"])
+            a = ops.tanh_(ops.conv1d(h, W["asp1"]["w"], 128, 1, bias=W["asp1"]["b"], mode=W["mode1"]))
+            logits = ops.conv1d(a, W["asp2"]["w"], 3 * C, 1, bias=W["asp2"]["b"], mode=W["mode1"])
             pooled = ops.attentive_stats(h, logits)                                 # [B, 2 * 3C, 1]
             e = ops.conv1d(pooled, W["emb"]["w"], self.embedding_size, 1, ch_scale=W["emb"]["scale"], ch_shift=W["emb"]["shift"])
             return ops.l2norm_rows(e.reshape(B, self.embedding_size))
