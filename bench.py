@@ -208,12 +208,12 @@ def main():
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
         hbm = GEN_BYTES_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_generator_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01o_generator_traffic.json")
         if os.path.exists(tpath) and tag == TAG:
             tj = json.load(open(tpath))["per_forward"]
             traffic = tj["traffic_GB_raw"] * 1e9
             traffic_note = (f"HBM bytes per generator forward (batch 32) from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                            f"passes (profiles/r01_generator_traffic.json): fetch {tj['fetch_GB_raw']} GB as counted "
+                            f"passes (profiles/r01o_generator_traffic.json): fetch {tj['fetch_GB_raw']} GB as counted "
                             f"({tj['fetch_GB_doubled']} GB with the gfx950 wide-load x2 correction as upper bound) + write "
                             f"{tj['write_GB']} GB; per-layer streaming model {tj['algorithmic_GB_per_layer_model']} GB")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
