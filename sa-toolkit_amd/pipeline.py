@@ -231,15 +231,20 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
                      torch.cuda.Stream(device=device) if use_streams else None) for w in wavscps]
 
     nj = max(1, min(int(settings.data_loader_nj), 18))
-    readers = ThreadPoolExecutor(max_workers=nj)
+    # the reference's DataLoader workers (pipeline.py:175): `nj` threads decode files (file IO and the numpy
+    # conversions release the GIL), one thread per job assembles its batches, two batches ahead of the GPU
+    file_pool = ThreadPoolExecutor(max_workers=nj)
+    readers = ThreadPoolExecutor(max_workers=max(1, len(wavscps)))
     writers = ThreadPoolExecutor(max_workers=4)
+    depth = 2
+
+    def read_one(item):
+        utid, entry = item
+        audio, freq = load_wav_from_scp(str(entry))
+        return {"utid": utid, "audio": audio, "f0": None, "freq": freq}
 
     def read_batch(chunk):
-        items = []
-        for utid, entry in chunk:
-            audio, freq = load_wav_from_scp(str(entry))
-            items.append({"utid": utid, "audio": audio, "f0": None, "freq": freq})
-        return collate_fn(items)
+        return collate_fn(list(file_pool.map(read_one, chunk)))
 
     def write_batch(wav_conv, done_event, utid, freq, original_len):
         if done_event is not None:
@@ -254,15 +259,27 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
     scp_lines = [[] for _ in shards]
     # round-robin over the jobs of this device: one batch of each in flight, each on its own stream; the next
     # batches are being read meanwhile
-    prefetch = [readers.submit(read_batch, c) if (c := s.next_keys()) else None for s in shards]
+    prefetch = [[] for _ in shards]
+
+    def top_up(si):
+        while len(prefetch[si]) < depth and (c := shards[si].next_keys()):
+            prefetch[si].append(readers.submit(read_batch, c))
+
+    for si in range(len(shards)):
+        top_up(si)
+    timing = os.environ.get("SATOOLS_AMD_PIPELINE_TIMING") == "1"     # diagnostic: where the launching thread waits
+    import time as _time
+    t_wait_read = t_wait_slot = t_launch = 0.0
     with torch.no_grad():
-        while any(p is not None for p in prefetch):
+        while any(prefetch):
             for si, sh in enumerate(shards):
-                if prefetch[si] is None:
+                if not prefetch[si]:
                     continue
-                audio, _f0, original_len, utid, freq = prefetch[si].result()
-                nxt = sh.next_keys()
-                prefetch[si] = readers.submit(read_batch, nxt) if nxt else None
+                _t0 = _time.perf_counter()
+                audio, _f0, original_len, utid, freq = prefetch[si].pop(0).result()
+                t_wait_read += _time.perf_counter() - _t0
+                top_up(si)
+                _t1 = _time.perf_counter()
                 targets = sh.selector(utid)
                 kw = {"target": targets} if len(targets) != 0 else {}
                 ctx = torch.cuda.stream(sh.stream) if sh.stream is not None else _null()
@@ -274,7 +291,9 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
                         slot = sh.ring[sh.ring_pos % len(sh.ring)]
                         sh.ring_pos += 1
                         if slot["busy"] is not None:
+                            _t2 = _time.perf_counter()
                             slot["busy"].result()
+                            t_wait_slot += _time.perf_counter() - _t2
                         if slot["in"] is None or slot["in"].numel() < audio.numel():
                             slot["in"] = torch.empty(audio.numel(), dtype=torch.float32, pin_memory=True)
                         pin = slot["in"][:audio.numel()].view(audio.shape)
@@ -311,6 +330,7 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
                         ev.record(sh.stream)
                     else:
                         host, ev = wav_conv.cpu(), None
+                t_launch += _time.perf_counter() - _t1
                 fut = writers.submit(write_batch, host, ev, utid, freq[0], original_len)
                 if slot is not None:
                     slot["busy"] = fut
@@ -323,7 +343,11 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
                         progress.value += len(utid)
     for w in pending_writes:
         w.result()
+    if timing:
+        print(f"[pipeline timing] launching thread: waited {t_wait_read:.3f} s for readers, {t_wait_slot:.3f} s for a free "
+              f"staging slot (writers / GPU), {t_launch - t_wait_slot:.3f} s in staging + launches, {n_done} utterances", flush=True)
     readers.shutdown()
+    file_pool.shutdown()
     writers.shutdown()
     # like the reference, each job (re)writes wav.scp of the output dir with ITS utterances; with several jobs
     # per process the lines are concatenated in job order
