@@ -77,7 +77,16 @@ class _TdnnfBase(nn.Module):
         return [self.tdnn1] + [m for m in self.tdnnfs if isinstance(m, TDNNFBatchNormParams)]
 
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in list(self.parameters()) + list(self.buffers()))
+        # the module tree is fixed after construction: walk it once, then only look at the tensors (this runs on
+        # every call).  `.to()` and `load_state_dict` keep the Parameter objects and show up in data_ptr / _version;
+        # `.to()` REPLACES buffer tensors, so buffers are looked up through their owning module every time
+        flat = self.__dict__.get("_flat_params")
+        if flat is None:
+            flat = self.__dict__["_flat_params"] = (list(self.parameters()),
+                                                    [(m, n) for m in self.modules() for n in m._buffers])
+        ps, bufs = flat
+        return tuple((p.data_ptr(), p._version) for p in ps) + tuple(
+            (t.data_ptr(), t._version) for t in (m._buffers[n] for m, n in bufs) if t is not None)
 
     def _layer_cache(self, lay, device, split):
         pack = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight

@@ -34,7 +34,12 @@ class CoreHifiGan(CoreHifiGanParams):
 
     # -- device-side weight cache ---------------------------------------------------------
     def _param_key(self):
-        return (self.precision, self.split_acts, self.branch_streams) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        # the module tree is fixed after construction: walk it once, then only look at the tensors (this runs on
+        # every forward; `.to()` and `load_state_dict` keep the Parameter objects and show up in data_ptr / _version)
+        ps = self.__dict__.get("_flat_params")
+        if ps is None:
+            ps = self.__dict__["_flat_params"] = list(self.parameters())
+        return (self.precision, self.split_acts, self.branch_streams) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def invalidate(self):
         self._packed_key = None

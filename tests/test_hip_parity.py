@@ -624,3 +624,29 @@ def test_full_size_batch_properties(model, fbank_tag_state):
     err = rms((full[17:18].cpu() - ref).numpy())
     print("full-size batch, utterance 17 vs oracle generator: rms", err)
     assert err < 1e-5
+
+
+def test_weight_caches_follow_in_place_updates():
+    """the packed-weight caches are keyed on (data_ptr, _version) of parameters and buffers looked up through a
+    module walk done once: an in-place update of a parameter or of a BatchNorm buffer (which `.to()` had replaced
+    by a new tensor object) must still invalidate them"""
+    from satools_amd import synthetic
+    m = _model()
+    wav = synthetic.harm_batch([0], 16000).to(DEV)
+    bn0 = m.get_bn(wav).clone()
+    bx = m.bn_extractor
+    with torch.no_grad():
+        saved = bx.tdnn1.bn.running_mean.clone()
+        bx.tdnn1.bn.running_mean.add_(0.25)
+    bn1 = m.get_bn(wav).clone()
+    assert not torch.equal(bn0, bn1)
+    with torch.no_grad():
+        bx.tdnn1.bn.running_mean.copy_(saved)
+        assert torch.equal(m.get_bn(wav), bn0)
+        x = torch.randn(1, m.hifigan.imput_dim, 50, device=DEV)
+        y0 = m.hifigan(x)[0].clone()
+        p = next(m.hifigan.parameters())
+        p.mul_(1.5)
+        y1 = m.hifigan(x)[0].clone()
+        p.div_(1.5)
+    assert not torch.equal(y0, y1)
