@@ -185,6 +185,15 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         wv, wg = f32(pc.weight_v), f32(pc.weight_g)
         wpos = torch._weight_norm(wv, wg, 2)                                      # weight_norm(dim=2)
         W["pos"] = {"w": packing.pack_conv_weight(wpos, groups=16), "b": f32(pc.bias)}
+        if self._mm_mode == _lib.CONV_F16X3:
+            # split-f16: the 128 taps as twelve 11-tap grouped convs over shifted windows, chained through the
+            # pre-activation residual (the split-f16 kernels are instantiated for 11 taps, not for 128)
+            W["pos"]["pieces"] = []
+            for s_ in range(12):
+                ws = torch.zeros(wpos.shape[0], wpos.shape[1], 11, dtype=torch.float32, device=wpos.device)
+                n_ = min(11, wpos.shape[2] - 11 * s_)
+                ws[:, :, :n_] = wpos[:, :, 11 * s_:11 * s_ + n_]
+                W["pos"]["pieces"].append(packing.pack_conv_weight_f16x3(ws, groups=16))
         W["ln"] = {"g": f32(tr.layer_norm.weight), "beta": f32(tr.layer_norm.bias)}
         W["layers"] = []
         for lay in tr.layers:
@@ -233,8 +242,16 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             x, xs = ops.layernorm_ch(x, W["fp"]["g"], W["fp"]["beta"]), None
         x = ops.conv1d(x, W["fp"]["w"], 1024, 1, bias=W["fp"]["b"], mode=mm, x_split=xs)
         # positional conv (grouped, k = 128, pad 64, last sample dropped) + GELU, added to x
-        x = ops.conv1d(x, W["pos"]["w"], 1024, 128, bias=W["pos"]["b"], pad_left=64, pad_right=63, groups=16,
-                       gelu=True, post_res=x)
+        if "pieces" in W["pos"]:
+            y = None
+            for s_, wsp in enumerate(W["pos"]["pieces"]):
+                pl = 64 - 11 * s_           # taps 11 s .. 11 s + 10 of the 128 (pad 64): a window shifted by 11 s
+                y = ops.conv1d(x, wsp, 1024, 11, bias=W["pos"]["b"] if s_ == 0 else None, pad_left=pl, pad_right=10 - pl,
+                               groups=16, mode=mm, res=y, gelu=(s_ == 11), out=y)
+            x = ops.add3(y, x)
+        else:
+            x = ops.conv1d(x, W["pos"]["w"], 1024, 128, bias=W["pos"]["b"], pad_left=64, pad_right=63, groups=16,
+                           gelu=True, post_res=x)
         x = ops.layernorm_ch(x, W["ln"]["g"], W["ln"]["beta"])
         G = B * heads
         tp = ((T + 63) // 64) * 64   # row pitch of the per-head tensors = the packed-weight co_pad for T rows
