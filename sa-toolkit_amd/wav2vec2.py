@@ -11,10 +11,12 @@ Everything runs on the HIP kernels with activations channel-major [B][C][T]:
   * the six stride-2 convs: the LayerNorm+GELU kernel writes its output split into even/odd time phases
     (2C channels, T/2 frames), which turns a stride-2 conv of k taps into a stride-1 conv of ceil(k/2) taps
     on the fused MFMA conv kernel;
-  * every Linear = 1x1 conv on the same kernel (bias / GELU / residual in the epilogue);
-  * attention: S^T = K^T Q and O = V P as GROUPED convs, one group per (utterance, head): a [64][T]
-    head slice of Q / of V^T stored with row pitch 256 is exactly the kernel's packed-weight layout, so no
-    batched-GEMM kernel is needed; softmax over keys is a column kernel in between.
+  * every Linear = 1x1 conv (bias / GELU / residual in the epilogue), in split-f16 through the GEMM kernel, its
+    input handed over as split planes by the LayerNorm / attention / previous Linear that produced it;
+  * attention, split-f16: one fused kernel per layer (Q, K as split planes from their projections, scores and
+    softmax in registers, context out as split planes); f32 mode: S^T = K^T Q and O = V P as GROUPED convs, one
+    group per (utterance, head) — a [64][T] head slice of Q / of V^T stored with row pitch 256 is exactly the
+    exact-f32 kernel's packed-weight layout — with a column softmax kernel in between.
 """
 import os
 
@@ -153,7 +155,8 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
     # ---- kernel-ready weights of the wav2vec2 part -------------------------------------------
     #: arithmetic of the wav2vec2 matrix products (conv feature extractor after layer 0, feature projection,
     #: the 24 x 6 transformer Linear layers): "f16x3" (split-f16 on the f16 matrix cores, ~2^-21 relative per
-    #: product) or "f32" (exact f32 MFMA).  The grouped positional conv and the attention products stay f32.
+    #: product; with it also the fused attention kernel and the positional conv as chained 11-tap pieces) or "f32"
+    #: (exact f32 MFMA everywhere, attention as scores GEMM + softmax + apply GEMM).
     w2v2_precision = os.environ.get("SATOOLS_AMD_W2V2_PRECISION", "f16x3")
 
     def _prepare_w2v2(self, device):
