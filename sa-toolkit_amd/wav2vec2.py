@@ -265,9 +265,9 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         for L in W["layers"]:
             h, hs = ln(x, L["ln1"])
             v = torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device)
-            if planes:
-                # fused attention (csrc/w2v2.hip): Q and K leave their projections as split planes, the scores stay
-                # in registers, the context comes back as planes for the output projection
+            if planes and T <= 256:
+                # fused attention (csrc/w2v2.hip; up to 256 frames = 5.1 s): Q and K leave their projections as split
+                # planes, the scores stay in registers, the context comes back as planes for the output projection
                 qs, ks = ops.split_like(B, 1024, T, x.device), ops.split_like(B, 1024, T, x.device)
                 ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], mode=mm, x_split=hs, y_split=qs, y_split_slope=1.0, no_y=True)
                 ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], mode=mm, x_split=hs, y_split=ks, y_split_slope=1.0, no_y=True)
@@ -277,9 +277,9 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             else:
                 q = torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device)
                 k = torch.empty_like(q)
-                ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], out=q[:, :, :T], mode=mm)
-                ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], out=k[:, :, :T], mode=mm)
-                ops.conv1d(h, L["v_w"], 1024, 1, bias=L["v_b"], out=v[:, :, :T], mode=mm)
+                ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], out=q[:, :, :T], mode=mm, x_split=hs)
+                ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], out=k[:, :, :T], mode=mm, x_split=hs)
+                ops.conv1d(h, L["v_w"], 1024, 1, bias=L["v_b"], out=v[:, :, :T], mode=mm, x_split=hs)
                 # S^T[j][q] = sum_c K[c][j] Q[c][q]  per (utterance, head): K as packed weights, Q as input
                 st = torch.empty(G * T, tp, dtype=torch.float32, device=x.device)
                 ops.attention_scores(q, k, st, B, heads, hd, T)

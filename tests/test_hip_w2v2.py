@@ -176,3 +176,28 @@ def test_fused_attention_matches_float64(T):
     # split-f16 drops the lo*lo term (2^-22 per product): ~5e-7 on a score of std 2, the same on a weight
     assert err < 1e-5 and e_rms < 1e-6
     assert torch.equal(os_, ops.act_split(o, 1.0))
+
+
+def test_long_utterance_takes_the_unfused_attention(model):
+    """more than 256 frames (5.1 s): the split-f16 path falls back from the fused attention kernel to scores GEMM +
+    softmax + apply GEMM; its bottleneck features agree with the all-f32 setting and with the fused kernel's on a
+    5 s input"""
+    from satools_amd import synthetic
+    bx = model.bn_extractor
+    old = bx.w2v2_precision
+    try:
+        out = {}
+        for n in (80000, 100000):                      # 249 and 312 frames
+            wav = synthetic.harm_batch([3, 4], n).to(DEV)
+            for prec in ("f16x3", "f32"):
+                bx.w2v2_precision = prec
+                bn, (z, idx, dist) = bx.extract_bn(wav.clone(), want_aux=True)
+                out[(n, prec)] = (z.clone(), idx.clone())
+            za, ia = out[(n, "f16x3")]
+            zb, ib = out[(n, "f32")]
+            assert za.shape == zb.shape
+            err = (za - zb).abs().max().item()
+            print(f"n={n}: pre-VQ bottleneck, split-f16 vs f32: max abs diff {err:.2e}; indices equal: {(ia == ib).float().mean().item():.4f}")
+            assert err < 2e-3 and (ia == ib).float().mean() > 0.99
+    finally:
+        bx.w2v2_precision = old
