@@ -308,7 +308,7 @@ int sat_softmax_columns_f32(float* st, int G, int T, int pitch, float scale, voi
  * tdnnf_wav2vec2_vq.py:39-56; 16 heads x 64) in split-f16 arithmetic, scores kept in registers:
  *   o[b][h*64 + d][t] = sum_j softmax_j(scale * sum_c q[b][h*64+c][t] k[b][h*64+c][j]) * v[b][h*64+d][j]
  * q_split / k_split: SAT_SPLIT_F16 planes [heads*64 channels][T frames] (the projections' y_split); v: f32
- * [B][heads*64][v_pitch >= T, a multiple of 4]; o (f32 [B][heads*64][T]) and / or o_split (planes), either may be null; T <= 256. */
+ * [B][heads*64][v_pitch >= T, a multiple of 4]; o (f32 [B][heads*64][T]) and / or o_split (planes), either may be null. */
 int sat_attention_f16x3(const void* q_split, const void* k_split, const float* v, float* o, void* o_split, int B,
                         int heads, int head_dim, int T, int v_pitch, float scale, void* stream);
 int sat_transpose_heads_f32(const float* v, float* vt, int G, int D, int T, int pitch, int jpad, void* stream);

@@ -203,7 +203,8 @@ __global__ void __launch_bounds__(1024) softmax_cols_kernel(float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // Fused self-attention of one (utterance, head) on the f16 matrix cores in split-f16 arithmetic (hi + lo f16
 // operands, lo*hi + hi*lo + hi*hi, f32 accumulate): S^T = K^T Q, softmax over keys, O = V P — the score matrix
-// never leaves registers.  hd = 64, at most 256 keys (T = 249 here).
+// never leaves registers.  hd = 64; keys go in blocks of 256 (one block at T = 249) with a running softmax over
+// the blocks for longer utterances.
 //   Q, K arrive as split planes (satools_hip.h) straight from their projections' epilogues: a 16-byte unit holds 8
 //   channels of one frame, which is an MFMA operand fragment both as A (K: row = key) and as B (Q: column = query).
 //   A wave owns 32 queries and ALL keys: S^T[key][query] is 8 accumulator tiles (128 VGPRs), a lane's column is one
@@ -238,107 +239,121 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   const size_t ub = (size_t)b * (C / 4) * T;                 // units per utterance: C * T * 4 bytes
 
-  // ---- K planes of the head -> LDS [chunk*4 + plane][256 keys] (keys >= T zero) ----
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    at_lds[r * 256 + tid] = tid < T ? ks[ub + (size_t)((4 * h + (r >> 2)) * 4 + (r & 3)) * T + tid] : zero4;
-  // ---- Q fragments of the wave's 32 queries ----
-  h8 qh[4], ql[4];
-#pragma unroll
-  for (int cl = 0; cl < 4; ++cl) {
-    const size_t u = ub + (size_t)((4 * h + cl) * 4 + lh) * T + q;
-    qh[cl] = __builtin_bit_cast(h8, qok ? qs[u] : zero4);
-    ql[cl] = __builtin_bit_cast(h8, qok ? qs[u + 2 * (size_t)T] : zero4);
-  }
-  __syncthreads();
-
-  // ---- S^T = K^T Q: 8 key tiles x (4 chunks of 16 channels) ----
-  f32x16 st[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[m][r] = 0.f;
-#pragma unroll
-  for (int cl = 0; cl < 4; ++cl) {
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const h8 a_hi = __builtin_bit_cast(h8, at_lds[(cl * 4 + 0 + lh) * 256 + 32 * m + l31]);
-      const h8 a_lo = __builtin_bit_cast(h8, at_lds[(cl * 4 + 2 + lh) * 256 + 32 * m + l31]);
-      st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, qh[cl], st[m], 0, 0, 0);
-      st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, ql[cl], st[m], 0, 0, 0);
-      st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, qh[cl], st[m], 0, 0, 0);
-    }
-  }
-  // ---- softmax over keys: register r of tile m is key 32m + 8(r>>2) + 4lh + (r&3) ----
-  float mx = -INFINITY;
-#pragma unroll
-  for (int m = 0; m < 8; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = 32 * m + 8 * (r >> 2) + 4 * lh + (r & 3);
-      const float t = j < T ? st[m][r] * scale : -INFINITY;
-      st[m][r] = t;
-      mx = fmaxf(mx, t);
-    }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float sum = 0.f;
-#pragma unroll
-  for (int m = 0; m < 8; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = expf(st[m][r] - mx);       // masked keys: exp(-inf) = 0
-      st[m][r] = e;
-      sum += e;
-    }
-  sum += __shfl_xor(sum, 32);
-  const float inv = 1.0f / sum;
-
-  // ---- V of the head (f32 [64][v_pitch]) -> LDS [64][AT_VP], keys >= T zero ----
-  __syncthreads();                        // every wave is done with K
-  float* vl = (float*)at_lds;
-  const float* vb = v + ((size_t)b * C + (size_t)h * 64) * v_pitch;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int u = tid + 256 * i;          // float4 index: row d = u / 64, keys 4 (u % 64) ..
-    const int d = u >> 6, j4 = (u & 63) * 4;
-    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j4 < v_pitch) w = *(const float4*)(vb + (size_t)d * v_pitch + j4);
-    if (j4 + 0 >= T) w.x = 0.f;
-    if (j4 + 1 >= T) w.y = 0.f;
-    if (j4 + 2 >= T) w.z = 0.f;
-    if (j4 + 3 >= T) w.w = 0.f;
-    *(float4*)(vl + d * AT_VP + j4) = w;
-  }
-  __syncthreads();
-
-  // ---- O = V P: 2 row tiles (64 head dims) x 16 k-steps of 16 keys ----
   f32x16 oa[2];
 #pragma unroll
   for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oa[m2][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;          // running maximum and sum of this lane's query column
+  float* vl = (float*)at_lds;
+  const float* vb = v + ((size_t)b * C + (size_t)h * 64) * v_pitch;
+
+  // keys in blocks of 256 (one block for T <= 256); longer utterances keep a running softmax over the blocks
+  for (int k0 = 0; k0 < T; k0 += 256) {
+    // ---- K planes of the head, keys k0 .. k0 + 255 -> LDS [chunk*4 + plane][256] (keys >= T zero) ----
+    __syncthreads();                        // the previous block's V is no longer read
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
+    for (int r = 0; r < 16; ++r)
+      at_lds[r * 256 + tid] = k0 + tid < T ? ks[ub + (size_t)((4 * h + (r >> 2)) * 4 + (r & 3)) * T + k0 + tid] : zero4;
+    // Q fragments of the wave's 32 queries (re-read per key block from L2: holding them across the V product
+    // would spill registers)
+    h8 qh[4], ql[4];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      float pv[8];
+    for (int cl = 0; cl < 4; ++cl) {
+      const size_t u = ub + (size_t)((4 * h + cl) * 4 + lh) * T + q;
+      qh[cl] = __builtin_bit_cast(h8, qok ? qs[u] : zero4);
+      ql[cl] = __builtin_bit_cast(h8, qok ? qs[u + 2 * (size_t)T] : zero4);
+    }
+    __syncthreads();
+
+    // ---- S^T = K^T Q: 8 key tiles x (4 chunks of 16 channels) ----
+    f32x16 st[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pv[e] = st[m][8 * hh + e];
-      h8 b_hi, b_lo;
-      split8(pv, b_hi, b_lo);
+    for (int m = 0; m < 8; ++m)
 #pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2) {
-        const float* row = vl + (32 * m2 + l31) * AT_VP + 32 * m + 16 * hh + 4 * lh;
-        const float4 va = *(const float4*)row, vc = *(const float4*)(row + 8);
-        const float av[8] = {va.x, va.y, va.z, va.w, vc.x, vc.y, vc.z, vc.w};
-        h8 a_hi, a_lo;
-        split8(av, a_hi, a_lo);
-        oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, oa[m2], 0, 0, 0);
-        oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, oa[m2], 0, 0, 0);
-        oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, oa[m2], 0, 0, 0);
+      for (int r = 0; r < 16; ++r) st[m][r] = 0.f;
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const h8 a_hi = __builtin_bit_cast(h8, at_lds[(cl * 4 + 0 + lh) * 256 + 32 * m + l31]);
+        const h8 a_lo = __builtin_bit_cast(h8, at_lds[(cl * 4 + 2 + lh) * 256 + 32 * m + l31]);
+        st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, qh[cl], st[m], 0, 0, 0);
+        st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, ql[cl], st[m], 0, 0, 0);
+        st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, qh[cl], st[m], 0, 0, 0);
+      }
+    }
+    // ---- softmax over keys: register r of tile m is key k0 + 32m + 8(r>>2) + 4lh + (r&3) ----
+    float mx = m_run;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jk = k0 + 32 * m + 8 * (r >> 2) + 4 * lh + (r & 3);
+        const float t = jk < T ? st[m][r] * scale : -INFINITY;
+        st[m][r] = t;
+        mx = fmaxf(mx, t);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float alpha = expf(m_run - mx);          // 0 on the first block (m_run = -inf)
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = expf(st[m][r] - mx);       // masked keys: exp(-inf) = 0
+        st[m][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    l_run = l_run * alpha + sum;
+    m_run = mx;
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oa[m2][r] *= alpha;
+
+    // ---- V of the head (f32 [64][v_pitch]), keys k0 .. -> LDS [64][AT_VP], keys >= T zero ----
+    __syncthreads();                        // every wave is done with K
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int u = tid + 256 * i;          // float4 index: row d = u / 64, keys k0 + 4 (u % 64) ..
+      const int d = u >> 6, j4 = (u & 63) * 4, jg = k0 + j4;
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (jg < v_pitch) w = *(const float4*)(vb + (size_t)d * v_pitch + jg);
+      if (jg + 0 >= T) w.x = 0.f;
+      if (jg + 1 >= T) w.y = 0.f;
+      if (jg + 2 >= T) w.z = 0.f;
+      if (jg + 3 >= T) w.w = 0.f;
+      *(float4*)(vl + d * AT_VP + j4) = w;
+    }
+    __syncthreads();
+
+    // ---- O += V P: 2 row tiles (64 head dims) x 16 k-steps of 16 keys ----
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = st[m][8 * hh + e];
+        h8 b_hi, b_lo;
+        split8(pv, b_hi, b_lo);
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+          const float* row = vl + (32 * m2 + l31) * AT_VP + 32 * m + 16 * hh + 4 * lh;
+          const float4 va = *(const float4*)row, vc = *(const float4*)(row + 8);
+          const float av[8] = {va.x, va.y, va.z, va.w, vc.x, vc.y, vc.z, vc.w};
+          h8 a_hi, a_lo;
+          split8(av, a_hi, a_lo);
+          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, oa[m2], 0, 0, 0);
+          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, oa[m2], 0, 0, 0);
+          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, oa[m2], 0, 0, 0);
+        }
       }
     }
   }
+  const float inv = 1.0f / l_run;
   if (!qok) return;
   // ---- store: register r of tile m2 is head dim 32 m2 + 8 (r>>2) + 4 lh + (r&3) ----
 #pragma unroll
@@ -454,7 +469,6 @@ extern "C" int sat_attention_f16x3(const void* q_split, const void* k_split, con
   SAT_REQUIRE(q_split && k_split && v && (o || o_split), "attention: null pointer");
   SAT_REQUIRE(B > 0 && heads > 0 && T > 0, "attention: empty shape");
   SAT_REQUIRE(head_dim == 64, "attention: head dimension 64 only (got %d)", head_dim);
-  SAT_REQUIRE(T <= 256, "attention: at most 256 keys per utterance (got %d)", T);
   SAT_REQUIRE(v_pitch >= T && v_pitch % 4 == 0, "attention: v needs a row pitch >= T that is a multiple of 4 floats (got %d)", v_pitch);
   const size_t lds_bytes = (size_t)64 * AT_VP * 4;       // V [64][260] f32 >= K planes (16 x 256 x 16 B)
   SAT_HIP(hipFuncSetAttribute((const void*)attention_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

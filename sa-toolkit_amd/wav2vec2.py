@@ -14,7 +14,7 @@ Everything runs on the HIP kernels with activations channel-major [B][C][T]:
   * every Linear = 1x1 conv (bias / GELU / residual in the epilogue), in split-f16 through the GEMM kernel, its
     input handed over as split planes by the LayerNorm / attention / previous Linear that produced it;
   * attention, split-f16: one fused kernel per layer (Q, K as split planes from their projections, scores and
-    softmax in registers, context out as split planes); f32 mode: S^T = K^T Q and O = V P as GROUPED convs, one
+    softmax in registers — a running softmax over blocks of 256 keys —, context out as split planes); f32 mode: S^T = K^T Q and O = V P as GROUPED convs, one
     group per (utterance, head) — a [64][T] head slice of Q / of V^T stored with row pitch 256 is exactly the
     exact-f32 kernel's packed-weight layout — with a column softmax kernel in between.
 """
@@ -265,9 +265,9 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         for L in W["layers"]:
             h, hs = ln(x, L["ln1"])
             v = torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device)
-            if planes and T <= 256:
-                # fused attention (csrc/w2v2.hip; up to 256 frames = 5.1 s): Q and K leave their projections as split
-                # planes, the scores stay in registers, the context comes back as planes for the output projection
+            if planes:
+                # fused attention (csrc/w2v2.hip): Q and K leave their projections as split planes, the scores stay
+                # in registers, the context comes back as planes for the output projection
                 qs, ks = ops.split_like(B, 1024, T, x.device), ops.split_like(B, 1024, T, x.device)
                 ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], mode=mm, x_split=hs, y_split=qs, y_split_slope=1.0, no_y=True)
                 ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], mode=mm, x_split=hs, y_split=ks, y_split_slope=1.0, no_y=True)

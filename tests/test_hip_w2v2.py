@@ -155,7 +155,7 @@ def test_layernorm_planes_equal_split_of_f32_output(C, T, split):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T", [249, 256, 100, 31])
+@pytest.mark.parametrize("T", [249, 256, 100, 31, 257, 312, 700])
 def test_fused_attention_matches_float64(T):
     """sat_attention_f16x3 (split-f16 products, scores in registers) against softmax(scale q^T k) v in float64; the
     pad columns of v hold NaN (they are uninitialised memory on the path) and must not leak"""
@@ -163,7 +163,7 @@ def test_fused_attention_matches_float64(T):
     B, heads, hd = 2, 16, 64
     g = torch.Generator().manual_seed(T)
     q, k, v = (torch.randn(B, heads * hd, T, generator=g) * s for s in (1.5, 1.5, 1.0))
-    vp = torch.full((B, heads * hd, 256), float("nan"))
+    vp = torch.full((B, heads * hd, ((T + 63) // 64) * 64 if T > 256 else 256), float("nan"))
     vp[:, :, :T] = v
     o, os_ = ops.attention_fused(ops.act_split(q.cuda(), 1.0), ops.act_split(k.cuda(), 1.0), vp.cuda(), B, heads, hd, T,
                                  hd ** -0.5, want_f32=True)
@@ -178,10 +178,9 @@ def test_fused_attention_matches_float64(T):
     assert torch.equal(os_, ops.act_split(o, 1.0))
 
 
-def test_long_utterance_takes_the_unfused_attention(model):
-    """more than 256 frames (5.1 s): the split-f16 path falls back from the fused attention kernel to scores GEMM +
-    softmax + apply GEMM; its bottleneck features agree with the all-f32 setting and with the fused kernel's on a
-    5 s input"""
+def test_long_utterance_attention(model):
+    """more than 256 frames (5.1 s): the fused attention kernel keeps a running softmax over blocks of 256 keys; the
+    bottleneck features of the split-f16 path agree with the all-f32 setting (scores GEMM + softmax + apply GEMM)"""
     from satools_amd import synthetic
     bx = model.bn_extractor
     old = bx.w2v2_precision
