@@ -303,6 +303,11 @@ int sat_layernorm_channels_f32(const float* x, const float* gamma, const float* 
 int sat_layernorm_channels_planes_f32(const float* x, const float* gamma, const float* beta, float* y, void* y_split,
                                       int B, int C, int T, int64_t x_bstride, int64_t x_cstride, int64_t y_bstride,
                                       int64_t y_cstride, int gelu, int split_phases, void* stream);
+/* conv layer 0 fused with its LayerNorm (+GELU, + phase split): y / y_split = LN(conv0(wav)) as the two entry points
+ * above would give it, bit for bit, without the [B][C][T0] f32 tensor in between (C <= 512, k <= 12). */
+int sat_w2v2_conv0_layernorm_f32(const float* wav, const float* w, const float* bias, const float* gamma,
+                                 const float* beta, float* y, void* y_split, int B, int n, int C, int k, int stride,
+                                 int64_t y_bstride, int64_t y_cstride, int gelu, int split_phases, void* stream);
 int sat_softmax_columns_f32(float* st, int G, int T, int pitch, float scale, void* stream);
 /* Fused self-attention of the wav2vec2 encoder layers (torchaudio SelfAttention as configured by
  * tdnnf_wav2vec2_vq.py:39-56; 16 heads x 64) in split-f16 arithmetic, scores kept in registers:

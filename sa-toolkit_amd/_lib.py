@@ -96,6 +96,7 @@ _PROTOS = {
     "sat_layernorm_channels_planes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                     C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                                     C.c_void_p]),
+    "sat_w2v2_conv0_layernorm_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "sat_conv_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "sat_attention_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_float, C.c_void_p]),

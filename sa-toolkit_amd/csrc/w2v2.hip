@@ -47,22 +47,52 @@ constexpr int LN_FR = 32;          // frames per block: a wave's load covers two
 // per SIMD); <16, 32> serves C <= 512 (feature extractor) and <32, 32> C <= 1024 (transformer: 249 frames are 256
 // blocks in all, so each one brings 16 waves to hide its own load latency).  Outputs: f32 `y` and / or split planes
 // `y16` (satools_hip.h: hi | lo f16 of the value, 16-byte units of 8 channels) — a thread's channels are whole units.
-template <int SLICES, int MAXPT>
+// CONV0: the input is not read but computed — the wav2vec2 feature extractor's first conv (1 -> C channels, ck <= 12
+// taps, stride cstride) of the waveform x [B][cn], weights in LDS as rows of 12 floats: y = LN(conv0(wav)) without the
+// [B][512][16k] f32 tensor ever reaching HBM.  Same accumulation order as w2v2_conv0_kernel, so the same bits.
+template <int SLICES, int MAXPT, bool CONV0 = false>
 __global__ void __launch_bounds__(LN_FR * SLICES) layernorm_ch_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-    uint4* __restrict__ y16, int C, int T, long long x_bs, long long x_cs, long long y_bs, long long y_cs, int gelu, int split) {
+    uint4* __restrict__ y16, int C, int T, long long x_bs, long long x_cs, long long y_bs, long long y_cs, int gelu, int split,
+    const float* __restrict__ cw = nullptr, const float* __restrict__ cbias = nullptr, int cn = 0, int ck = 0, int cstride = 0) {
   __shared__ float part[SLICES][LN_FR];
   __shared__ float s_mean[LN_FR], s_rstd[LN_FR];
+  extern __shared__ __attribute__((aligned(16))) float ln_wl[];     // CONV0: [C][12]
   const int b = blockIdx.y;
   const int tx = threadIdx.x & (LN_FR - 1), sl = threadIdx.x / LN_FR;
   const int t = blockIdx.x * LN_FR + tx;
   const bool ok = t < T;
   const int cb = sl * MAXPT;
-  const float* xb = x + (size_t)b * x_bs + (ok ? t : 0);
   float v[MAXPT];
   float s = 0.f;
+  if constexpr (CONV0) {
+    for (int i = threadIdx.x; i < C * 12; i += LN_FR * SLICES) {
+      const int c = i / 12, j = i - 12 * c;
+      ln_wl[i] = j < ck ? cw[c * ck + j] : 0.f;
+    }
+    __syncthreads();
+    float xv[12];
 #pragma unroll
-  for (int k = 0; k < MAXPT; ++k) v[k] = (ok && cb + k < C) ? xb[(size_t)(cb + k) * x_cs] : 0.f;
+    for (int j = 0; j < 12; ++j) xv[j] = (ok && j < ck) ? x[(size_t)b * cn + (size_t)t * cstride + j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXPT; ++k) {
+      v[k] = 0.f;
+      if (ok && cb + k < C) {
+        const float4 w0 = *(const float4*)&ln_wl[(cb + k) * 12], w1 = *(const float4*)&ln_wl[(cb + k) * 12 + 4],
+                     w2 = *(const float4*)&ln_wl[(cb + k) * 12 + 8];
+        const float wr[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+        float acc = cbias[cb + k];
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+          if (j < ck) acc = fmaf(wr[j], xv[j], acc);
+        v[k] = acc;
+      }
+    }
+  } else {
+    const float* xb = x + (size_t)b * x_bs + (ok ? t : 0);
+#pragma unroll
+    for (int k = 0; k < MAXPT; ++k) v[k] = (ok && cb + k < C) ? xb[(size_t)(cb + k) * x_cs] : 0.f;
+  }
 #pragma unroll
   for (int k = 0; k < MAXPT; ++k)
     if (cb + k < C) s += v[k];
@@ -426,11 +456,27 @@ static int layernorm_launch(const float* x, const float* gamma, const float* bet
   SAT_REQUIRE(!y_split || C % 16 == 0, "layernorm_channels: split planes need a multiple of 16 channels (got %d)", C);
   dim3 grid(ceil_div(T, LN_FR), B);
   const bool wide = C > 512;
-  auto kern = wide ? layernorm_ch_kernel<32, 32> : layernorm_ch_kernel<16, 32>;
+  auto kern = wide ? layernorm_ch_kernel<32, 32, false> : layernorm_ch_kernel<16, 32, false>;
   hipLaunchKernelGGL(kern, grid, dim3(LN_FR * (wide ? 32 : 16)), 0, (hipStream_t)stream, x, gamma, beta, y, (uint4*)y_split, C, T,
                      (long long)x_bstride, (long long)x_cstride, (long long)y_bstride, (long long)y_cstride, gelu,
-                     split_phases);
+                     split_phases, (const float*)nullptr, (const float*)nullptr, 0, 0, 0);
   SAT_LAUNCH_CHECK("layernorm_ch_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_w2v2_conv0_layernorm_f32(const float* wav, const float* w, const float* bias, const float* gamma,
+                                            const float* beta, float* y, void* y_split, int B, int n, int C, int k, int stride,
+                                            int64_t y_bstride, int64_t y_cstride, int gelu, int split_phases, void* stream) {
+  SAT_REQUIRE(wav && w && bias && gamma && beta && (y || y_split), "w2v2_conv0_layernorm: null pointer");
+  SAT_REQUIRE(B > 0 && C > 0 && C <= 512 && k >= 1 && k <= 12 && stride >= 1 && n >= k, "w2v2_conv0_layernorm: unsupported shape");
+  SAT_REQUIRE(!y_split || C % 16 == 0, "w2v2_conv0_layernorm: split planes need a multiple of 16 channels (got %d)", C);
+  const int T = (n - k) / stride + 1;
+  dim3 grid(ceil_div(T, LN_FR), B);
+  auto kern = layernorm_ch_kernel<16, 32, true>;
+  hipLaunchKernelGGL(kern, grid, dim3(LN_FR * 16), (size_t)C * 12 * sizeof(float), (hipStream_t)stream, wav, gamma, beta, y,
+                     (uint4*)y_split, C, T, 0LL, 0LL, (long long)y_bstride, (long long)y_cstride, gelu, split_phases, w, bias, n, k,
+                     stride);
+  SAT_LAUNCH_CHECK("layernorm_ch_kernel<conv0>");
   return SAT_OK;
 }
 

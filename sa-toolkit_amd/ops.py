@@ -161,6 +161,20 @@ def w2v2_conv0(wav, w, bias, stride=5):
     return y
 
 
+def w2v2_conv0_ln(wav, w, bias, gamma, beta, gelu=True, split_phases=True, planes=True, want_f32=False, stride=5):
+    """layernorm_ch(w2v2_conv0(wav, w, bias), gamma, beta, ...) in one kernel (the same bits): returns (y, planes)"""
+    wav = _f32c(wav)
+    B, n = wav.shape
+    c, k = w.shape
+    t = (n - k) // stride + 1
+    y = torch.empty((B, 2 * c, (t + 1) // 2) if split_phases else (B, c, t), dtype=torch.float32, device=wav.device)
+    ys = split_like(B, y.shape[1], y.shape[2], wav.device) if planes else None
+    check(lib().sat_w2v2_conv0_layernorm_f32(ptr(wav), ptr(w), ptr(bias), ptr(gamma), ptr(beta), ptr(y) if want_f32 else None,
+                                             ptr(ys), B, n, c, k, stride, y.stride(0), y.stride(1), int(gelu), int(split_phases),
+                                             stream()), "sat_w2v2_conv0_layernorm_f32")
+    return y, ys
+
+
 def layernorm_ch(x, gamma, beta, gelu=False, split_phases=False, planes=False, want_f32=True):
     """LayerNorm over channels of [B, C, T]; split_phases -> [B, 2C, ceil(T/2)] (even | odd frames).
     planes: also (want_f32=False: only) write the result as split planes for a following split-f16 conv and

@@ -224,12 +224,15 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         heads, hd = 16, 64
         # conv feature extractor
         planes = mm == _lib.CONV_F16X3        # split-f16: LayerNorm hands its result on as split planes (16-byte staging)
-        x = ops.w2v2_conv0(wav, W["fe"][0]["w"], W["fe"][0]["b"])                   # [B, 512, T0]
+        x = None if planes else ops.w2v2_conv0(wav, W["fe"][0]["w"], W["fe"][0]["b"])   # [B, 512, T0]
         for i in range(7):
             e = W["fe"][i]
             last = i == 6
             # LayerNorm over channels + GELU; for a following stride-2 conv the output is phase-split
-            if planes and not last:
+            if planes and i == 0:
+                # conv layer 0 and its LayerNorm in one kernel: the [B, 512, 16k] f32 tensor (1 GB) never exists
+                x, xs = ops.w2v2_conv0_ln(wav, e["w"], e["b"], e["g"], e["beta"])
+            elif planes and not last:
                 x, xs = ops.layernorm_ch(x, e["g"], e["beta"], gelu=True, split_phases=True, planes=True, want_f32=False)
             else:
                 x, xs = ops.layernorm_ch(x, e["g"], e["beta"], gelu=True, split_phases=not last), None

@@ -200,3 +200,17 @@ def test_long_utterance_attention(model):
             assert err < 2e-3 and (ia == ib).float().mean() > 0.99
     finally:
         bx.w2v2_precision = old
+
+
+@pytest.mark.parametrize("n", [4005, 16000, 4010])
+def test_conv0_fused_with_layernorm_gives_the_same_bits(n):
+    """sat_w2v2_conv0_layernorm_f32 = sat_layernorm_channels(_planes)_f32 of sat_w2v2_conv0_f32, bit for bit"""
+    from satools_amd import ops
+    x = _rand(2, n, seed=1, scale=0.3).to(DEV)
+    w, b = _rand(512, 10, seed=2, scale=0.3).to(DEV), _rand(512, seed=3, scale=0.1).to(DEV)
+    g, beta = (1 + _rand(512, seed=4, scale=0.1)).to(DEV), _rand(512, seed=5, scale=0.1).to(DEV)
+    y0, ys0 = ops.layernorm_ch(ops.w2v2_conv0(x, w, b), g, beta, gelu=True, split_phases=True, planes=True)
+    y1, ys1 = ops.w2v2_conv0_ln(x, w, b, g, beta, want_f32=True)
+    assert y0.shape == y1.shape and torch.equal(y0, y1) and torch.equal(ys0, ys1)
+    _, ys2 = ops.w2v2_conv0_ln(x, w, b, g, beta)
+    assert torch.equal(ys0, ys2)
