@@ -116,9 +116,11 @@ def main():
     gathered = ([torch.empty(world * BATCH, 1, N_SAMPLES + 1, dtype=torch.float32, device=dev)
                  for _ in range(max(1, a.jobs))] if use_pg else None)   # indexed modulo the job count
 
-    # every job stream owns its workspaces: never more streams than warmup steps, so that each one has run
-    # (and allocated) before the timed region starts
-    jobs = max(1, min(a.jobs, a.warmup) if a.warmup > 0 else 1)
+    # every job stream owns its workspaces and must have run (and allocated) once before the timed region starts: when
+    # --warmup is smaller than the number of job streams, the missing runs are done as untimed set-up steps first
+    # (reported as config.setup_steps)
+    jobs = max(1, a.jobs)
+    setup_steps = max(0, jobs - a.warmup)
     streams = [torch.cuda.Stream(device=dev) for _ in range(jobs)]
     step_no = [0]
 
@@ -135,7 +137,7 @@ def main():
                 dist.all_gather_into_tensor(gathered[step_no[0] % jobs], y.contiguous())
         return y
 
-    for _ in range(a.warmup):
+    for _ in range(setup_steps + a.warmup):
         step()
     if use_pg:
         dist.barrier()
@@ -246,7 +248,7 @@ def main():
             "config": {"workload": f"{tag}{'+f0-transformation=' + a.f0_transformation if a.f0_transformation else ''} model.convert, batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
                        "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
                        "f0": "YAAPT computed on-path on the GPU inside convert()",
-                       "jobs_per_gpu": jobs,
+                       "jobs_per_gpu": jobs, "setup_steps": setup_steps,
                        "parallelism": f"dp{world}" + (" + RCCL all_gather of waveforms per step" if world > 1 else "")},
             "roofline": roofline,
         }
