@@ -252,7 +252,7 @@ def main():
                        "parallelism": f"dp{world}" + (" + RCCL all_gather of waveforms per step" if world > 1 else "")},
             "roofline": roofline,
         }
-        if not a.no_cpu_baseline and tag == TAG:
+        if not a.no_cpu_baseline and tag == TAG and world == 1:     # the CPU leg runs at N = 1 only
             state, _ = synthetic.checkpoint(TAG)
             sample = list(range(4))
             out["cpu_baseline"] = cpu_baseline(state, model.spk, sample)
