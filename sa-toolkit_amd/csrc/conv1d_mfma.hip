@@ -2036,6 +2036,11 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     if (a.x16 && a.ksize == 1 && !a.f8 && !a.poly_planes && a.fast_epi && d->groups == 1 && a.rows_g >= 128 &&
         (a.cin_pad / CI_CHUNK) % 4 == 0 && g_k1_gemm)
       return launch_f16x3_k1(a, d->B, s);
+    // few blocks (TDNNF linearB: 128 rows x 250 frames x 32 utterances = 64 tiles of 64 x 256 on 256 CUs): half-width
+    // tiles double the blocks of these latency-bound launches
+    if (a.x16 && a.ksize == 3 && !a.f8 && !a.poly_planes && a.rows_g > 32 && a.T_q > 128 &&
+        (long long)ceil_div(a.rows_g, 64) * ceil_div(a.T_q, 256) * d->B * d->groups < 256)
+      return launch_f16x3<2, 1, 3>(a, d->B, d->groups, s);
     if (a.rows_g > 32) return launch_f16x3_ks<2, 2>(a, d->B, d->groups, s);   // 64 rows x 256 positions
     return launch_f16x3_ks<1, 4>(a, d->B, d->groups, s);                       // 32 rows x 512 positions
   }
