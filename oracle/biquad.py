@@ -1,19 +1,32 @@
 """Band-limiting biquads used by YAAPT (reference call site: satools/satools/hifigan/yaapt.py:42-51
--> torchaudio.functional.lowpass_biquad / highpass_biquad).
+-> torchaudio.functional.lowpass_biquad / highpass_biquad).  Test infrastructure only.
 
 THIRD-PARTY, PARITY UNPINNED: torchaudio is a dependency of the reference whose source is not under
 /root/reference and which is not installed here (its version is not pinned by the reference either,
-install.sh:115-116 -> 2.1.x).  This restates torchaudio 2.1's published algorithm:
+install.sh:115-116 -> 2.1.x).  This restates torchaudio 2.1's published algorithm
+(`functional/filtering.py`: `lowpass_biquad` -> `biquad` -> `lfilter` -> `_lfilter`; the recursion is
+`_lfilter_core_loop`, csrc/lfilter.cpp `host_lfilter_core_loop`):
   * RBJ cookbook coefficients computed in the waveform dtype (f32), Q = 0.707;
-  * lfilter: FIR part = conv1d of the 2-sample left-padded input with [b2, b1, b0], divided by a0;
-    a-coefficients divided by a0; sequential recursion in f32
-        y[t] = fir[t] - a2'*y[t-2] - a1'*y[t-1]     (multiply, subtract; that order; no fma)
+  * `_lfilter` normalises FIRST: b' = b / a0, a' = a / a0 (f32 divisions of the coefficients), then
+    FIR part = `conv1d` of the 2-sample left-padded input with the flipped [b2', b1', b0'];
+  * sequential recursion in f32, exactly the C++ loop's order
+        y[t] = fir[t];  y[t] -= a2'*y[t-2];  y[t] -= a1'*y[t-1]     (multiply, subtract; no fma)
   * output clamped to [-1, 1] (lfilter(clamp=True)); the recursion itself runs on unclamped values.
-The FIR sum order is fixed here as (b2*x[t-2] + b1*x[t-1]) + b0*x[t] without fma."""
+
+FIR summation order (`order=`):
+  "torchaudio" (default, shipped in csrc/yaapt.hip): what torch's CPU `conv1d` evaluates for this 1-channel
+      3-tap kernel — an FMA chain in tap order, acc = b2'*x[t-2]; acc = fma(b1', x[t-1], acc);
+      acc = fma(b0', x[t], acc) — measured bit-identical to `F.conv1d` on 80 000 samples for both filters in the
+      build container (oneDNN, AVX-512 host; tests/test_oracle_yaapt.py pins it).  The FMA is emulated here
+      exactly (round-to-odd in float64) so the oracle gives the same bits on any host.
+  "raw_b_then_divide": round 1's order, ((b2*x[t-2] + b1*x[t-1]) + b0*x[t]) / a0 with the raw b; kept as the
+      variant of the rounding-order study (tests/golden/make_biquad_order_study.py, fx_biquad_order.json)."""
 import math
 
 import numpy as np
 import torch
+
+ORDERS = ("torchaudio", "raw_b_then_divide")
 
 
 def coeffs(kind, sample_rate, cutoff, Q=0.707):
@@ -33,22 +46,50 @@ def coeffs(kind, sample_rate, cutoff, Q=0.707):
 
 
 def kernel_constants(kind, sample_rate, cutoff):
-    """(b0, b1, b2, a0, c1 = a1/a0, c2 = a2/a0) as f32 — what the recursion uses"""
+    """(b0' = b0/a0, b1' = b1/a0, b2' = b2/a0, a0, c1 = a1/a0, c2 = a2/a0) as f32 — what the FIR and the
+    recursion use (a0 itself is no longer used by the kernel; kept in the tuple for the plan layout)"""
     b, a = coeffs(kind, sample_rate, cutoff)
-    return b[0], b[1], b[2], a[0], np.float32(a[1] / a[0]), np.float32(a[2] / a[0])
+    return (np.float32(b[0] / a[0]), np.float32(b[1] / a[0]), np.float32(b[2] / a[0]), a[0],
+            np.float32(a[1] / a[0]), np.float32(a[2] / a[0]))
 
 
-def biquad(x, kind, sample_rate, cutoff):
-    """x: 1-D float32 numpy array -> filtered, clamped float32 array"""
-    b0, b1, b2, a0, c1, c2 = kernel_constants(kind, sample_rate, cutoff)
+def fma32(a, b, c):
+    """exact f32 fused multiply-add on numpy arrays: the f32 x f32 product is exact in float64; the float64 sum
+    is rounded to odd (TwoSum error term), which makes the final rounding to f32 the correctly rounded result"""
+    p = np.asarray(a, np.float32).astype(np.float64) * np.asarray(b, np.float32).astype(np.float64)
+    c64 = np.asarray(c, np.float32).astype(np.float64)
+    s = p + c64
+    bb = s - p
+    e = (p - (s - bb)) + (c64 - bb)
+    t = np.nextafter(s, np.where(e > 0, np.inf, -np.inf))
+    odd = (s.view(np.int64) & 1) == 1
+    s = np.where((e != 0) & ~odd, t, s)
+    return s.astype(np.float32)
+
+
+def fir(x, kind, sample_rate, cutoff, order="torchaudio"):
+    """FIR half of lfilter on a 1-D f32 array (2-sample zero history)"""
     x = np.asarray(x, dtype=np.float32)
     xp = np.concatenate([np.zeros(2, np.float32), x])
-    fir = ((b2 * xp[:-2] + b1 * xp[1:-1]) + b0 * xp[2:]) / a0
-    out = np.empty_like(x)
+    x2, x1, x0 = xp[:-2], xp[1:-1], xp[2:]
+    if order == "torchaudio":
+        b0, b1, b2, _, _, _ = kernel_constants(kind, sample_rate, cutoff)
+        return fma32(b0, x0, fma32(b1, x1, b2 * x2))
+    if order == "raw_b_then_divide":
+        b, a = coeffs(kind, sample_rate, cutoff)
+        return ((b[2] * x2 + b[1] * x1) + b[0] * x0) / a[0]
+    raise ValueError(order)
+
+
+def biquad(x, kind, sample_rate, cutoff, order="torchaudio"):
+    """x: 1-D float32 numpy array -> filtered, clamped float32 array"""
+    _, _, _, _, c1, c2 = kernel_constants(kind, sample_rate, cutoff)
+    f = fir(x, kind, sample_rate, cutoff, order)
+    out = np.empty_like(f)
     y1 = np.float32(0)
     y2 = np.float32(0)
-    for t in range(x.shape[0]):
-        v = fir[t] - c2 * y2
+    for t in range(f.shape[0]):
+        v = f[t] - c2 * y2
         v = v - c1 * y1
         out[t] = v
         y2 = y1
@@ -56,7 +97,7 @@ def biquad(x, kind, sample_rate, cutoff):
     return np.clip(out, np.float32(-1), np.float32(1))
 
 
-def band_limit(x, sample_rate=16000, bp_low=50.0, bp_high=1500.0):
+def band_limit(x, sample_rate=16000, bp_low=50.0, bp_high=1500.0, order="torchaudio"):
     """SignalObj.filtered_version (yaapt.py:42-51): low-pass at bp_low THEN high-pass at bp_high
     (yes, as written in the reference), each through its own clamped lfilter"""
-    return biquad(biquad(x, "lp", sample_rate, bp_low), "hp", sample_rate, bp_high)
+    return biquad(biquad(x, "lp", sample_rate, bp_low, order), "hp", sample_rate, bp_high, order)

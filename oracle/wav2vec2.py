@@ -2,15 +2,25 @@
 tdnnf_wav2vec2_vq.py:39-56 -> satools/satools/utils/import_fairseq_model.py:81-113 ->
 torchaudio.models.wav2vec2.model.wav2vec2_model), CPU restatement.
 
-THIRD-PARTY, PARITY UNPINNED: torchaudio is not under /root/reference and not installed here.  This
-restates the published torchaudio 2.1 module semantics:
+THIRD-PARTY: torchaudio is not under /root/reference and not installed here.  This restates the published
+torchaudio 2.1 module semantics and is CROSS-CHECKED against an independent implementation that IS installed
+in the build container, Hugging Face transformers' `Wav2Vec2Model(do_stable_layer_norm=True,
+feat_extract_norm="layer")` — the architecture torchaudio's own `import_huggingface_model` maps one-to-one
+onto this configuration — by tests/golden/make_w2v2_crosscheck.py (fixtures tests/golden/fx_w2v2_hf.npz,
+tests/test_oracle_w2v2.py).  Against torchaudio itself parity stays unpinned.
   * extractor_mode="layer_norm": 7 x [Conv1d(bias) -> LayerNorm over channels (affine) -> GELU]
     with (k, s) = (10,5), (3,2) x4, (2,2) x2; no waveform normalisation;
   * feature projection: LayerNorm(512) -> Linear(512, 1024);
   * positional conv: weight_norm(Conv1d(1024, 1024, 128, padding=64, groups=16), dim=2), last output
     sample dropped (even kernel), GELU, added to the input;
-  * encoder_layer_norm_first=True: LayerNorm(1024) right after the positional add, BEFORE the 24 layers;
-    layer: x = x + Attn(LN(x)); x = x + FFN(LN(x)); no trailing LayerNorm;
+  * encoder_layer_norm_first=True: the 24 layers are pre-LN, x = x + Attn(LN(x)); x = x + FFN(LN(x)).
+    torchaudio builds `Transformer(..., layer_norm_first=not layer_norm_first)` (`_get_encoder`), so the
+    encoder-level LayerNorm(1024) runs AFTER the stack in `forward()` (as in fairseq / HF) and NOT AT ALL in
+    `get_intermediate_outputs`, which is what `extract_features` returns: the reference's
+    `extract_features(x)[0][-1]` (tdnnf_wav2vec2_vq.py:295-297) is the raw output of layer 24.  The
+    parameter `encoder.transformer.layer_norm.*` stays in the state dict, unused by `extract_bn`.
+    (Round 1 applied that LayerNorm before the stack, following SURVEY Appendix D's "from memory" note; HF
+    refutes it: make_w2v2_crosscheck.py measures both placements.)
   * extract_features returns the list of per-layer outputs (the reference takes [-1]).
 Parameter names follow torchaudio's state-dict keys so reference checkpoints (`preprocessor.*`) load.
 It doubles as the `wav2vec2_model` factory of the fixture generator's torchaudio stand-in."""
@@ -122,9 +132,12 @@ class _Transformer(nn.Module):
         self.layer_norm = nn.LayerNorm(dim)
         self.layers = nn.ModuleList([_EncoderLayer(dim, heads, inter) for _ in range(layers)])
 
-    def intermediate(self, x):
+    def intermediate(self, x, ln_placement="none_in_extract_features"):
         x = x + self.pos_conv_embed(x)
-        x = self.layer_norm(x)                 # layer_norm_first: before the stack
+        if ln_placement == "before_stack":     # the refuted round-1 reading, kept only for the cross-check script
+            x = self.layer_norm(x)
+        else:
+            assert ln_placement == "none_in_extract_features"
         outs = []
         for layer in self.layers:
             x = layer(x)
@@ -145,13 +158,14 @@ class Wav2Vec2Restated(nn.Module):
         self.feature_extractor = _FeatureExtractor()
         self.encoder = _Encoder(layers=num_layers)
 
-    def extract_features(self, waveforms, lengths=None, num_layers=None):
+    def extract_features(self, waveforms, lengths=None, num_layers=None, _ln_placement="none_in_extract_features"):
         x = self.feature_extractor(waveforms)
         x = self.encoder.feature_projection(x)
-        return self.encoder.transformer.intermediate(x), None
+        return self.encoder.transformer.intermediate(x, _ln_placement), None
 
     def forward(self, waveforms, lengths=None):
-        return self.extract_features(waveforms)[0][-1], None
+        """torchaudio's `forward()`: the encoder-level LayerNorm after the pre-LN stack"""
+        return self.encoder.transformer.layer_norm(self.extract_features(waveforms)[0][-1]), None
 
 
 def build_wav2vec2(*args, **cfg):

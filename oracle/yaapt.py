@@ -373,12 +373,14 @@ def dynamic(rp, rm, energy, plan):
     return rp[path, torch.arange(T)]
 
 
-def yaapt_one(x, opts, aux=None):
-    """x [n] f32 -> final pitch [nframes] (Hz, 0 = unvoiced)   (`_yaapt`, yaapt.py:795-944)"""
+def yaapt_one(x, opts, aux=None, biquad_order="torchaudio"):
+    """x [n] f32 -> final pitch [nframes] (Hz, 0 = unvoiced)   (`_yaapt`, yaapt.py:795-944).
+    `biquad_order`: FIR summation order of the third-party biquads (oracle/biquad.py)"""
     plan = Plan(x.numel(), opts)
     sig = F.pad(x.to(F32), (plan.pad, plan.pad))
-    filt = torch.from_numpy(biquad.band_limit(sig.numpy(), int(plan.fs), plan.p["bp_low"], plan.p["bp_high"]))
-    filt2 = torch.from_numpy(biquad.band_limit((sig ** 2).numpy(), int(plan.fs), plan.p["bp_low"], plan.p["bp_high"]))
+    bl = lambda v: torch.from_numpy(biquad.band_limit(v.numpy(), int(plan.fs), plan.p["bp_low"], plan.p["bp_high"], biquad_order))
+    filt = bl(sig)
+    filt2 = bl(sig ** 2)
     energy, vuv = nlfer(filt, plan)
     spec_pitch, pitch_std = spec_track(filt2, energy, vuv, plan, aux=aux)
     tp1, tm1 = time_track(filt, spec_pitch, pitch_std, plan)
@@ -394,6 +396,6 @@ def yaapt_one(x, opts, aux=None):
     return final
 
 
-def yaapt(wav, opts):
+def yaapt(wav, opts, biquad_order="torchaudio"):
     """wav [B, n] -> [B, nframes]   (`yaapt`, yaapt.py:946-951: a serial loop over the batch)"""
-    return torch.stack([yaapt_one(wav[i], opts) for i in range(wav.shape[0])], 0)
+    return torch.stack([yaapt_one(wav[i], opts, biquad_order=biquad_order) for i in range(wav.shape[0])], 0)

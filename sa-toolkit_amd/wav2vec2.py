@@ -2,8 +2,9 @@
 `tdnnf_wav2vec2_vq.Net.extract_bn` (egs/asr/librispeech/local/chain/tuning/tdnnf_wav2vec2_vq.py:21-345).
 
 The wav2vec2 model itself is torchaudio's (`import_fairseq_model.py:81-113`), third-party to the
-reference and absent here: its module semantics are restated from torchaudio 2.1 (SURVEY Appendix D,
-oracle/wav2vec2.py) — parity unpinned.  Parameters keep torchaudio's state-dict key names
+reference and absent here: its module semantics are restated from torchaudio 2.1 (oracle/wav2vec2.py) and
+cross-checked layer by layer against HF transformers' stable-layer-norm Wav2Vec2Model, the architecture
+torchaudio's own importer maps one-to-one onto this configuration (tests/golden/fx_w2v2_hf.npz).  Parameters keep torchaudio's state-dict key names
 (`preprocessor.feature_extractor...`, `preprocessor.encoder...`) so reference checkpoints load.
 
 Everything runs on the HIP kernels with activations channel-major [B][C][T]:
@@ -197,7 +198,6 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
                 n_ = min(11, wpos.shape[2] - 11 * s_)
                 ws[:, :, :n_] = wpos[:, :, 11 * s_:11 * s_ + n_]
                 W["pos"]["pieces"].append(packing.pack_conv_weight_f16x3(ws, groups=16))
-        W["ln"] = {"g": f32(tr.layer_norm.weight), "beta": f32(tr.layer_norm.bias)}
         W["layers"] = []
         for lay in tr.layers:
             at = lay.attention
@@ -258,7 +258,11 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         else:
             x = ops.conv1d(x, W["pos"]["w"], 1024, 128, bias=W["pos"]["b"], pad_left=64, pad_right=63, groups=16,
                            gelu=True, post_res=x)
-        x = ops.layernorm_ch(x, W["ln"]["g"], W["ln"]["beta"])
+        # NO encoder-level LayerNorm here: torchaudio builds Transformer(layer_norm_first=not encoder_layer_norm_first),
+        # so `encoder.transformer.layer_norm` runs after the stack in forward() and not at all in
+        # get_intermediate_outputs / extract_features, whose [-1] the reference takes (tdnnf_wav2vec2_vq.py:295-297);
+        # cross-checked against HF transformers (tests/golden/make_w2v2_crosscheck.py).  The parameter stays in the
+        # state dict, unused on this path.
         G = B * heads
         tp = ((T + 63) // 64) * 64   # row pitch of the per-head tensors = the packed-weight co_pad for T rows
         # Linear layers read their input as split planes (16-byte staging, two 16-channel sub-chunks per pipeline

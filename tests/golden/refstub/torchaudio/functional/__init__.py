@@ -1,9 +1,11 @@
 """lowpass_biquad / highpass_biquad following torchaudio 2.1's published algorithm:
-coefficients from the RBJ cookbook in the waveform dtype (f32), `lfilter` = FIR part by
-conv1d with the raw b coefficients, division of that and of the a coefficients by a0, then the
-sequential recursion  y[t] = fir[t] - a2'*y[t-2] - a1'*y[t-1]  in f32 (separate multiply and
-subtract, that order), and a final clamp to [-1, 1].  Same arithmetic as oracle/biquad.py.  The recursion runs in numpy float32
-scalars behind torch.jit.ignore so that the scripted reference can call it."""
+coefficients from the RBJ cookbook in the waveform dtype (f32); `_lfilter` divides b and a by a0
+FIRST, takes the FIR part with torch's own `conv1d` over the 2-sample left-padded input and the
+flipped b' (as torchaudio's DifferentiableFIR does), then runs the sequential recursion of
+`_lfilter_core_loop`  y[t] = fir[t]; y[t] -= a2'*y[t-2]; y[t] -= a1'*y[t-1]  in f32 (separate multiply
+and subtract, that order), and clamps to [-1, 1].  Same arithmetic as oracle/biquad.py order="torchaudio"
+(which emulates conv1d's FMA chain exactly).  The recursion runs in numpy float32 scalars behind
+torch.jit.ignore so that the scripted reference can call it."""
 import math
 
 import numpy as np
@@ -37,10 +39,12 @@ def _lfilter(x: Tensor, b: Tensor, a: Tensor) -> Tensor:
     an = a.numpy().astype(np.float32)
     c1, c2 = np.float32(an[1] / an[0]), np.float32(an[2] / an[0])
     out = np.empty_like(xn)
+    # FIR part as in torchaudio: conv1d of the padded waveform with the flipped b / a0
+    bnorm = (b.to(torch.float32) / a.to(torch.float32)[0:1]).flip(0).contiguous().view(1, 1, 3)
+    xpad = torch.nn.functional.pad(x.reshape(-1, 1, shape[-1]).to(torch.float32), (2, 0))
+    fir = torch.nn.functional.conv1d(xpad, bnorm).reshape(-1, shape[-1]).numpy()
     for r in range(xn.shape[0]):
-        xp = np.concatenate([np.zeros(2, np.float32), xn[r]])
-        # FIR part (torchaudio: conv1d with the flipped b), summed as (b2*x[t-2] + b1*x[t-1]) + b0*x[t]
-        f = ((bn[2] * xp[:-2] + bn[1] * xp[1:-1]) + bn[0] * xp[2:]) / an[0]
+        f = fir[r]
         o = out[r]
         y1 = np.float32(0.0)
         y2 = np.float32(0.0)
