@@ -245,7 +245,8 @@ int sat_assemble_input_f32(const float* bn, const float* f0, const float* spk, f
  * The plan carries every integer / scalar constant the reference derives from its option dict
  * (yaapt.py:815-886, :156-157, :190-204, :396-406, :686-688); the host computes it
  * (sa-toolkit_amd/f0.py) so that the rounding of those derivations is done once, in Python, the
- * way the reference does it.  lp / hp = biquad constants {b0, b1, b2, a0, a1/a0, a2/a0}.
+ * way the reference does it.  lp / hp = biquad constants {b0/a0, b1/a0, b2/a0, a0, a1/a0, a2/a0}
+ * (torchaudio's _lfilter normalises b and a by a0 first; FIR = fma chain in tap order, see csrc/yaapt.hip).
  *   wav [B][n]  ->  f0 [B][nframes] (Hz, 0 = unvoiced);  status [B] (device int32):
  *   0 ok, 1 = no voiced frame (the reference raises RuntimeError there), 2 = NCCF window
  *   invalid (the reference's assert N > 0).

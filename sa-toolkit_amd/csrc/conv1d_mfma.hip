@@ -1181,10 +1181,11 @@ static int launch_f16x3_k1(const ConvArgs& a, int B, hipStream_t s) {
   p.pp_total = p.pp_tiles_t * B;
   const size_t lds_bytes = (size_t)2 * SC * 4 * 128 * 16;
   auto kern = conv1d_f16x3_k1_kernel<SC>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};      // per device (one static per SC instantiation)
+  int dev;
+  if (attr_needed_on_current_device(attr_done, &dev)) {
     SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
+    attr_done_on_device(attr_done, dev);
   }
   dim3 grid(8 * p.co_tiles_g * ceil_div(p.pp_total, 8), 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);

@@ -14,6 +14,7 @@
 // Decision rules (strict/non-strict comparisons, first/last extremum on ties, stable ordering) are
 // kept exactly; f32 operation order is kept wherever the reference's order is defined by its source.
 #include <cmath>
+#include <type_traits>
 
 #include "common.h"
 
@@ -67,86 +68,240 @@ __device__ __forceinline__ float tmin(float a, float b) { return (a != a || b !=
 __device__ __forceinline__ int ulen(const int* __restrict__ U, int b, int k, int dflt) { return U ? U[b * 4 + k] : dflt; }
 
 // ------------------------------------------------------------------------------------------------
-// prefilter: zero-pad, (square), low-pass biquad -> clamp -> high-pass biquad -> clamp.
-// The FIR halves are lane-parallel on 64-sample chunks; the two IIR recursions are inherently
-// sequential (y[t] depends on y[t-1], y[t-2]) and keep the exact f32 order of the restated lfilter
-//   f = ((b2*x[t-2] + b1*x[t-1]) + b0*x[t]) / a0 ;  v = f - c2*y[t-2] ;  v = v - c1*y[t-1]
-// One block of two waves per (utterance, signal): wave 0 runs the low-pass on chunk i while wave 1
-// runs the high-pass on chunk i-1 (hand-off through a double-buffered LDS line), so the two
-// dependent chains overlap.  Inside a wave the 64 steps of a chunk are unrolled on wave-uniform
-// values and each lane then picks its own sample with a 6-level select tree.
+// prefilter: zero-pad, (square), low-pass biquad -> clamp -> high-pass biquad -> clamp   (yaapt.py:42-51).
+// torchaudio's lfilter order (third party, restated in oracle/biquad.py, order "torchaudio"):
+//   FIR   f[t] = fma(b0', x[t], fma(b1', x[t-1], b2' * x[t-2]))      b' = b / a0  (conv1d's FMA chain in tap order)
+//   IIR   v = f[t] - c2 * y[t-2];  v = v - c1 * y[t-1];  y[t] = v    c = a / a0   (multiply, subtract; no fma)
+//   out   clamp(y[t], -1, 1); the recursion itself runs on unclamped values
+// The recursion is sequential in t and its f32 rounding order is part of the result, so the only parallelism is
+// ACROSS chains: a chain = (utterance, signal in {x, x^2}), and a lane of the IIR waves owns one chain (one
+// wave-instruction advances 64 chains by one sample).  A block takes 32 utterances = 64 chains through a six-stage
+// software pipeline over tiles of 64 samples, one role per wave, one barrier per tile, the tile's LDS buffer
+// (row = chain, 68 floats: 16-byte rows, ds_read_b128 of 64 rows conflict-free) handed down the stages and
+// transformed IN PLACE:
+//   L  load 32 utterances (coalesced, registers one tile ahead), write rows x | x^2        lane = 4 samples of a row
+//   F1 low-pass FIR    (3 VALU per sample)                                                  lane = chain
+//   I1 low-pass IIR + clamp (sub, sub, 2 mul, clamp: the critical wave, ~18 cycles/sample)  lane = chain
+//   F2 high-pass FIR, I2 high-pass IIR + clamp                                              lane = chain
+//   S  store rows (zero past the chain's own padded length: the zero extension spec_track reads)
+// A workgroup's waves are dealt to the CU's four SIMDs cyclically (k and k + 4 share one), so the roles are
+// numbered to leave each IIR wave alone on its SIMD: waves 0 / 1 = I1 / I2, 2 / 3 = F1 / F2, 4 / 5 idle,
+// 6 = L (beside F1), 7 = S (beside F2; placement checked with s_getreg HW_ID).  Measured (s_memtime stamps per role,
+// 32 x 5 s): 2.2k cycles per tile in the IIR waves (34 cycles per sample: sub, sub, pk_mul — 8 issue cycles, no
+// gain over two v_mul —, clamp, plus the row's LDS traffic; a lone wave issues one VALU per ~4.2 cycles,
+// tools/valu_lat.hip), 2.0-2.5k in the others; 1 260 tiles = 1.25 ms at the 2.4 GHz the chip holds under this
+// one-CU kernel, for any batch up to 32 (round 1: one block of two waves per chain with wave-uniform recursions,
+// 1.7-2.5 ms, 64 blocks).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float iir_chunk(const float* __restrict__ f, float c1, float c2, float& y1, float& y2,
-                                           int lane) {
-  float r[64];
+constexpr int PF_T = 64;
+constexpr int PF_PITCH = 68;
+constexpr int PF_RING = 6;
+constexpr int PF_THREADS = 512;
+
+__device__ __forceinline__ void pf_fir_tile(float* __restrict__ row, float b0, float b1, float b2, float& x1, float& x2) {
+  float4 xq[PF_T / 4];
 #pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    float v = f[i] - c2 * y2;
-    v = v - c1 * y1;
-    y2 = y1;
-    y1 = v;
-    r[i] = v;
+  for (int q = 0; q < PF_T / 4; ++q) xq[q] = *reinterpret_cast<const float4*>(row + 4 * q);
+#pragma unroll
+  for (int q = 0; q < PF_T / 4; ++q) {
+    const float4 x = xq[q];
+    float4 f;
+    f.x = __builtin_fmaf(b0, x.x, __builtin_fmaf(b1, x1, b2 * x2));
+    f.y = __builtin_fmaf(b0, x.y, __builtin_fmaf(b1, x.x, b2 * x1));
+    f.z = __builtin_fmaf(b0, x.z, __builtin_fmaf(b1, x.y, b2 * x.x));
+    f.w = __builtin_fmaf(b0, x.w, __builtin_fmaf(b1, x.z, b2 * x.y));
+    x2 = x.z;
+    x1 = x.w;
+    *reinterpret_cast<float4*>(row + 4 * q) = f;
   }
-#pragma unroll
-  for (int w = 32; w >= 1; w >>= 1) {
-    const bool hi = (lane & w) != 0;
-#pragma unroll
-    for (int k = 0; k < w; ++k) r[k] = hi ? r[k + w] : r[k];
-  }
-  return r[0];
 }
 
-__global__ void __launch_bounds__(128) yaapt_prefilter_kernel(const float* __restrict__ wav, float* __restrict__ filt,
-                                                              const int* __restrict__ U, const Plan P) {
-  __shared__ __attribute__((aligned(16))) float s_f[2][64];   // per-wave FIR outputs feeding the recursion
-  __shared__ __attribute__((aligned(16))) float s_u[2][64];   // clamped low-pass chunks handed to wave 1
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int b = blockIdx.x, sig = blockIdx.y;
-  const float* w = wav + (size_t)b * P.n;
-  float* out = filt + ((size_t)b * 2 + sig) * P.Lz;
-  const float* k = wave == 0 ? P.lp : P.hp;
-  const float b0 = k[0], b1 = k[1], b2 = k[2], a0 = k[3], c1 = k[4], c2 = k[5];
-  float h1 = 0.f, h2 = 0.f;   // last two inputs of the previous chunk
-  float y1 = 0.f, y2 = 0.f;
-  const int n_b = ulen(U, b, 0, P.n), L_b = ulen(U, b, 1, P.L);
-  const int nchunks = (L_b + 63) / 64;
-  auto load_x = [&](int c) {   // padded (and squared) input sample of chunk c for this lane
-    float x = 0.f;
-    const int src = c * 64 + lane - P.pad;
-    if (c < nchunks && src >= 0 && src < n_b) x = w[src];
-    return sig ? x * x : x;
-  };
-  float x_next = wave == 0 ? load_x(0) : 0.f;
-  for (int it = 0; it <= nchunks; ++it) {
-    const int c = wave == 0 ? it : it - 1;        // chunk this wave works on
-    const bool live = c >= 0 && c < nchunks;
-    const int t = c * 64 + lane;
-    if (live) {
-      float x;
-      if (wave == 0) {
-        x = x_next;
-        x_next = load_x(c + 1);                   // in flight during this chunk's recursion
-      } else {
-        x = s_u[c & 1][lane];
-      }
-      float x1 = __shfl_up(x, 1, 64), x2 = __shfl_up(x, 2, 64);
-      if (lane == 0) { x1 = h1; x2 = h2; }
-      if (lane == 1) { x2 = h1; }
-      h1 = __shfl(x, 63, 64);
-      h2 = __shfl(x, 62, 64);
-      s_f[wave][lane] = ((b2 * x2 + b1 * x1) + b0 * x) / a0;
+// One step of the recursion.  State: p1 = c1*y[t-1], p2n = c2*y[t-1], d = f[t] - c2*y[t-2] (the first subtraction, taken
+// one step ahead: it does not depend on y[t-1], and in program order right behind `v = d - p1` it fills that
+// instruction's result latency instead of standing in front of it).  Dependent chain per sample: sub -> pk_mul.
+// The operations and their order per sample are exactly  v = f - c2*y2;  v = v - c1*y1.
+__device__ __forceinline__ float pf_iir_step(float f_next, float c1, float c2, float& p1, float& p2n, float& d) {
+  const float v = d - p1;
+  d = f_next - p2n;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f q = (v2f){c1, c2} * (v2f){v, v};      // one v_pk_mul_f32: the same two IEEE products
+  p1 = q.x;
+  p2n = q.y;
+  return fminf(fmaxf(v, -1.f), 1.f);
+}
+// `d` enters holding f[first sample of this tile] - c2*y[t-2] ... which needs this tile's first f: the caller passes
+// `dp2` = c2*y[t-2] pending from the previous tile instead, and the tile finishes the subtraction itself.
+__device__ __forceinline__ void pf_iir_tile(float* __restrict__ row, float c1, float c2, float& p1, float& p2n, float& dp2) {
+  // the whole row up front (64 registers): one LDS round trip per tile instead of one per group of reads
+  float4 fq[PF_T / 4];
+#pragma unroll
+  for (int q = 0; q < PF_T / 4; ++q) fq[q] = *reinterpret_cast<const float4*>(row + 4 * q);
+  float d = fq[0].x - dp2;
+#pragma unroll
+  for (int q = 0; q < PF_T / 4; ++q) {
+    const float4 f = fq[q];
+    float4 u;
+    u.x = pf_iir_step(f.y, c1, c2, p1, p2n, d);
+    u.y = pf_iir_step(f.z, c1, c2, p1, p2n, d);
+    u.z = pf_iir_step(f.w, c1, c2, p1, p2n, d);
+    if (q + 1 < PF_T / 4) {
+      u.w = pf_iir_step(fq[q + 1 < PF_T / 4 ? q + 1 : q].x, c1, c2, p1, p2n, d);
+    } else {                                    // last sample of the tile: the next f is not here yet
+      const float v = d - p1;
+      dp2 = p2n;                                // c2*y[t-1] of this sample = c2*y[t-2] of the next tile's first
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      const v2f qq = (v2f){c1, c2} * (v2f){v, v};
+      p1 = qq.x;
+      p2n = qq.y;
+      u.w = fminf(fmaxf(v, -1.f), 1.f);
     }
-    __syncthreads();
-    if (live) {
-      const float v = iir_chunk(s_f[wave], c1, c2, y1, y2, lane);
-      const float u = fminf(fmaxf(v, -1.f), 1.f);
-      if (wave == 0) s_u[c & 1][lane] = u;
-      else if (t < L_b) out[t] = u;
-    }
-    __syncthreads();
+    *reinterpret_cast<float4*>(row + 4 * q) = u;
   }
-  for (int t = L_b + (int)threadIdx.x; t < P.Lz; t += 128) out[t] = 0.f;  // zero extension read by spec_track
+}
+
+// VEC: rows of wav / filt are 16-byte aligned (n, pad, Lz multiples of 4): 16-byte global accesses.
+// Loads and stores go through buffer descriptors over the block's rows: a lane outside its row's valid range gets
+// an out-of-range offset (loads return 0, stores are dropped), so both roles are branch-free and the compiler
+// batches a tile's LDS reads and memory operations instead of one round trip per row.
+template <bool VEC>
+__global__ void __launch_bounds__(PF_THREADS) yaapt_prefilter_kernel(const float* __restrict__ wav, float* __restrict__ filt,
+                                                                     const int* __restrict__ U, const Plan P, int B) {
+  __shared__ __attribute__((aligned(16))) float ring[PF_RING][64 * PF_PITCH];
+  __shared__ int s_n[32], s_L[32];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int ub = blockIdx.x * 32;                       // first utterance of the block
+  const int rows = min(32, B - ub);
+  if (threadIdx.x < 32) {
+    const int b = ub + threadIdx.x;
+    s_n[threadIdx.x] = b < B ? ulen(U, b, 0, P.n) : 0;
+    s_L[threadIdx.x] = b < B ? ulen(U, b, 1, P.L) : 0;
+  }
+  __syncthreads();
+  // role -> pipeline stage
+  const int stage = wave == 6 ? 0 : wave == 2 ? 1 : wave == 0 ? 2 : wave == 3 ? 3 : wave == 1 ? 4 : wave == 7 ? 5 : -1;
+  const int ntiles = (P.Lz + PF_T - 1) / PF_T;
+  const float* kc = (wave == 0 || wave == 2) ? P.lp : P.hp;
+  const float kb0 = kc[0], kb1 = kc[1], kb2 = kc[2], c1 = kc[4], c2 = kc[5];
+  float x1 = 0.f, x2 = 0.f;                 // FIR history
+  float p1 = 0.f, p2n = 0.f, dp2 = 0.f;     // IIR history (products of zeros)
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(wav + (size_t)ub * P.n), 0, (unsigned)((size_t)rows * P.n * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(filt + (size_t)ub * 2 * P.Lz), 0, (unsigned)((size_t)rows * 2 * P.Lz * 4), 0x00020000);
+  const int rsub = lane >> 4, jq = lane & 15;
+  // per-lane row constants of the loader (NL rows per tile and lane) and of the storer (NS)
+  constexpr int NL = VEC ? 8 : 32, NS = VEC ? 16 : 64;
+  int l_n[NL], s_len[NS];
+  unsigned l_off[NL], s_off[NS];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int r = VEC ? i * 4 + rsub : i;
+    l_n[i] = stage == 0 ? s_n[r] : 0;
+    l_off[i] = r < rows ? (unsigned)r * (unsigned)P.n * 4u : OOB;            // OOB + a row offset stays out of range
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int c = VEC ? i * 4 + rsub : i;
+    s_len[i] = stage == 5 ? s_L[c >> 1] : 0;
+    s_off[i] = (c >> 1) < rows ? (unsigned)c * (unsigned)P.Lz * 4u : OOB;     // no such chain: nothing stored
+  }
+  int n_min = P.n, L_min = P.L;          // over the block's utterances: tiles inside them need no per-lane masks
+  for (int r = 0; r < rows; ++r) {
+    n_min = min(n_min, s_n[r]);
+    L_min = min(L_min, s_L[r]);
+  }
+  constexpr int NPRE = VEC ? 8 : 32;
+  typedef typename std::conditional<VEC, float4, float>::type pre_t;
+  constexpr int PD = 2;                  // tiles in flight in the loader's registers (two tile periods of latency)
+  pre_t pre[PD][NPRE];
+  auto load_tile = [&](int tile, pre_t* pre) {
+    const int src = tile * PF_T + (VEC ? 4 * jq : lane) - P.pad;   // VEC: a multiple of 4, a quad starts inside [0, n) or outside
+    const bool interior = tile * PF_T - P.pad >= 0 && tile * PF_T + PF_T - P.pad <= n_min;     // wave-uniform
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < NPRE; ++i) {
+        const unsigned off = l_off[i] + (unsigned)src * 4u;
+        if constexpr (VEC) pre[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+        else pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, off, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPRE; ++i) {
+        const unsigned off = (tile < ntiles && src >= 0 && src < l_n[i]) ? l_off[i] + (unsigned)src * 4u : OOB;
+        if constexpr (VEC) {
+          float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+          if (src + 1 >= l_n[i]) v.y = 0.f;      // ragged tail inside the row pitch
+          if (src + 2 >= l_n[i]) v.z = 0.f;
+          if (src + 3 >= l_n[i]) v.w = 0.f;
+          pre[i] = v;
+        } else {
+          pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, off, 0, 0));
+        }
+      }
+    }
+  };
+  if (stage == 0) {
+#pragma unroll
+    for (int k = 0; k < PD; ++k) load_tile(k, pre[k]);
+  }
+  auto loader = [&](int tile, float* buf, pre_t* pk) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      if constexpr (VEC) {
+        const int r = i * 4 + rsub;
+        const float4 v = pk[i];
+        *reinterpret_cast<float4*>(buf + (2 * r) * PF_PITCH + 4 * jq) = v;
+        *reinterpret_cast<float4*>(buf + (2 * r + 1) * PF_PITCH + 4 * jq) = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+      } else {
+        buf[(2 * i) * PF_PITCH + lane] = pk[i];
+        buf[(2 * i + 1) * PF_PITCH + lane] = pk[i] * pk[i];
+      }
+    }
+    load_tile(tile + PD, pk);              // the same registers: lands during the next PD tile periods
+  };
+  for (int it = 0; it < ntiles + PF_RING - 1; ++it) {
+    const int tile = it - stage;
+    if (stage >= 0 && tile >= 0 && tile < ntiles) {
+      float* buf = ring[tile % PF_RING];
+      if (stage == 0) {
+        switch (tile & (PD - 1)) {          // compile-time register set per case
+          case 0: loader(tile, buf, pre[0]); break;
+          default: loader(tile, buf, pre[1]); break;
+        }
+      } else if (stage == 1 || stage == 3) {
+        pf_fir_tile(buf + lane * PF_PITCH, kb0, kb1, kb2, x1, x2);
+      } else if (stage == 2 || stage == 4) {
+        pf_iir_tile(buf + lane * PF_PITCH, c1, c2, p1, p2n, dp2);
+      } else {
+        typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+        const int t = tile * PF_T + (VEC ? 4 * jq : lane);   // VEC: Lz % 4 == 0, a quad is inside or outside as a whole
+        const bool interior = tile * PF_T + PF_T <= L_min;   // wave-uniform (L_min <= L <= Lz)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const unsigned off = (interior || t < P.Lz) ? s_off[i] + (unsigned)t * 4u : OOB;
+          if constexpr (VEC) {
+            float4 v = *reinterpret_cast<const float4*>(buf + (i * 4 + rsub) * PF_PITCH + 4 * jq);
+            if (!interior) {
+              if (t + 0 >= s_len[i]) v.x = 0.f;         // zero extension past the chain's own padded length
+              if (t + 1 >= s_len[i]) v.y = 0.f;
+              if (t + 2 >= s_len[i]) v.z = 0.f;
+              if (t + 3 >= s_len[i]) v.w = 0.f;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), frs, off, 0, 0);
+          } else {
+            float v = buf[i * PF_PITCH + lane];
+            if (!interior && t >= s_len[i]) v = 0.f;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), frs, off, 0, 0);
+          }
+        }
+      }
+    }
+    // LDS-only barrier: __syncthreads() also drains vmcnt, i.e. it would wait every tile for the loader's prefetch
+    // and for the storer's write acknowledgements
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -923,16 +1078,20 @@ static int yaapt_run(const sat_yaapt_plan* plan, const float* wav, const int32_t
   const float2* tw = (const float2*)twiddle;
   SAT_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
 
-  hipLaunchKernelGGL(yaapt_prefilter_kernel, dim3(B, 2), dim3(128), 0, s, wav, filt, U, P);
+  const bool pf_vec = (P.n % 4 == 0) && (P.pad % 4 == 0) && (P.Lz % 4 == 0) && (((uintptr_t)wav & 15) == 0) && (((uintptr_t)filt & 15) == 0);
+  SAT_REQUIRE((size_t)32 * P.n * 4 < ((size_t)1 << 31) && (size_t)64 * P.Lz * 4 < ((size_t)1 << 31), "yaapt: utterance too long for the prefilter's 31-bit row offsets");
+  if (pf_vec) hipLaunchKernelGGL(yaapt_prefilter_kernel<true>, dim3((B + 31) / 32), dim3(PF_THREADS), 0, s, wav, filt, U, P, B);
+  else hipLaunchKernelGGL(yaapt_prefilter_kernel<false>, dim3((B + 31) / 32), dim3(PF_THREADS), 0, s, wav, filt, U, P, B);
   SAT_LAUNCH_CHECK("yaapt_prefilter_kernel");
   const size_t fft_lds = 2 * FFT_N * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};      // per device
+  int dev;
+  if (attr_needed_on_current_device(attr_done, &dev)) {
     SAT_HIP(hipFuncSetAttribute((const void*)yaapt_nlfer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds));
     SAT_HIP(hipFuncSetAttribute((const void*)yaapt_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds));
     SAT_HIP(hipFuncSetAttribute((const void*)yaapt_spec_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SAT_HIP(hipFuncSetAttribute((const void*)yaapt_refine_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_done_on_device(attr_done, dev);
   }
   hipLaunchKernelGGL(yaapt_nlfer_kernel, dim3(P.nframes, B), dim3(FFT_THREADS), fft_lds, s, filt, hann, tw, e_raw, U, P);
   SAT_LAUNCH_CHECK("yaapt_nlfer_kernel");

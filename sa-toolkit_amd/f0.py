@@ -39,8 +39,10 @@ class YaaptPlan(C.Structure):
 
 def biquad_constants(kind, sample_rate, cutoff, Q=0.707):
     """RBJ biquad as torchaudio.functional.{lowpass,highpass}_biquad computes it (f32 tensors), then
-    the normalisation lfilter applies: {b0, b1, b2, a0, a1/a0, a2/a0}.  torchaudio is third-party to
-    the reference (yaapt.py:46-47) and absent here: restated from its published algorithm."""
+    the normalisation `_lfilter` applies FIRST to both coefficient vectors: {b0/a0, b1/a0, b2/a0, a0, a1/a0, a2/a0}
+    (f32 divisions; a0 itself is unused by the kernel).  torchaudio is third-party to the reference
+    (yaapt.py:46-47) and absent here: restated from its published algorithm, the FIR order a tested decision
+    (oracle/biquad.py, tests/golden/fx_biquad_order.json)."""
     f32 = torch.float32
     w0 = 2 * math.pi * torch.as_tensor(cutoff, dtype=f32) / sample_rate
     alpha = torch.sin(w0) / 2 / torch.as_tensor(Q, dtype=f32)
@@ -52,7 +54,8 @@ def biquad_constants(kind, sample_rate, cutoff, Q=0.707):
         b1 = -1 - torch.cos(w0)
     a0, a1, a2 = 1 + alpha, -2 * torch.cos(w0), 1 - alpha
     v = np.array([float(b0), float(b1), float(b0), float(a0), float(a1), float(a2)], dtype=np.float32)
-    return [float(v[0]), float(v[1]), float(v[2]), float(v[3]), float(np.float32(v[4] / v[3])), float(np.float32(v[5] / v[3]))]
+    return [float(np.float32(v[0] / v[3])), float(np.float32(v[1] / v[3])), float(np.float32(v[2] / v[3])), float(v[3]),
+            float(np.float32(v[4] / v[3])), float(np.float32(v[5] / v[3]))]
 
 
 def make_plan(n, opts):

@@ -118,3 +118,28 @@ def test_ragged_batch_equals_per_utterance_tracks():
     # uniform lengths through the ragged entry point = the batch entry point
     u = synthetic.harm_batch([0, 1, 2], 32000).to("cuda")
     assert torch.equal(f0_hip.yaapt_ragged(u, [32000] * 3, opts), f0_hip.yaapt(u, opts))
+
+
+@pytest.mark.parametrize("B,n", [(1, 8000), (3, 16123), (2, 31999), (33, 4800), (32, 16000)])
+def test_prefilter_bit_identical_to_the_oracle_biquads(B, n):
+    """row a18: the band-limited signals (x and x^2 through low-pass -> clamp -> high-pass -> clamp) of the lane-per-chain
+    pipeline kernel equal oracle/biquad.py (torchaudio's order: b / a0 first, FIR as conv1d's FMA chain, recursion as
+    multiply-subtract) on every sample; aligned (16-byte) and unaligned row paths, one and two blocks of 32 utterances;
+    the zero extension past the padded length is zero"""
+    from oracle import biquad
+    from satools_amd import f0 as f0_hip
+    from satools_amd import synthetic
+    seeds = list(range(40, 40 + B))
+    wav = synthetic.harm_batch(seeds, n)
+    if B > 2:
+        wav[1] = (wav[1] * 40).clamp(-1, 1)                          # a clipped utterance: exercises the clamps
+    _, aux = f0_hip.yaapt(wav.to(DEV), OPTS, return_aux=True)
+    filt = aux["filt"].cpu().numpy()                                 # [B, 2, Lz]
+    pad = (filt.shape[2] - n) // 2 if False else 280
+    L = n + 2 * pad
+    for b in sorted(set([0, 1 % B, B // 2, B - 1])):
+        x = np.concatenate([np.zeros(pad, np.float32), wav[b].numpy(), np.zeros(pad, np.float32)])
+        for sig, v in ((0, x), (1, x * x)):
+            ref = biquad.band_limit(v)
+            assert np.array_equal(filt[b, sig, :L], ref), (b, sig, int((filt[b, sig, :L] != ref).sum()))
+            assert not filt[b, sig, L:].any()
