@@ -1,17 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark of the anonymize / model.convert() hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" = one `model.convert` over one batch of 32 synthetic 5 s @ 16 kHz utterances per rank
-(BASELINE.json configs[1], tag hifigan_bn_tdnnf_600h_vq_48_v1), inputs resident in HBM, followed
-for N > 1 by the RCCL all-gather of the anonymized waveforms (weak scaling: per-GPU work fixed).
-Prints ONE JSON line on rank 0.
+A "step" = one `model.convert` over one batch of 32 synthetic 5 s @ 16 kHz utterances per rank, everything on
+the path (YAAPT F0, bottleneck extractor, one-hot, generator), inputs resident in HBM.  Rank 0 prints one JSON
+line per measured BASELINE.json config; the LAST line is the headline (configs[1]: tag
+hifigan_bn_tdnnf_600h_vq_48_v1) the driver records, the lines before it are the other configs:
+
+  N = 1   configs[2] (wav2vec2 tag), configs[3] (wav2vec2 tag + f0-transformation=quant_16_awgn_2), then the
+          headline; every line carries its own `roofline` and `cpu_baseline`.
+  N > 1   one process per GPU under torch.distributed (RCCL).  `python bench.py --gpus N` typed as is starts
+          `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (the parent never
+          touches the GPU) and relays its output and exit code; under the driver's own torch.distributed.run
+          launch the ranks are used as they are.  Workload per line = the sharded job of SURVEY §8(d)/(e):
+          N x K x 32 utterances, contiguous shards of K x 32 per rank, batches of 32 in index order
+          (satools_amd.dist.convert_sharded), ONE all_gather_into_tensor of the [K*32, 1, 80001] shards at the
+          end, inside the timed region.  First line = BASELINE configs[4] (wav2vec2 tag; K = 16 at N = 8 is exactly
+          its 4096 utterances), last line = the headline tag through the same code (weak scaling: the per-GPU
+          work is fixed, so the driver's N = 1, 2, 4, 8 values are comparable).
+
+The CPU leg (`cpu_baseline`, rank 0 at N = 1 only) times the oracle — a port of the reference's PyTorch CPU path —
+on a bounded sample, at 1 thread (the reference's own setting, satools/satools/hifigan/yaapt.py:27) and at the
+host's physical core count.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -23,51 +41,380 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 TAG = "hifigan_bn_tdnnf_600h_vq_48_v1"
+TAG_W2V2 = "hifigan_bn_tdnnf_wav2vec2_vq_48_v1"
 BATCH = 32
 N_SAMPLES = 80000
 UTT_SECONDS = 5.0
-# algorithmic work per 5 s utterance (SURVEY §8d / DESIGN.md): generator 40.43 GMAC
-GEN_FLOP_PER_UTT = 80.86e9
-GEN_BYTES_PER_UTT = 731.4e6      # per-layer streaming model of the generator
+METRIC = "anonymized audio seconds per wall-clock second (real-time factor), 5 s @ 16 kHz utterances"
+UNIT = "x real-time (audio s / wall s)"
+# algorithmic work per 5 s utterance (SURVEY §8d / DESIGN.md §3)
+GEN_FLOP_PER_UTT = 80.86e9          # generator: 40.43 GMAC
+GEN_BYTES_PER_UTT = 731.4e6         # per-layer streaming model of the generator
+W2V2_FLOP_PER_UTT = 185.5e9 + 0.92e9   # wav2vec2-large 92.73 GMAC + TDNNF tail 0.46 GMAC
 PEAK_F32_MFMA_TFLOPS = 157.3
-PEAK_F16_MFMA_TFLOPS = 2500.0    # dense f16/bf16 MFMA (MI355X_MICROARCH.md); split-f16 issues 3 MFMA products per product
+PEAK_F16_MFMA_TFLOPS = 2500.0       # dense f16/bf16 MFMA (MI355X_MICROARCH.md); split-f16 issues 3 MFMA products per product
 PEAK_HBM_TBS = 8.0
+F0_OPTS = {"frame_length": 35.0, "frame_space": 20.0, "nccf_thresh1": 0.25, "tda_frame_length": 25.0}
 
 
-def analytic_f0(seeds, frames=250):
-    """F0 track of the `harm` utterances at the YAAPT frame centres (0 where the envelope is off);
-    used while F0 is handed over through set_f0 (the anonymize pipeline's hand-off)"""
-    import math
-    import torch
-    t = (torch.arange(frames, dtype=torch.float64) * 320) / 16000.0
-    rows = []
-    for s in seeds:
-        f0 = (100 + 5 * (s % 16)) + 60 * torch.sin(2 * math.pi * 0.7 * t)
-        env = (torch.sin(2 * math.pi * 1.5 * t) > -0.3).to(torch.float64)
-        rows.append((f0 * env).to(torch.float32))
-    return torch.stack(rows)
+# ---------------------------------------------------------------------------------------------------------
+# CPU leg
+# ---------------------------------------------------------------------------------------------------------
+def host_cpu():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return model, int(cores)
 
 
-def cpu_baseline(state, spk, seeds):
-    """the CPU oracle (a port of the reference's PyTorch path: YAAPT loop over the batch, fbank,
-    TDNNF-VQ, generator) timed on the host cores over a bounded sample of the same workload"""
+def cpu_baseline(tag, f0_transformation, spk, n_utt, runs_1, runs_n, n_utt_1=None, budget_note=""):
+    """the CPU oracle (a port of the reference's PyTorch path: serial YAAPT loop over the batch, fbank / wav2vec2,
+    TDNNF-VQ, generator) timed on the host cores over a bounded sample of the same workload: one convert() batch of
+    `n_utt` utterances, median of `runs_*` runs, at 1 thread and at the physical core count"""
     import torch
     from oracle import convert as oconv
+    from oracle import f0 as of0
     from oracle import yaapt as oyaapt
+    from satools_amd import f0_transforms, synthetic
+    state, _ = synthetic.checkpoint(tag)
+    sd = state["base_model_state_dict"]
+    w2 = tag == TAG_W2V2
+    omodel = None
+    if w2:
+        from oracle import wav2vec2 as ow
+        omodel = ow.Wav2Vec2Restated(24)
+        pfx = "bn_extractor.preprocessor."
+        omodel.load_state_dict({k[len(pfx):]: v for k, v in sd.items() if k.startswith(pfx)})
+        omodel.eval()
+    quant = f0_transforms.parse_quant_bins(f0_transformation) if "quant" in f0_transformation else 0
+    db = f0_transforms.parse_awgn_db(f0_transformation) if "awgn" in f0_transformation else None
+
+    def once(seeds):
+        wav = synthetic.harm_batch(seeds)
+        tg = synthetic.targets(spk, seeds)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            f0 = oyaapt.yaapt(wav, F0_OPTS)
+            t1 = time.perf_counter()
+            noise = f0_transforms.draw_awgn((len(seeds), 1, f0.shape[1]), db) if db is not None else None
+            if w2:
+                oconv.convert_w2v2(sd, spk, wav, tg, f0, quant, noise, model=omodel)
+            else:
+                oconv.convert_fbank(sd, spk, wav, tg, f0, quant, noise)
+            t2 = time.perf_counter()
+        return t2 - t0, t1 - t0
+
+    model_name, cores = host_cpu()
+    keep = torch.get_num_threads()
+    out = {"unit": UNIT, "kind": "port", "cpu_model": model_name}
+    try:
+        res = {}
+        for label, threads, runs, n in (("threads1", 1, runs_1, n_utt_1 or n_utt), ("threadsN", cores, runs_n, n_utt)):
+            torch.set_num_threads(threads)
+            ts = [once(list(range(n))) for _ in range(runs)]
+            dt = statistics.median(t[0] for t in ts)
+            res[label] = {"value": round(n * UTT_SECONDS / dt, 3), "threads": threads, "utterances": n, "runs": runs,
+                          "seconds": round(dt, 2), "yaapt_seconds": round(statistics.median(t[1] for t in ts), 2)}
+    finally:
+        torch.set_num_threads(keep)
+    out.update(res)
+    # `value` / `cores` = the faster of the two settings (what the host can do), both kept above
+    best = max(("threads1", "threadsN"), key=lambda k: res[k]["value"])
+    out["value"], out["cores"] = res[best]["value"], res[best]["threads"]
+    out["sample"] = (f"one convert() batch, torch CPU f32: {res['threads1']['utterances']} x 5 s at 1 thread (the reference's "
+                     f"setting, yaapt.py:27; median of {runs_1}) = {res['threads1']['value']} x RT in {res['threads1']['seconds']} s; "
+                     f"{res['threadsN']['utterances']} x 5 s at {cores} threads (physical cores; median of {runs_n}) = "
+                     f"{res['threadsN']['value']} x RT in {res['threadsN']['seconds']} s" + budget_note)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GPU legs
+# ---------------------------------------------------------------------------------------------------------
+def load(tag, f0_transformation, dev):
+    import satools_amd
+    m = satools_amd.load_model("synthetic:" + tag, option_args={"f0_transformation": f0_transformation} if f0_transformation else None)
+    m.to(dev)
+    m.eval()
+    return m
+
+
+def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each):
+    """N = 1 mode: K independent convert() batches, `jobs` deep in flight on separate HIP streams (the reference's
+    jobs_per_compute_device, satools/satools/bin/anonymize:85-93).  Returns (seconds, setup_steps)."""
+    import torch
     from satools_amd import synthetic
-    wav = synthetic.harm_batch(seeds)
-    tg = synthetic.targets(spk, seeds)
-    cores = torch.get_num_threads()
-    opts = {"frame_length": 35.0, "frame_space": 20.0, "nccf_thresh1": 0.25, "tda_frame_length": 25.0}
+    seeds = [rank * BATCH + i for i in range(BATCH)]
+    wav = synthetic.harm_batch(seeds).to(dev)
+    targets = synthetic.targets(model.spk, seeds)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(jobs)]
+    # every job stream owns its workspaces and must have run (and allocated) once before the timed region starts: when
+    # --warmup is smaller than the number of job streams, the missing runs are done as untimed set-up steps first
+    setup_steps = max(0, jobs - warmup)
+    n = [0]
+
+    def step():
+        s = streams[n[0] % jobs]
+        n[0] += 1
+        if seed_before_each:
+            torch.manual_seed(1234)          # SURVEY §8(d) C4: the awgn draw of every batch is reproducible
+        with torch.cuda.stream(s):
+            return model.convert(wav, target=targets)
+
+    for _ in range(setup_steps + warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, setup_steps
+
+
+def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each):
+    """N > 1 mode (and SAT_BENCH_FORCE_PG=1 with one rank): world x steps x 32 utterances sharded through
+    satools_amd.dist.convert_sharded, one all-gather of the shards at the end, all inside the timed region.
+    Returns (seconds [max over ranks], all-gather ms [max over ranks], ranks seen, setup_steps)."""
+    import torch
+    import torch.distributed as dist
+    from satools_amd import dist as sdist
+    from satools_amd import synthetic
+    n_items = world * steps * BATCH
+    lo, hi = sdist.shard_bounds(n_items, rank, world)
+    # this rank's shard of utterances, resident in HBM (seeds = global utterance indices)
+    wav = torch.cat([synthetic.harm_batch(list(range(s, e))) for s, e in sdist.batches(lo, hi, BATCH)], 0).to(dev)
+    targets = synthetic.targets(model.spk, list(range(lo, hi)))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(jobs)]
+    local = torch.empty(hi - lo, 1, N_SAMPLES + 1, dtype=torch.float32, device=dev)
+    setup_steps = max(0, jobs - warmup)
+    cur = torch.cuda.current_stream(dev)
+    n = [0]
+
+    def convert_fn(a, b):
+        s = streams[n[0] % jobs]
+        n[0] += 1
+        if seed_before_each:
+            torch.manual_seed(1234)
+        with torch.cuda.stream(s):
+            y = model.convert(wav[a - lo:b - lo], target=targets[a - lo:b - lo])
+            local[a - lo:b - lo].copy_(y.reshape(b - a, 1, -1))
+        return None
+
+    def join_streams():
+        for s in streams:
+            cur.wait_stream(s)
+        ev[0].record(cur)
+
+    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    for i in range(setup_steps + warmup):
+        convert_fn(lo + (i % steps) * BATCH, lo + (i % steps) * BATCH + BATCH)
+    join_streams()
+    sdist.all_gather_rows(local, n_items)                 # first collective: RCCL builds its communicator / rings here
+    ranks_seen = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(ranks_seen, torch.tensor([rank], dtype=torch.int64, device=dev))
+    ranks_seen = [int(t.item()) for t in ranks_seen]
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = sdist.convert_sharded(convert_fn, n_items, BATCH, gather=True, local_out=local, before_gather=join_streams)
+    ev[1].record(cur)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    assert out.shape == (n_items, 1, N_SAMPLES + 1)
+    t = torch.tensor([dt, ev[0].elapsed_time(ev[1])], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0].item()), float(t[1].item()), ranks_seen, setup_steps
+
+
+def time_events(fn, reps, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def roofline_generator(model, dev, reps):
+    """the generator (dominant on the fbank tag): all launches of one forward timed with events on the launch
+    stream, and its dominant kernel alone"""
+    import torch
+    from satools_amd import ops, packing, synthetic
+    seeds = list(range(BATCH))
+    wav = synthetic.harm_batch(seeds).to(dev)
+    targets = synthetic.targets(model.spk, seeds)
     with torch.no_grad():
-        t0 = time.perf_counter()
-        f0 = oyaapt.yaapt(wav, opts)
-        t1 = time.perf_counter()
-        oconv.convert_fbank(state["base_model_state_dict"], spk, wav, tg, f0)
-        dt = time.perf_counter() - t0
-    return {"value": round(len(seeds) * UTT_SECONDS / dt, 3), "unit": "x real-time (audio s / wall s)", "cores": cores,
-            "kind": "port", "sample": f"{len(seeds)} utterances x 5 s in one convert() batch, torch CPU f32, {cores} "
-                                      f"threads ({dt:.1f} s, of which YAAPT {t1 - t0:.1f} s)"}
+        f0n = model.get_f0(wav)
+        bn = model.get_bn(wav)
+        spk = model.get_spk_id(wav, targets)
+        ops.f0_norm_transform_(f0n)
+        x = ops.assemble_input(bn, f0n, spk.to(dev, torch.float32).contiguous(), spk.shape[1])
+        gen_ms = time_events(lambda: model.hifigan(x), reps)
+    split = model.hifigan.precision == "f16x3"
+    dom = None
+    if split:
+        C, T, k, d = 256, 1250, 11, 5
+        g = torch.Generator(device="cpu").manual_seed(0)
+        xk = torch.randn(BATCH, C, T, generator=g).to(dev)
+        wk = packing.pack_conv_weight_f16x3((torch.randn(C, C, k, generator=g) * 0.02).to(dev))
+        bk = torch.zeros(C, device=dev)
+        xs, rs, ys = ops.act_split(xk, 0.1), ops.act_split(xk * 0.5, 0.1), ops.split_like(BATCH, C, T, dev)
+        run = lambda: ops.conv1d(xk, wk, C, k, bias=bk, dilation=d, pad_left=(k * d - d) // 2, mode=1, x_split=xs,
+                                 y_split=ys, y_split_slope=0.1, res_split=rs, res_split_slope=0.1, no_y=True, out=xk)
+        us = time_events(run, 20, warm=3) * 1e3
+        flop = 2.0 * BATCH * C * C * k * T
+        dom = {"name": "conv1d_f16x3_planes_kernel, 11 taps, C=256, T=1250, dilation 5, batch 32 (18 launches per forward)",
+               "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
+               "frac": round(flop / us / 1e6 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)}
+    achieved = GEN_FLOP_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
+    peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+    hbm = GEN_BYTES_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
+    traffic, note = None, None
+    for name in ("r02_generator_traffic.json", "r01o_generator_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))["per_forward"]
+            # gfx950 counts a 128-byte request of a 16-byte-per-lane load as 64 bytes in FETCH_SIZE: these kernels
+            # issue such loads, so the fetch figure is doubled (MI355X_MICROARCH.md, HBM)
+            traffic = (tj["fetch_GB_doubled"] + tj["write_GB"]) * 1e9
+            note = (f"HBM bytes per generator forward (batch 32), separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                    f"(profiles/{name}): fetch {tj['fetch_GB_doubled']} GB (FETCH_SIZE x 2, the gfx950 wide-load correction) "
+                    f"+ write {tj['write_GB']} GB; per-layer streaming model {tj['algorithmic_GB_per_layer_model']} GB")
+            break
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note,
+            "kernel": ("split-f16 conv family of the generator" if split else "conv1d_mfma_kernel (exact f32)")
+                      + f": all launches of one forward, {gen_ms:.3f} ms per batch of {BATCH}",
+            "dominant_kernel": dom,
+            "arithmetic": ("f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 "
+                           "MFMA peak / 3" if split else "exact f32 MFMA"),
+            "algorithmic_flop_per_launch_group": GEN_FLOP_PER_UTT * BATCH,
+            "hbm_model": {"achieved_TBps": round(hbm, 3), "peak_TBps": PEAK_HBM_TBS, "frac": round(hbm / PEAK_HBM_TBS, 4),
+                          "bytes_per_launch_group": GEN_BYTES_PER_UTT * BATCH}}
+
+
+def roofline_w2v2(model, dev, reps):
+    """the wav2vec2 bottleneck extractor (dominant on the wav2vec2 tag, ~2/3 of a step): all its launches timed with
+    events, and its dominant kernel (the 1x1 GEMM of the 146 Linear layers) alone on the FFN shape"""
+    import torch
+    from satools_amd import ops, packing, synthetic
+    wav = synthetic.harm_batch(list(range(BATCH))).to(dev)
+    with torch.no_grad():
+        ext_ms = time_events(lambda: model.get_bn(wav), reps)
+        cin, cout, T = 1024, 4096, 249
+        g = torch.Generator(device="cpu").manual_seed(0)
+        x = torch.randn(BATCH, cin, T, generator=g).to(dev)
+        w = packing.pack_conv_weight_f16x3((torch.randn(cout, cin, 1, generator=g) * 0.03).to(dev))
+        b = torch.zeros(cout, device=dev)
+        xs, ys = ops.act_split(x, 1.0), ops.split_like(BATCH, cout, T, dev)
+        run = lambda: ops.conv1d(x, w, cout, 1, bias=b, gelu=True, mode=1, x_split=xs, y_split=ys, y_split_slope=1.0, no_y=True)
+        us = time_events(run, 20, warm=3) * 1e3
+    flop = 2.0 * BATCH * T * cin * cout
+    peak = PEAK_F16_MFMA_TFLOPS / 3.0
+    achieved = W2V2_FLOP_PER_UTT * BATCH / (ext_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel": f"wav2vec2-large + TDNNF tail bottleneck extractor (get_bn): all launches, {ext_ms:.3f} ms per batch of {BATCH}",
+            "dominant_kernel": {"name": "conv1d_f16x3_k1_kernel (1x1 GEMM on split planes), FFN 1024 -> 4096 + GELU, 249 frames, batch 32",
+                                "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
+                                "frac": round(flop / us / 1e6 / peak, 4)},
+            "arithmetic": "f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 MFMA peak / 3",
+            "algorithmic_flop_per_launch_group": W2V2_FLOP_PER_UTT * BATCH}
+
+
+def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu, cpu_args):
+    """measure one BASELINE config on the loaded device; returns the JSON object (rank 0) or None"""
+    model = load(tag, f0_tr, dev)
+    seed_each = "awgn" in f0_tr
+    extra = {}
+    if use_pg:
+        dt, ag_ms, ranks, setup = run_sharded(model, dev, rank, world, steps, warmup, a.jobs, seed_each)
+        extra = {"all_gather_ms": round(ag_ms, 3), "ranks_seen_by_rccl": ranks,
+                 "utterances": world * steps * BATCH,
+                 "all_gather": f"one all_gather_into_tensor of [{steps * BATCH}, 1, {N_SAMPLES + 1}] f32 per rank "
+                               f"({steps * BATCH * (N_SAMPLES + 1) * 4 / 1e6:.0f} MB) at the end, inside the timed region"}
+    else:
+        dt, setup = run_steps(model, dev, rank, steps, warmup, a.jobs, seed_each)
+    if rank != 0:
+        return None
+    w2 = tag == TAG_W2V2
+    reps = max(3, min(steps, 10))
+    roof = roofline_w2v2(model, dev, reps) if w2 else roofline_generator(model, dev, reps)
+    split = model.hifigan.precision == "f16x3"
+    out = {"metric": METRIC, "value": round(world * steps * BATCH * UTT_SECONDS / dt, 2), "unit": UNIT, "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (matrix products as split-f16 x3 with f32 accumulate)" if split else "f32", "data": "synthetic",
+           "config": dict({"workload": f"{name}: {tag}{'+f0-transformation=' + f0_tr if f0_tr else ''} model.convert, "
+                                       f"batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
+                           "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
+                           "f0": "YAAPT computed on-path on the GPU inside convert()", "jobs_per_gpu": a.jobs,
+                           "setup_steps": setup,
+                           "parallelism": f"dp{world}" + (" sharded (contiguous shards, batches of 32 in index order)" if use_pg else "")},
+                          **extra),
+           "roofline": roof}
+    if want_cpu:
+        out["cpu_baseline"] = cpu_baseline(tag, f0_tr, model.spk, **cpu_args)
+    del model
+    return out
+
+
+def dryrun(a, rank, world):
+    """SAT_BENCH_DRYRUN=1 (CPU tests): the launch plumbing and the sharded job without a GPU — gloo ranks, the same
+    convert_sharded call as run_sharded (preallocated shard buffer filled by the callback, pre-gather hook, one
+    all-gather), a stand-in convert() whose rows carry their global utterance index"""
+    import torch
+    import torch.distributed as dist
+    from satools_amd import dist as sdist
+    dist.init_process_group("gloo")
+    assert dist.get_world_size() == world == a.gpus, (dist.get_world_size(), world, a.gpus)
+    n_items = world * a.steps * BATCH
+    lo, hi = sdist.shard_bounds(n_items, rank, world)
+    local = torch.full((hi - lo, 1, 5), -1.0)
+    calls, hooked = [], []
+
+    def convert_fn(s, e):
+        calls.append((s, e))
+        local[s - lo:e - lo] = torch.arange(s, e, dtype=torch.float32).view(-1, 1, 1)
+
+    t0 = time.perf_counter()
+    out = sdist.convert_sharded(convert_fn, n_items, BATCH, gather=True, local_out=local, before_gather=lambda: hooked.append(1))
+    dt = time.perf_counter() - t0
+    assert hooked == [1] and calls == sdist.batches(lo, hi, BATCH) and len(calls) == a.steps
+    assert out.shape == (n_items, 1, 5) and torch.equal(out[:, 0, 0], torch.arange(n_items, dtype=torch.float32))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": round(n_items * UTT_SECONDS / dt, 2), "unit": UNIT, "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "data": "dry run (CPU, gloo, stand-in convert)",
+                          "config": {"workload": "dry run of the sharded job", "utterances": n_items, "parallelism": f"dp{world}"}}), flush=True)
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -76,12 +423,23 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the lines of the other BASELINE configs")
     ap.add_argument("--jobs", type=int, default=4,
                     help="convert() calls in flight per GPU, each on its own HIP stream (the reference's "
                          "jobs_per_compute_device, satools/satools/bin/anonymize:85-93)")
-    ap.add_argument("--tag", default=TAG, help="model tag (default: the headline config; the wav2vec2 tag is BASELINE configs[2])")
-    ap.add_argument("--f0-transformation", default="", help="e.g. quant_16_awgn_2 (BASELINE configs[3])")
+    ap.add_argument("--tag", default=None, help="measure only this tag (one line)")
+    ap.add_argument("--f0-transformation", default="", help="with --tag: e.g. quant_16_awgn_2")
     a = ap.parse_args()
+    a.jobs = max(1, a.jobs)
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python bench.py --gpus N`: start the ranks as a CHILD process (this parent has not touched the GPU
+        # and never does — no exec of a process that initialised HIP) and relay its output and exit code
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -89,174 +447,52 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        print(f"bench.py --gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus}",
-              file=sys.stderr)
+    if os.environ.get("SAT_BENCH_DRYRUN") == "1":
+        return dryrun(a, rank, world)
+    if a.gpus != world and not (a.gpus == 1 and world == 1):
+        print(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # SAT_BENCH_FORCE_PG=1: take the RCCL path (process group, all-gather per step) with one rank too, to check it on a
-    # 1-GPU box (launch under torch.distributed.run --nproc-per-node 1)
+    # SAT_BENCH_FORCE_PG=1: take the sharded RCCL path with one rank too (checked on a 1-GPU box)
     use_pg = world > 1 or os.environ.get("SAT_BENCH_FORCE_PG") == "1"
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    import satools_amd
-    from satools_amd import synthetic
-
-    tag = a.tag
-    model = satools_amd.load_model("synthetic:" + tag, option_args={"f0_transformation": a.f0_transformation} if a.f0_transformation else None)
-    model.to(dev)
-    model.eval()
-    seeds = [rank * BATCH + i for i in range(BATCH)]
-    wav = synthetic.harm_batch(seeds).to(dev)
-    f0 = analytic_f0(seeds).to(dev)
-    targets = synthetic.targets(model.spk, seeds)
-    gathered = ([torch.empty(world * BATCH, 1, N_SAMPLES + 1, dtype=torch.float32, device=dev)
-                 for _ in range(max(1, a.jobs))] if use_pg else None)   # indexed modulo the job count
-
-    # every job stream owns its workspaces and must have run (and allocated) once before the timed region starts: when
-    # --warmup is smaller than the number of job streams, the missing runs are done as untimed set-up steps first
-    # (reported as config.setup_steps)
-    jobs = max(1, a.jobs)
-    setup_steps = max(0, jobs - a.warmup)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(jobs)]
-    step_no = [0]
-
-    def step():
-        # the whole path is on the timed region: fbank -> TDNNF-VQ, YAAPT F0, one-hot, generator.
-        # Steps are independent batches; like the reference's jobs_per_compute_device they are kept
-        # `jobs` deep in flight, each on its own stream, so one batch's latency-bound front end
-        # overlaps the previous batch's generator.
-        s = streams[step_no[0] % jobs]
-        step_no[0] += 1
-        with torch.cuda.stream(s):
-            y = model.convert(wav, target=targets)
-            if use_pg:
-                dist.all_gather_into_tensor(gathered[step_no[0] % jobs], y.contiguous())
-        return y
-
-    for _ in range(setup_steps + a.warmup):
-        step()
-    if use_pg:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if use_pg:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if use_pg:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # dominant kernel family: the fused conv1d MFMA kernel inside the generator.  Timed live with
-    # events on the launch stream (= torch's current stream) around the generator forward.
-    gen_ms = None
+    want_cpu = (not a.no_cpu_baseline) and world == 1 and not use_pg
+    lines = []
+    if a.tag:
+        plan = [("--tag", a.tag, a.f0_transformation, a.steps, a.warmup, dict(n_utt=8, runs_1=1, runs_n=3, n_utt_1=4))]
+    elif use_pg:
+        k2 = min(a.steps, 16)
+        plan = ([] if a.headline_only else [("configs[4]", TAG_W2V2, "", k2, min(a.warmup, 4), None)]) + \
+               [("configs[1] sharded", TAG, "", a.steps, a.warmup, None)]
+    else:
+        k2 = min(a.steps, 12)
+        plan = ([] if a.headline_only else [
+            ("configs[2]", TAG_W2V2, "", k2, a.warmup, dict(n_utt=8, runs_1=1, runs_n=3, n_utt_1=4)),
+            ("configs[3]", TAG_W2V2, "quant_16_awgn_2", k2, a.warmup,
+             dict(n_utt=8, runs_1=1, runs_n=1, n_utt_1=2,
+                  budget_note="; configs[3] differs from configs[2] by the quantisation + noise of 250 x B values only, so its CPU leg is a shorter sample"))]) + \
+            [("configs[1]", TAG, "", a.steps, a.warmup, dict(n_utt=8, runs_1=3, runs_n=3))]
+    for name, tag, f0_tr, steps, warmup, cpu_args in plan:
+        out = one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu and cpu_args is not None, cpu_args or {})
+        torch.cuda.empty_cache()
+        if rank == 0:
+            lines.append(out)
     if rank == 0:
-        with torch.no_grad():
-            f0n = f0.clone()
-            bn = model.get_bn(wav)
-            spk = model.get_spk_id(wav, targets)
-            from satools_amd import ops
-            ops.f0_norm_transform_(f0n)
-            x = ops.assemble_input(bn, f0n, spk.to(dev, torch.float32).contiguous(), spk.shape[1])
-            model.hifigan(x)
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = max(3, min(a.steps, 10))
-            ev0.record()
-            for _ in range(reps):
-                model.hifigan(x)
-            ev1.record()
-            torch.cuda.synchronize()
-            gen_ms = ev0.elapsed_time(ev1) / reps
-
-    # the single dominant kernel (20 % of GPU time in profiles/r01j_*): the 11-tap split-f16 conv of the
-    # generator's first resblock stage, timed alone with events on its launch stream
-    dom = None
-    if rank == 0 and model.hifigan.precision == "f16x3":
-        with torch.no_grad():
-            from satools_amd import ops, packing
-            C, T, k, d = 256, 1250, 11, 5
-            g = torch.Generator(device="cpu").manual_seed(0)
-            xk = torch.randn(BATCH, C, T, generator=g).to(dev)
-            wk = packing.pack_conv_weight_f16x3((torch.randn(C, C, k, generator=g) * 0.02).to(dev))
-            bk = torch.zeros(C, device=dev)
-            xs, rs, ys = ops.act_split(xk, 0.1), ops.act_split(xk * 0.5, 0.1), ops.split_like(BATCH, C, T, dev)
-            run = lambda: ops.conv1d(xk, wk, C, k, bias=bk, dilation=d, pad_left=(k * d - d) // 2, mode=1, x_split=xs,
-                                     y_split=ys, y_split_slope=0.1, res_split=rs, res_split_slope=0.1, no_y=True, out=xk)
-            for _ in range(3):
-                run()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            for _ in range(20):
-                run()
-            ev1.record()
-            torch.cuda.synchronize()
-            us = ev0.elapsed_time(ev1) / 20 * 1e3
-            flop = 2.0 * BATCH * C * C * k * T
-            dom = {"name": "conv1d_f16x3_planes_kernel<2,2,11,5> (C=256, T=1250, 11 taps, dilation 5, batch 32; 18 launches per forward)",
-                   "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
-                   "frac": round(flop / us / 1e6 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)}
-
-    if rank == 0:
-        total_audio = world * a.steps * BATCH * UTT_SECONDS
-        achieved = GEN_FLOP_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
-        split = model.hifigan.precision == "f16x3"
-        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-        hbm = GEN_BYTES_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01o_generator_traffic.json")
-        if os.path.exists(tpath) and tag == TAG:
-            tj = json.load(open(tpath))["per_forward"]
-            traffic = tj["traffic_GB_raw"] * 1e9
-            traffic_note = (f"HBM bytes per generator forward (batch 32) from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                            f"passes (profiles/r01o_generator_traffic.json): fetch {tj['fetch_GB_raw']} GB as counted "
-                            f"({tj['fetch_GB_doubled']} GB with the gfx950 wide-load x2 correction as upper bound) + write "
-                            f"{tj['write_GB']} GB; per-layer streaming model {tj['algorithmic_GB_per_layer_model']} GB")
-        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
-                    "kernel": ("split-f16 conv family (conv1d_f16x3_planes_kernel, resblock_pair16/32_kernel)" if split else "conv1d_mfma_kernel")
-                              + f": all launches of one generator forward (+ upsampler split pass and output stage), {gen_ms:.3f} ms per batch of {BATCH}",
-                    "dominant_kernel": dom,
-                    "practical_ceiling": {"value": 592.0, "unit": "TFLOP/s", "frac": round(achieved / 592.0, 4),
-                                          "note": "bare loop of the same three f16 MFMAs per product on random operands: the chip holds "
-                                                  "~1.78 GHz under that load (tools/mfma_rate.hip)"} if split else None,
-                    "arithmetic": ("f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = "
-                                   "dense f16 MFMA peak / 3" if split else "exact f32 MFMA"),
-                    "algorithmic_flop_per_launch_group": GEN_FLOP_PER_UTT * BATCH,
-                    "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "hbm_model": {"achieved_TBps": round(hbm, 3), "peak_TBps": PEAK_HBM_TBS, "frac": round(hbm / PEAK_HBM_TBS, 4),
-                                  "bytes_per_launch_group": GEN_BYTES_PER_UTT * BATCH}}
-        out = {
-            "metric": "anonymized audio seconds per wall-clock second (real-time factor), 5 s @ 16 kHz utterances",
-            "value": round(total_audio / dt, 2),
-            "unit": "x real-time (audio s / wall s)",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32 (generator matrix products as split-f16 x3 with f32 accumulate)" if model.hifigan.precision == "f16x3" else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{tag}{'+f0-transformation=' + a.f0_transformation if a.f0_transformation else ''} model.convert, batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
-                       "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
-                       "f0": "YAAPT computed on-path on the GPU inside convert()",
-                       "jobs_per_gpu": jobs, "setup_steps": setup_steps,
-                       "parallelism": f"dp{world}" + (" + RCCL all_gather of waveforms per step" if world > 1 else "")},
-            "roofline": roofline,
-        }
-        if not a.no_cpu_baseline and tag == TAG and world == 1:     # the CPU leg runs at N = 1 only
-            state, _ = synthetic.checkpoint(TAG)
-            sample = list(range(4))
-            out["cpu_baseline"] = cpu_baseline(state, model.spk, sample)
-        print(json.dumps(out), flush=True)
+        head = lines[-1]
+        if len(lines) > 1:
+            head["configs"] = {o["config"]["workload"].split(":")[0]: {
+                "value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "roofline_frac": o["roofline"]["frac"],
+                **({"all_gather_ms": o["config"]["all_gather_ms"]} if "all_gather_ms" in o["config"] else {}),
+                **({"cpu_value": o["cpu_baseline"]["value"]} if "cpu_baseline" in o else {})} for o in lines[:-1]}
+        for o in lines:
+            print(json.dumps(o), flush=True)
     if use_pg:
         dist.destroy_process_group()
 

@@ -237,6 +237,10 @@ int sat_log_softmax_channels_f32(float* x, int B, int C, int T, void* stream);
 int sat_f0_stats_f32(const float* f0, int n, float* stats, void* stream);
 int sat_f0_apply_f32(float* f0, int n, const float* stats, int quant_bins, const float* noise,
                      void* stream);
+/* mean-reversion F0 transformation, one track [T] (hifigan/nn.py:64-90 `moving_average_f0` + `mean_reverv_f0`;
+ * dispatched at egs/vc/libritts/local/tuning/hifigan.py:79-80): out = (1 - alpha) f0 + alpha movavg_n(f0), window
+ * f0[t - n/2 .. t - n/2 + n - 1] with zeros outside.  out != f0.  The reference handles a batch of 1 only. */
+int sat_f0_mean_reversion_f32(const float* f0, float* out, int T, float alpha, int n, void* stream);
 int sat_assemble_input_f32(const float* bn, const float* f0, const float* spk, float* x,
                            int B, int C_bn, int T, int T_f0, int n_spk, void* stream);
 

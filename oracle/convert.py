@@ -44,3 +44,12 @@ def convert_fbank(sd, spk_list, wav, target, f0, quant_bins=0, noise=None):
     bn = tdnnf.extract_bn_fbank(asr, wav).permute(0, 2, 1)
     y = forward(gen, f0.clone().unsqueeze(0), bn, spk_one_hot(spk_list, target), quant_bins, noise)
     return y.squeeze(0)
+
+
+def convert_w2v2(sd, spk_list, wav, target, f0, quant_bins=0, noise=None, model=None):
+    """wav2vec2-tag convert with F0 given; `model` = a prebuilt oracle.wav2vec2.Wav2Vec2Restated holding the
+    `preprocessor.*` weights (315 M parameters: build it once outside a timed region)"""
+    asr, gen = split_state_dict(sd)
+    bn = tdnnf.extract_bn_w2v2(asr, wav, model=model).permute(0, 2, 1)
+    y = forward(gen, f0.clone().unsqueeze(0), bn, spk_one_hot(spk_list, target), quant_bins, noise)
+    return y.squeeze(0)

@@ -108,15 +108,12 @@ AFTER_KS = [1, 3, 3, 3]
 AFTER_SUB = [1.5, 1, 1, 1]
 
 
-def forward_fbank(sd, wav, hook=None):
-    """the ASR half of the fbank-tag net, `Net.forward` (tdnnf_vq.py:259-284; SURVEY §8 f4): wav [N, n] ->
-    (chain_out [N, T', output_dim], log_softmax(xent_out) [N, T', output_dim]).  Eval mode (dropout = identity)."""
-    x = wav.detach().clone() * 32768
-    x = fb.fbank(x, 80)
-    x = x - x.mean(dim=1).unsqueeze(1)
-    x = pad_input(x, 19)
-    ks, subs = FBANK_KS, FBANK_SUB
-    x = tdnnf_layer(sd, "tdnn1.", x, ks[0], subs[0], bypass=False)
+def _asr_head(sd, x, ks, subs, hook=None):
+    """tdnn1 .. VQ layer (all of it) -> pad_input(padding_after) -> tdnnfs_after -> prefinals -> output affines
+    (tdnnf_vq.py:259-284 == tdnnf_wav2vec2_vq.py:316-345 from `self.tdnn1(x)` on)"""
+    # TDNNF adds its bypass when feat_dim == output_dim (chain/nn.py:279-292): never for 80 fbank bins, always for the
+    # 1024-dimensional wav2vec2 features
+    x = tdnnf_layer(sd, "tdnn1.", x, ks[0], subs[0], bypass=(x.shape[-1] == 1024))
     for i in range(1, len(ks) - 1):
         x = tdnnf_layer(sd, f"tdnnfs.{2 * (i - 1)}.", x, ks[i], subs[i], bypass=True)
     x = tdnnf_layer(sd, f"tdnnfs.{2 * (len(ks) - 2)}.", x, ks[-1], subs[-1], bypass=False)      # VQ layer, all of it
@@ -136,6 +133,31 @@ def forward_fbank(sd, wav, hook=None):
     chain = pc.matmul(sd["chain_output.weight"].t()) + sd["chain_output.bias"]
     xent = px.matmul(sd["xent_output.weight"].t()) + sd["xent_output.bias"]
     return chain, F.log_softmax(xent, dim=2)
+
+
+def forward_fbank(sd, wav, hook=None):
+    """the ASR half of the fbank-tag net, `Net.forward` (tdnnf_vq.py:259-284; SURVEY §8 f4): wav [N, n] ->
+    (chain_out [N, T', output_dim], log_softmax(xent_out) [N, T', output_dim]).  Eval mode (dropout = identity)."""
+    x = wav.detach().clone() * 32768
+    x = fb.fbank(x, 80)
+    x = x - x.mean(dim=1).unsqueeze(1)
+    x = pad_input(x, 19)
+    return _asr_head(sd, x, FBANK_KS, FBANK_SUB, hook=hook)
+
+
+def forward_w2v2(sd, wav, hook=None, model=None):
+    """`Net.forward` of the wav2vec2-tag net (tdnnf_wav2vec2_vq.py:316-345): the same head behind the wav2vec2
+    features (raw waveform, no 32768 scaling; replicate-pad one frame; pad_input(3))"""
+    from . import wav2vec2 as w2
+    if model is None:
+        model = w2.Wav2Vec2Restated(24)
+        model.load_state_dict({k[len("preprocessor."):]: v for k, v in sd.items() if k.startswith("preprocessor.")})
+        model.eval()
+    with torch.no_grad():
+        x = model.extract_features(wav.detach().clone())[0][-1]
+    x = F.pad(x.transpose(2, 1), (0, 1), "replicate").transpose(2, 1).to(torch.float32)
+    x = pad_input(x, 3)
+    return _asr_head(sd, x, W2V2_KS, W2V2_SUB, hook=hook)
 
 
 def extract_bn_w2v2(sd, wav, aux=None, hook=None, model=None):

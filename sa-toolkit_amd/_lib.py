@@ -73,6 +73,7 @@ _PROTOS = {
                                         C.c_int, C.c_void_p]),
     "sat_f0_stats_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "sat_f0_apply_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "sat_f0_mean_reversion_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "sat_yaapt_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "sat_yaapt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
@@ -161,3 +162,22 @@ def stream():
 
 def int_array(vals):
     return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def cache_rebuild_begin(device, had_old):
+    """call before a device-side weight cache is (re)built.  The packed buffers about to be dropped go back to the
+    allocator pool of the stream that built them while OTHER streams (several convert() jobs in flight, the
+    reference's jobs_per_compute_device) may still be reading them: wait for the whole device first.  Rebuilds happen
+    at load time or after a parameter edit, never on the steady-state path."""
+    import torch
+    if had_old and getattr(device, "type", "cuda") == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def cache_rebuild_end(device):
+    """call after a device-side weight cache has been built: the fold / pack / BatchNorm-affine kernels ran
+    asynchronously on the builder's stream, and nothing else orders them before the first launch of another stream
+    that reads the cache — so the builder waits for them once, here."""
+    import torch
+    if getattr(device, "type", "cuda") == "cuda":
+        torch.cuda.current_stream(device).synchronize()

@@ -77,8 +77,13 @@ def build(args):
         # ---- feature extractors (decorators are pass-through under SA_JIT_TWEAK=true,
         #      utils/feature_extractor_decorator.py:60-71; parse_wavinfo_wav clones) -------------
         def get_bn(self, wavinfo):
-            wav = self._to_device(getattr(wavinfo, "wav", wavinfo).detach()).clone()
-            return self.bn_extractor.extract_bn(wav).permute(0, 2, 1)
+            wav = self._to_device(getattr(wavinfo, "wav", wavinfo).detach())
+            # parse_wavinfo_wav clones because the extractor scales its argument in place (wav_scp_dataset.py:48-53);
+            # the private entry leaves the input untouched instead (no clone, no scaling pass)
+            private = getattr(self.bn_extractor, "_extract_bn_private", None)
+            if private is not None:
+                return private(wav).permute(0, 2, 1)
+            return self.bn_extractor.extract_bn(wav.clone()).permute(0, 2, 1)
 
         def set_f0(self, f0):
             self.f0 = f0
@@ -181,11 +186,23 @@ def build(args):
             if spec and "awgn" in spec:
                 noise = f0_transforms.draw_awgn(f0.shape, f0_transforms.parse_awgn_db(spec)).to(f0.dtype)
                 noise = noise.pin_memory().to(f0.device, non_blocking=True) if f0.is_cuda else noise
-            if spec and "mean-reverv" in spec:
-                raise NotImplementedError("f0 transformation 'mean-reverv' is not part of the accelerated path")
             if quant or noise is not None:
                 f0 = f0.clone()
                 self._apply_transform_(f0, quant, noise)
+            if spec and "mean-reverv" in spec:
+                # hifigan/nn.py:64-90: the reference's moving average squeezes [B, 1, T'] to 2-D before conv1d, which
+                # then reads B as the channel count of ONE sequence: batches of 1 only (RuntimeError otherwise)
+                alpha, n = f0_transforms.parse_mean_reverv(spec)
+                if f0.shape[0] != 1:
+                    raise RuntimeError(f"Given groups=1, weight of size [1, 1, {n}], expected input[1, {f0.shape[0]}, "
+                                       f"{f0.shape[-1] + 2 * (n // 2)}] to have 1 channels, but got {f0.shape[0]} channels instead "
+                                       "(mean-reverv handles one utterance per call, as in the reference)")
+                from ._lib import check, lib, ptr, stream
+                src = f0.contiguous()
+                out = torch.empty_like(src)
+                check(lib().sat_f0_mean_reversion_f32(ptr(src), ptr(out), src.shape[-1], float(alpha), int(n), stream()),
+                      "sat_f0_mean_reversion_f32")
+                f0 = out
             return f0
 
         @staticmethod

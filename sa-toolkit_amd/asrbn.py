@@ -122,9 +122,11 @@ class _TdnnfBase(nn.Module):
         if self._cache_key == key:
             return
         split = self.precision == "f16x3"
+        _lib.cache_rebuild_begin(device, self._cache is not None)
         self._cache = [self._layer_cache(lay, device, split) for lay in self._stack_layers()]
         self._cache_full = None
         self._cache_key = key
+        _lib.cache_rebuild_end(device)
 
     def _tdnnf_layer(self, lay, c, x, xs=None, return_bottleneck=False, want_aux=False):
         """x [B, feat, T] -> [B, out, T'] (or the bottleneck [B, bott, T']).  In split-f16 mode the layers
@@ -197,6 +199,7 @@ class _TdnnfBase(nn.Module):
                     "out": [((packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight)(f32(o.weight).unsqueeze(-1)),
                              f32(o.bias).reshape(-1), o.weight.shape[0]) for o in (self.chain_output, self.xent_output)]}
             self._cache_full = full
+            _lib.cache_rebuild_end(device)
         return self._cache_full
 
     def _asr_outputs(self, x):
@@ -265,10 +268,20 @@ class TdnnfVqNet(_TdnnfBase):
                             hi.to(torch.int32).to(device))
         return self._tables
 
-    def features(self, x):
-        """fbank + UttCMVN + pad_input -> [N, 80, T + 2*padding] (x already scaled)"""
+    def features(self, x, scale=1.0):
+        """fbank + UttCMVN + pad_input -> [N, 80, T + 2*padding]; `scale` multiplies the samples inside the framing
+        kernel (1.0: x already scaled by 32768)"""
         win, mel, lo, hi = self._fbank_tables(x.device)
-        return ops.fbank_cmvn_pad(x, win, mel, lo, hi, scale=1.0, pad=self.padding, cmvn=True)
+        return ops.fbank_cmvn_pad(x, win, mel, lo, hi, scale=scale, pad=self.padding, cmvn=True)
+
+    def _extract_bn_private(self, x):
+        """extract_bn for a caller that owns no view of `x` afterwards (Net.get_bn, whose reference version clones
+        its input only because extract_bn scales in place): the 32768 scaling happens inside the framing kernel,
+        the input is left untouched and neither the clone nor the scaling pass is launched.  Same values: the
+        kernel multiplies each sample by the scale before anything else."""
+        if not x.is_cuda or x.dim() != 2:
+            raise _lib.SatError("extract_bn expects a 2-dimensional tensor [N, samples] on the HIP device")
+        return self._run_stack(self.features(x.to(torch.float32).contiguous(), scale=32768.0)).permute(0, 2, 1)
 
     def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
         """inputs [N, n] -> [N, T, 256]   (tdnnf_vq.py:236-257; like the reference this scales

@@ -220,6 +220,26 @@ __global__ void __launch_bounds__(256) f0_apply_kernel(float* __restrict__ f0, i
   f0[i] = v;
 }
 
+// mean reversion of a normalised F0 track (hifigan/nn.py:64-90): out = (1 - alpha) * f0 + alpha * avg, avg[t] = the
+// n-tap moving average over f0[t - n/2 .. t - n/2 + n - 1] (zeros outside), summed as torch's CPU conv1d sums it:
+// an FMA chain in tap order with every tap = 1/n (measured on the biquad FIR: oracle/biquad.py); the blend is
+// multiply, multiply, add (three separate torch kernels in the reference)
+__global__ void __launch_bounds__(256) f0_mean_reversion_kernel(const float* __restrict__ f0, float* __restrict__ out, int T,
+                                                                float one_minus_alpha, float alpha, float w, int n) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int t0 = t - n / 2;
+  float acc = 0.f;
+  for (int k = 0; k < n; ++k) {
+    const int i = t0 + k;
+    const float x = (i >= 0 && i < T) ? f0[i] : 0.f;
+    acc = k == 0 ? w * x : __builtin_fmaf(w, x, acc);
+  }
+  const float a = one_minus_alpha * f0[t];
+  const float b = alpha * acc;
+  out[t] = a + b;
+}
+
 // x[b] = [ bn[b] ; nearest-interpolated f0[b] ; spk[b] (the one-hot row as f32) broadcast over T ]
 __global__ void __launch_bounds__(256) assemble_kernel(const float* __restrict__ bn, const float* __restrict__ f0,
                                                        const float* __restrict__ spk, float* __restrict__ x, int C_bn,
@@ -284,6 +304,17 @@ extern "C" int sat_f0_apply_f32(float* f0, int n, const float* stats, int quant_
   hipLaunchKernelGGL(f0_apply_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, f0, n, stats,
                      quant_bins, noise);
   SAT_LAUNCH_CHECK("f0_apply_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_f0_mean_reversion_f32(const float* f0, float* out, int T, float alpha, int n, void* stream) {
+  SAT_REQUIRE(f0 && out && f0 != out && T > 0 && n > 0, "f0_mean_reversion: bad arguments");
+  // (1 - alpha) is taken in double like the reference's Python float, then rounded to f32 as torch's scalar multiply does
+  const float oma = (float)(1.0 - (double)alpha);
+  const float w = 1.0f / (float)n;     // torch.ones(n) / n in f32
+  hipLaunchKernelGGL(f0_mean_reversion_kernel, dim3(ceil_div(T, 256)), dim3(256), 0, (hipStream_t)stream, f0, out, T, oma,
+                     alpha, w, n);
+  SAT_LAUNCH_CHECK("f0_mean_reversion_kernel");
   return SAT_OK;
 }
 

@@ -30,6 +30,10 @@ def all_gather_rows(local, n_items, group=None):
     world = dist.get_world_size(group)
     sizes = [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
     mx = max(sizes)
+    mine = sizes[dist.get_rank(group)]
+    if local is None or local.shape[0] != mine:
+        raise ValueError(f"all_gather_rows: this rank's block must hold {mine} rows, got "
+                         f"{None if local is None else local.shape[0]}")
     if local.shape[0] != mx:
         pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 0)
@@ -45,13 +49,29 @@ def all_gather_rows(local, n_items, group=None):
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], 0)
 
 
-def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None):
+def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, local_out=None, before_gather=None):
     """run `convert_fn(lo, hi) -> [hi-lo, ...]` over this rank's shard in fixed batches and
-    (optionally) all-gather the results in global index order"""
+    (optionally) all-gather the results in global index order.
+
+    `local_out` [shard rows, ...]: a preallocated buffer `convert_fn` fills itself (row `i - lo` for item `i`, e.g.
+    from several HIP streams); its return values are then ignored and nothing is concatenated.  `before_gather()`
+    runs after the last batch has been issued and before the collective (e.g. make the current stream wait for the
+    job streams).  Every rank must hold at least one item: with n_items < world some shard is empty, its rank has no
+    rows to give the trailing shape of, and the collective would hang on the others — refused on ALL ranks before
+    anything is launched (the reference's `split_dict` never produces more shards than entries either)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if n_items < world:
+        raise ValueError(f"convert_sharded: {n_items} items cannot be sharded over {world} ranks (every rank needs one)")
     lo, hi = shard_bounds(n_items, rank, world)
     outs = [convert_fn(s, e) for s, e in batches(lo, hi, batch_size)]
-    local = torch.cat(outs, 0) if outs else None
+    if local_out is not None:
+        if local_out.shape[0] != hi - lo:
+            raise ValueError(f"convert_sharded: local_out holds {local_out.shape[0]} rows, the shard {hi - lo}")
+        local = local_out
+    else:
+        local = torch.cat(outs, 0)
+    if before_gather is not None:
+        before_gather()
     if not gather:
         return local
     return all_gather_rows(local, n_items, group)

@@ -18,6 +18,13 @@ def parse_awgn_db(spec: str) -> int:
     return int(_digits(tok))
 
 
+def parse_mean_reverv(spec: str):
+    """"mean-reverv_<alpha>:<n>" -> (alpha, n)   (hifigan/nn.py:83-87)"""
+    tok = spec[spec.index("mean-reverv"):].split("_")[1]
+    alpha = float("".join(ch for ch in tok.split(":")[0] if "0" <= ch <= "9" or ch == "."))
+    return alpha, int(_digits(tok.split(":")[1]))
+
+
 def draw_awgn(shape, target_noise_db: int) -> torch.Tensor:
     """the reference draws on the CPU global generator with exactly this call
     (hifigan/nn.py:49-57); keeping the call identical keeps the draws identical under a seed"""

@@ -5,6 +5,7 @@ state-dict layout (params.CoreHifiGanParams); the forward runs entirely in the H
 re-laid out for the MFMA conv kernel, and both are cached until parameters change."""
 import ctypes as C
 import os
+from collections import OrderedDict
 
 import torch
 
@@ -25,6 +26,9 @@ class CoreHifiGan(CoreHifiGanParams):
     #: single convert() in flight, a loss once two are (bench --jobs 2), so off by default
     branch_streams = int(os.environ.get("SATOOLS_AMD_GEN_BRANCH_STREAMS", "0"))
 
+    #: per-stream workspaces kept (3.3 GB each at 32 x 5 s); beyond it the least recently used one is dropped
+    max_workspaces = int(os.environ.get("SATOOLS_AMD_GEN_MAX_WORKSPACES", "16"))
+
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._handle = None
@@ -44,6 +48,13 @@ class CoreHifiGan(CoreHifiGanParams):
     def invalidate(self):
         self._packed_key = None
 
+    def remove_weight_norm(self):
+        # the reference's Net API (hifigan.py:51-52): weight_g / weight_v are replaced by a new `weight` Parameter, so
+        # the walked parameter list of _param_key is stale and the packed weights must be rebuilt from the new tensors
+        super().remove_weight_norm()
+        self.__dict__.pop("_flat_params", None)
+        self.invalidate()
+
     def _conv_modules(self):
         mods = [self.conv_pre] + list(self.ups)
         for rb in self.resblocks:
@@ -56,6 +67,7 @@ class CoreHifiGan(CoreHifiGanParams):
         if self._packed_key == key and self._handle is not None:
             return
         l = lib()
+        _lib.cache_rebuild_begin(device, self._packed is not None)
         if self._handle is None:
             h = C.c_void_p()
             dil = [d for ds in self.resblock_dilation_sizes for d in ds]
@@ -93,6 +105,7 @@ class CoreHifiGan(CoreHifiGanParams):
         check(l.sat_hifigan_set_option(self._handle, b"branch_streams", int(self.branch_streams)), "sat_hifigan_set_option")
         self._packed = packed  # keeps the device buffers alive
         self._packed_key = key
+        _lib.cache_rebuild_end(device)
 
     def _workspace(self, B, T, device):
         # one workspace per launch stream: concurrent convert() calls on different streams (the
@@ -100,11 +113,14 @@ class CoreHifiGan(CoreHifiGanParams):
         need = lib().sat_hifigan_workspace_bytes(self._handle, B, T)
         key = torch.cuda.current_stream(device).cuda_stream
         if self._ws is None:
-            self._ws = {}
+            self._ws = OrderedDict()
         ws = self._ws.get(key)
+        if ws is not None:
+            self._ws.move_to_end(key)
         if ws is None or ws.numel() * 4 < need or ws.device != device:
-            if len(self._ws) >= 8:
-                self._ws.clear()      # workspaces of streams that no longer exist (keys are raw stream handles)
+            self._ws.pop(key, None)
+            while len(self._ws) >= self.max_workspaces:
+                self._ws.popitem(last=False)   # least recently used: a stream that no longer exists (keys are raw handles)
             ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
             self._ws[key] = ws
         return ws, need

@@ -166,6 +166,7 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             return self._w2
         if self.w2v2_precision not in ("f16x3", "f32"):
             raise _lib.SatError(f"unknown wav2vec2 precision {self.w2v2_precision!r}")
+        _lib.cache_rebuild_begin(device, self._w2 is not None)
         split = self.w2v2_precision == "f16x3"
         pack_mm = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight
         self._mm_mode = _lib.CONV_F16X3 if split else _lib.CONV_F32
@@ -214,6 +215,7 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
                 "f2_b": f32(lay.feed_forward.output_dense.bias),
             })
         self._w2, self._w2_key = W, key
+        _lib.cache_rebuild_end(device)
         return W
 
     # ---- wav2vec2 forward: [B, n] -> last layer output [B, 1024, frames] ------------------------
@@ -305,13 +307,13 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
                 x = ops.conv1d(h, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm)
         return x
 
-    def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
-        """inputs [N, n] in [-1, 1] (no 32768 scaling on this tag) -> [N, T, 256]
-        (tdnnf_wav2vec2_vq.py:289-314)"""
+    def features(self, x):
+        """[N, n] raw waveforms -> [N, 1024, 250 + 2 * padding]: last transformer layer output, replicate-padded by one
+        frame (249 -> 250), then pad_input(self.padding)   (tdnnf_wav2vec2_vq.py:295-306 == :320-331)"""
         if not x.is_cuda:
-            raise _lib.SatError("extract_bn runs on the HIP device only (no CPU fallback); move the input to 'cuda'")
+            raise _lib.SatError("the wav2vec2 extractor runs on the HIP device only (no CPU fallback); move the input to 'cuda'")
         if x.dim() != 2:
-            raise _lib.SatError("extract_bn expects a 2-dimensional tensor [N, samples]")
+            raise _lib.SatError("expected a 2-dimensional tensor [N, samples]")
         n = x.shape[1]
         lens, t = [], n
         for _, k, s in CONV_LAYERS:
@@ -322,11 +324,22 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         self._fe_len = lens
         feats = self.w2v2_features(x.to(torch.float32).contiguous())                # [N, 1024, 249]
         feats = ops.pad_replicate(feats, 0, 1)                                      # F.pad(.., (0, 1), "replicate")
-        feats = ops.pad_replicate(feats, self.padding, self.padding, interleave_right=True)   # pad_input
-        out = self._run_stack(feats, want_aux=want_aux)
+        return ops.pad_replicate(feats, self.padding, self.padding, interleave_right=True)   # pad_input
+
+    def _extract_bn_private(self, x):
+        return self.extract_bn(x)            # this tag never mutates its input
+
+    def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
+        """inputs [N, n] in [-1, 1] (no 32768 scaling on this tag) -> [N, T, 256]
+        (tdnnf_wav2vec2_vq.py:289-314)"""
+        out = self._run_stack(self.features(x), want_aux=want_aux)
         if want_aux:
             return out[0].permute(0, 2, 1), out[1]
         return out.permute(0, 2, 1)
 
     def forward(self, x):
-        raise NotImplementedError("the ASR output head is outside the anonymization hot path (SURVEY §8 f4)")
+        """waveforms [N, n] in [-1, 1] -> (chain_out, log_softmax(xent_out)), each [N, T', output_dim]
+        (tdnnf_wav2vec2_vq.py:316-345, eval mode): the wav2vec2 features through tdnn1, the TDNNF
+        layers with the VQ layer run through, pad_input(padding_after), tdnnfs_after (1.5x subsampling first),
+        the two prefinal layers and the output affines — the boundary to the Kaldi decoder"""
+        return self._asr_outputs(self.features(x))

@@ -136,6 +136,7 @@ def build(args=None):
             key = (self.precision,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in list(self.parameters()) + list(self.buffers()))
             if self._cache_key == key:
                 return self._cache
+            _lib.cache_rebuild_begin(device, self._cache is not None)
             f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
             # the wide 1x1 convs (block in / out, the 1536 -> 1536 conv before pooling, the attention MLP) run as
             # split-f16 products on the f16 matrix cores (~2^-21 per product) unless precision is "f32"
@@ -176,6 +177,7 @@ def build(args=None):
             W["fb"] = f32(self.preprocessor.MelSpec.mel_scale.fb).t().contiguous()      # [80][513]
             W["coef"] = float(-self.preprocessor.PreEmphasis.flipped_filter.reshape(-1)[0])
             self._cache, self._cache_key = W, key
+            _lib.cache_rebuild_end(device)
             return W
 
         # ---- forward -----------------------------------------------------------------------------

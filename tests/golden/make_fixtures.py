@@ -304,6 +304,32 @@ def main():
             out["harm01_16000_quant16_awgn2_seed1234"] = net2.convert(w, target=[spk[3], spk[10]]).numpy()
         np.savez_compressed(os.path.join(GOLD, "fx_e2e.npz"), **out)
         json.dump(shapes, open(os.path.join(GOLD, "fx_shapes.json"), "w"))
+    if want("meanrev"):
+        # option f0-transformation=mean-reverv_<alpha>:<n> (hifigan/nn.py:65-90, dispatched at hifigan.py:79-80)
+        out = {}
+        norm = satools.cmvn.UttCMVN(var_norm=True, keep_zeros=True)
+        f0a = norm(net.get_f0(synthetic.harm_batch([0], 16384)).clone()).unsqueeze(0).permute(1, 0, 2)    # [1, 1, 52]
+        f0c = norm(net.get_f0(synthetic.harm_batch([2], 80000)).clone()).unsqueeze(0).permute(1, 0, 2)    # [1, 1, 250]
+        out["in_T52"], out["in_T250"] = f0a.numpy().copy(), f0c.numpy().copy()
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):          # the reference prints the shape
+            for spec in ("mean-reverv_0.5:32", "mean-reverv_0.3:7", "mean-reverv_1:4"):
+                out[f"T52/{spec}"] = satools.hifigan.nn.mean_reverv_f0(f0a.clone(), alpha=spec).numpy()
+                out[f"T250/{spec}"] = satools.hifigan.nn.mean_reverv_f0(f0c.clone(), alpha=spec).numpy()
+            net3 = build_reference_model(ref, asr_name, f0_transformation="mean-reverv_0.5:32")
+            net3.load_state_dict(state["base_model_state_dict"], strict=True)
+            net3.eval()
+            with torch.no_grad():
+                out["harm0_16000_meanrev_0.5_32"] = net3.convert(synthetic.harm_batch([0], 16000), target=spk[3]).numpy()
+                try:
+                    net3.convert(synthetic.harm_batch([0, 1], 16000), target=[spk[3], spk[10]])
+                    batch_error = ""
+                except Exception as e:      # batches fail inside conv1d (the squeezed [B, T] input is read as B channels)
+                    batch_error = type(e).__name__
+        np.savez_compressed(os.path.join(GOLD, "fx_meanrev.npz"), **out)
+        json.dump({"batch_of_2_raises": batch_error}, open(os.path.join(GOLD, "fx_meanrev.json"), "w"))
+        print("mean-reverv: batch of 2 raises", batch_error)
+
     if want("w2v2"):
         # wav2vec2 tag: the reference's own tdnnf_wav2vec2_vq.Net / hifigan Net with the torchaudio stand-in's
         # wav2vec2 factory (= oracle/wav2vec2.py).  Pins the plumbing around the third-party model
@@ -340,7 +366,20 @@ def main():
             feats = net2.bn_extractor.preprocessor.extract_features(w)[0][-1]
             out["harm01_16000/w2v2_last_sub"] = feats[:, :, ::16].numpy()
             out["harm0_16000/convert"] = net2.convert(synthetic.harm_batch([0], 16000), target=net2.spk[3]).numpy()
-            shapes2 = {}
+            # the ASR half of the wav2vec2-tag net (Net.forward, tdnnf_wav2vec2_vq.py:316-345)
+            bx2 = net2.bn_extractor
+            acts2 = {}
+            hk = [bx2.tdnnfs_after[0].register_forward_hook(lambda m, i, o: acts2.__setitem__("after0", o.detach())),
+                  bx2.tdnnfs[2].register_forward_hook(lambda m, i, o: acts2.__setitem__("vq_layer", o.detach()))]
+            chain, xent = bx2(w.clone())
+            for h_ in hk:
+                h_.remove()
+            out["harm01_16000/chain_sub"] = chain[..., ::8].numpy()
+            out["harm01_16000/xent_sub"] = xent[..., ::8].numpy()
+            out["harm01_16000/xent_lse"] = torch.logsumexp(xent, dim=2).numpy()
+            out["harm01_16000/after0_sub"] = acts2["after0"][..., ::16].numpy()
+            out["harm01_16000/vq_layer_sub"] = acts2["vq_layer"][..., ::16].numpy()
+            shapes2 = {"forward_2x32000": list(bx2(torch.arange(2 * 32000, dtype=torch.float32).reshape(2, 32000) / 64000.0)[0].shape)}
             for n in (16000, 32000, 80000):
                 ww = synthetic.harm_batch([2], n)
                 shapes2[str(n)] = [list(net2.get_bn(ww).shape), list(net2.get_f0(ww).shape)]

@@ -239,3 +239,23 @@ def test_conv0_fused_with_layernorm_gives_the_same_bits(n):
     assert y0.shape == y1.shape and torch.equal(y0, y1) and torch.equal(ys0, ys1)
     _, ys2 = ops.w2v2_conv0_ln(x, w, b, g, beta)
     assert torch.equal(ys0, ys2)
+
+
+def test_asr_forward_matches_reference(model, gold):
+    """f4 for the wav2vec2-tag net: `TdnnfWav2vec2VqNet.forward` (tdnnf_wav2vec2_vq.py:316-345) against the reference's
+    own `Net.forward` run — chain output and xent log-softmax over 3280 pdfs, 1.5x subsampling included; the frame
+    count of the reference's validate_model check (2 x 32000 samples -> 66 frames)"""
+    from satools_amd import synthetic
+    fx = gold.npz("fx_w2v2.npz")
+    chain, xent = model.bn_extractor(synthetic.harm_batch([0, 1], 16000).to(DEV))
+    assert chain.shape == xent.shape and chain.shape[2] == 3280
+    for got, key in ((chain, "chain_sub"), (xent, "xent_sub")):
+        want = torch.from_numpy(fx[f"harm01_16000/{key}"])
+        g = got.cpu()[..., ::8]
+        assert g.shape == want.shape
+        err = (g - want).pow(2).mean().sqrt().item() / want.pow(2).mean().sqrt().item()
+        print(f"wav2vec2-tag ASR forward {key}: relative RMS error {err:.2e}")
+        assert err < 1e-4
+    assert (torch.logsumexp(xent.cpu(), dim=2) - torch.from_numpy(fx["harm01_16000/xent_lse"])).abs().max() < 1e-3
+    x = (torch.arange(2 * 32000, dtype=torch.float32).reshape(2, 32000) / 64000.0).to(DEV)
+    assert list(model.bn_extractor(x)[0].shape) == gold.json("fx_shapes_w2v2.json")["forward_2x32000"] == [2, 66, 3280]

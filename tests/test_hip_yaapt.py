@@ -143,3 +143,39 @@ def test_prefilter_bit_identical_to_the_oracle_biquads(B, n):
             ref = biquad.band_limit(v)
             assert np.array_equal(filt[b, sig, :L], ref), (b, sig, int((filt[b, sig, :L] != ref).sum()))
             assert not filt[b, sig, L:].any()
+
+
+def test_mean_reversion_option_matches_golden(gold):
+    """option f0-transformation=mean-reverv_<alpha>:<n> (hifigan/nn.py:64-90, hifigan.py:79-80): the kernel against the
+    reference's own outputs — bit for bit for the short windows (an FMA chain in tap order, as torch's conv1d sums
+    them), within one ulp of O(1) values for the 32-tap window (the reference's conv1d takes a oneDNN path whose
+    summation order is internal to it); `convert` with the option against the reference run; a batch of 2 raises
+    RuntimeError as in the reference (its conv1d reads the squeezed [B, T] tensor as B channels)"""
+    import satools_amd
+    from satools_amd import synthetic
+    fx = gold.npz("fx_meanrev.npz")
+    model = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1",
+                                   option_args={"f0_transformation": "mean-reverv_0.5:32"})
+    model.to(DEV)
+    model.eval()
+    for T in ("T52", "T250"):
+        x = torch.from_numpy(fx["in_" + T]).to(DEV)
+        for spec in ("mean-reverv_0.5:32", "mean-reverv_0.3:7", "mean-reverv_1:4"):
+            m = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1", option_args={"f0_transformation": spec}) \
+                if spec != "mean-reverv_0.5:32" else model
+            if m is not model:
+                m.to(DEV)
+            got = m.f0_transformation(x.clone()).cpu().numpy()
+            ref = fx[f"{T}/{spec}"]
+            assert got.shape == ref.shape
+            if spec.endswith(":32"):
+                assert np.abs(got - ref).max() <= 2.4e-7, (T, spec, np.abs(got - ref).max())
+            else:
+                assert np.array_equal(got, ref), (T, spec)
+    y = model.convert(synthetic.harm_batch([0], 16000).to(DEV), target=model.spk[3])
+    err = rms(y.cpu().numpy() - fx["harm0_16000_meanrev_0.5_32"])
+    print("convert mean-reverv_0.5:32 RMS error vs reference:", err)
+    assert y.shape == (1, 16001) and err < 1e-4
+    assert gold.json("fx_meanrev.json")["batch_of_2_raises"] == "RuntimeError"
+    with pytest.raises(RuntimeError):
+        model.convert(synthetic.harm_batch([0, 1], 16000).to(DEV), target=[model.spk[3], model.spk[10]])

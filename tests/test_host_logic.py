@@ -154,6 +154,21 @@ out = sdist.convert_sharded(conv, N, batch_size=4)
 assert out.shape == (N, 1, 5) and torch.equal(out[:, 0, 0], torch.arange(N, dtype=torch.float32)), out[:, 0, 0]
 exp = {{0: [(0, 4), (4, 6)], 1: [(6, 10), (10, 11)]}}[rank]
 assert calls == exp, (rank, calls)
+# a preallocated shard buffer filled by the callback (what bench.py does from its job streams) + the pre-gather hook
+lo, hi = sdist.shard_bounds(N, rank, 2)
+buf = torch.full((hi - lo, 1, 5), -1.0)
+hooked = []
+def fill(a, b):
+    buf[a - lo:b - lo] = torch.arange(a, b, dtype=torch.float32).view(-1, 1, 1)
+out2 = sdist.convert_sharded(fill, N, batch_size=4, local_out=buf, before_gather=lambda: hooked.append(1))
+assert hooked == [1] and torch.equal(out2, out)
+# fewer items than ranks: refused on every rank before any collective (no hang)
+try:
+    sdist.convert_sharded(conv, 1, batch_size=4)
+    raise SystemExit("expected ValueError")
+except ValueError:
+    pass
+dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
 ''')
@@ -200,3 +215,47 @@ target_constant_spkid = 6081
         assert A.vartoml(cfg)["other"]["results_dir"] == "/env/x"
     finally:
         del os.environ["SAT_TEST_ROOT"]
+
+
+def test_remove_weight_norm_invalidates_the_packed_weight_key():
+    """`remove_weight_norm()` (the reference Net API, hifigan.py:51-52) swaps weight_g / weight_v for a new
+    `weight` Parameter; the generator's weight-cache key must follow the NEW tensors (no GPU needed for the key)"""
+    from satools_amd.hifigan import CoreHifiGan
+    g = CoreHifiGan(imput_dim=32, upsample_rates=[2, 2], upsample_kernel_sizes=[4, 4], upsample_initial_channel=32)
+    for p in g.parameters():
+        torch.nn.init.normal_(p, std=0.1)
+    k0 = g._param_key()
+    assert g._param_key() == k0
+    w_before = g.conv_pre.folded_weight().clone()
+    g.remove_weight_norm()
+    k1 = g._param_key()
+    assert k1 != k0 and g._packed_key is None
+    assert "weight" in g.conv_pre._parameters and "weight_v" not in g.conv_pre._parameters
+    assert torch.equal(g.conv_pre.folded_weight(), w_before)            # folding is exact
+    with torch.no_grad():
+        g.conv_post.weight.mul_(0.5)                                    # an in-place edit of the NEW parameter
+    assert g._param_key() != k1
+    sd = {k: v.clone() + 1 for k, v in g.state_dict().items()}
+    g.load_state_dict(sd)
+    assert g._param_key() != k1
+
+
+def test_bench_gpus_2_as_typed_spawns_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` without torch.distributed.run around it: the parent starts the ranks as a child
+    process and relays the JSON line and the exit code (dry run on the CPU: gloo, stand-in convert, the same
+    convert_sharded call as the GPU path)"""
+    env = dict(os.environ, SAT_BENCH_DRYRUN="1", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["utterances"] == 2 * 3 * 32
+    # a failing rank's exit code comes back through the parent
+    env["SAT_BENCH_DRYRUN"] = "0"
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

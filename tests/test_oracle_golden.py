@@ -111,3 +111,19 @@ def test_convert_matches_reference_with_reference_f0(gold, fbank_tag_state):
     assert rms(y.numpy() - fx["harm01_80000_list"]) < 1e-5
     # batch-coupled F0 normalisation: the same utterance differs alone vs in a batch of 2
     assert np.abs(fx["harm01_80000_list"][0, 0] - fx["harm0_80000_str"][0]).max() > 1e-6
+
+
+def test_mean_reversion_matches_reference(gold):
+    """hifigan/nn.py:64-90 `mean_reverv_f0` (option f0-transformation=mean-reverv_<alpha>:<n>)"""
+    from oracle import f0 as of0
+    fx = gold.npz("fx_meanrev.npz")
+    assert of0.parse_mean_reverv("quant_16_mean-reverv_0.5:32") == (0.5, 32)
+    for T in ("T52", "T250"):
+        x = torch.from_numpy(fx["in_" + T])
+        for spec in ("mean-reverv_0.5:32", "mean-reverv_0.3:7", "mean-reverv_1:4"):
+            got = of0.mean_reversion(x.clone(), *of0.parse_mean_reverv(spec))
+            assert got.shape == x.shape and np.array_equal(got.numpy(), fx[f"{T}/{spec}"]), (T, spec)
+    assert gold.json("fx_meanrev.json")["batch_of_2_raises"] == "RuntimeError"
+    import pytest
+    with pytest.raises(RuntimeError):
+        of0.mean_reversion(torch.zeros(2, 1, 50), 0.5, 32)

@@ -40,6 +40,7 @@ def test_extract_bn_matches_reference(gold, w2v2_state):
 
 def test_frame_counts(gold):
     shapes = gold.json("fx_shapes_w2v2.json")
+    assert shapes.pop("forward_2x32000") == [2, 66, 3280]      # the reference's own validate_model assertion (66 frames)
     for n, (bn_shape, f0_shape) in shapes.items():
         assert ow.frames_out(int(n)) + 1 == bn_shape[2]     # 249 wav2vec2 frames -> replicate-padded to 250
     assert ow.frames_out(80000) == 249
@@ -78,3 +79,21 @@ def test_w2v2_model_matches_hf_transformers(gold, w2v2_state):
     assert cmp(wrong[:, :, ::16], fx["layer23_sub"]) > 0.5
     ver = gold.json("fx_w2v2_hf.json")["max_abs_diff_vs_hf"]
     assert ver["none_in_extract_features"]["layer23"] < 1e-4 < ver["before_stack"]["layer23"]
+
+
+def test_asr_forward_matches_reference(gold, w2v2_state):
+    """f4 for the wav2vec2-tag net: `Net.forward` (tdnnf_wav2vec2_vq.py:316-345) up to the chain / xent outputs"""
+    state, _ = w2v2_state
+    asr, _ = oconv.split_state_dict(state["base_model_state_dict"])
+    fx = gold.npz("fx_w2v2.npz")
+    acts = {}
+    chain, xent = otd.forward_w2v2(asr, synthetic.harm_batch([0, 1], 16000), hook=lambda k, v: acts.__setitem__(k, v))
+    assert chain.shape == xent.shape and chain.shape[2] == 3280
+    r = lambda a: float(np.sqrt(np.mean(np.square(a))))
+    for key, sub in (("vq_layer", 16), ("after0", 16)):
+        want = fx[f"harm01_16000/{key}_sub"]
+        assert r(acts[key][..., ::sub].numpy() - want) <= 2e-5 * max(1.0, r(want)), key
+    for got, key in ((chain, "chain_sub"), (xent, "xent_sub")):
+        want = fx[f"harm01_16000/{key}"]
+        assert got[..., ::8].shape == want.shape and r(got[..., ::8].numpy() - want) <= 2e-5 * max(1.0, r(want)), key
+    assert np.abs(torch.logsumexp(xent, dim=2).numpy() - fx["harm01_16000/xent_lse"]).max() < 1e-4
