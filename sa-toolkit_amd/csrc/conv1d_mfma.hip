@@ -13,381 +13,14 @@
 // Replaces (reference): torch Conv1d/ConvTranspose1d calls of hifigan/archi.py:77-91 and
 // hifigan/nn.py:179-186; unfold+matmul/addmm of chain/nn.py:267-292 + BatchNorm/ReLU :338-347.
 #include "common.h"
+#include "conv_common.h"
 #include <cstring>
 
 namespace sat {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-
-// power-of-two scales of the e4m3 cross-term operands (exact): x_lo * 2^10, W_hi * 2^6, W_lo * 2^16;
-// E8M0 scale bytes of v_mfma_scale (value 2^(e - 127)) undo them: lanes 0-31 carry the K block
-// "W_lo8 . x_hi8", lanes 32-63 the block "W_hi8 . x_lo8"
-constexpr float F8_XLO_SCALE = 1024.f;
-constexpr int F8_E_XHI = 127, F8_E_XLO = 127 - 10, F8_E_WHI = 127 - 6, F8_E_WLO = 127 - 16;
-
-__device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
-  // OCP e4m3 saturates at 448; clamp first so an out-of-range activation degrades gracefully
-  a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
-  b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
-  c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f);
-  d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (unsigned)w;
-}
-
-constexpr int CI_CHUNK = 16;  // input channels staged per K-chunk (8 MFMA k-pairs)
-
-static int g_k1_gemm = 1;    // sat_conv_set_option("k1_gemm", 0/1): 1x1 convs on split planes through conv1d_f16x3_k1_kernel
-struct ConvArgs {
-  const float* x;
-  const float* w;   // exact-f32 packing, or (split-f16 mode) the f16 hi|lo packing reinterpreted
-  float* y;
-  const float* bias;
-  const float* res;
-  const float* ch_scale;
-  const float* ch_shift;
-  long long x_bs, x_cs, y_bs, y_cs, r_bs, r_cs;
-  long long w_gs;  // packed weight elements per group
-  int cin_g, T_in, rows_g, cout_g, T_q;
-  int ksize, dil, stride, pad_left, up;
-  int cin_pad, co_pad, xw, co_tiles_g;
-  int in_lrelu, relu, accum, gelu, res_after, relu_first;
-  float in_slope, accum_div, res_scale;
-  int res_toff, res_tstride;
-  const void* w2;        // fused pair: packed split-f16 weights of the second conv
-  const float* bias1;    // fused pair: bias of the first conv
-  int fast_epi;  // up == 1 and every (utterance, group) slab addressable with 31-bit byte offsets
-  const void* x16;       // input as split planes (see satools_hip.h), or null
-  void* y16;             // output as split planes, or null
-  float y16_slope;
-  int no_y;
-  const void* res16;     // residual as SAT_SPLIT_F16 planes of lrelu(r, res16_slope) (inverted on the fly), or null
-  float res16_inv;       // 1 / slope
-  int f8;                // planes kernels: cross terms hi*lo + lo*hi on the block-scaled e4m3 MFMA
-  int poly_planes;       // up > 1, planes only: the LDS-transposed polyphase epilogue
-  int y16_f8;            // output planes carry (hi f16 | e4m3(hi) | e4m3(lo * 2^10)) instead of (hi f16 | lo f16)
-  int pp_tiles_t, pp_total, pp_per_xcd, pp_nslots;   // persistent pair kernel: tiles per utterance / in all / per XCD, blocks per XCD
-#ifdef SAT_STAMPS
-  long long* dbg;        // diagnostic build (tools/stamp_conv.hip): per-block, per-chunk phase time stamps
-#endif
-};
-#ifdef SAT_STAMPS
-long long* g_stamp_buffer = nullptr;
-int g_stamp_variant = 0;   // 1: no output stores, 2: no residual, 3: neither
-#define SAT_STAMP(i) do { \
-    __builtin_amdgcn_sched_barrier(0); \
-    unsigned long long t_; \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-    __builtin_amdgcn_sched_barrier(0); \
-    if (p.dbg && tid == 0) p.dbg[((long long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (p.cin_pad / CI_CHUNK) + chunk) * 8 + (i)] = (long long)t_; \
-  } while (0)
-// block-level record in the slots 6/7 of chunk 0 and 1: 100 MHz wall clock at start/end, HW_ID, XCC_ID
-#define SAT_STAMP_BLOCK(i, expr) do { \
-    if (p.dbg && tid == 0) p.dbg[((long long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (p.cin_pad / CI_CHUNK)) * 8 + (i)] = (long long)(expr); \
-  } while (0)
-#else
-#define SAT_STAMP(i)
-#define SAT_STAMP_BLOCK(i, expr)
-#endif
-
-// ---- epilogue shared by the exact-f32 and the split-f16 kernels: bias, residual / bypass, folded
-// BatchNorm, ReLU, MRF accumulation, (polyphase) store ----
-// residual of the whole wave tile fetched ahead of the epilogue (fast path only): issued before the last
-// K-chunk's MFMA phase, the HBM round trip hides under the matrix work instead of stalling the epilogue
-template <int MT, int NT>
-__device__ __forceinline__ void epilogue_prefetch_res(const ConvArgs& p, float (&rpre)[MT][NT][16], int b, int g, int co_w,
-                                                      int q_w, int l31, int lh, int q_step = 32, int q_end = 0x7fffffff) {
-  const long long rb = (long long)b * p.r_bs + (long long)(g * p.cout_g) * p.r_cs;
-  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res ? p.res + rb : p.y), 0, p.res ? (unsigned)(p.rows_g * p.r_cs * 4) : 0u, 0x00020000);
-  const int r_rb = (int)p.r_cs * 4;
-  if (p.res16) {
-    // residual from the split planes: per 4 consecutive rows the 8-byte hi and lo words of this column (raw)
-    const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.res16 + (long long)b * p.rows_g * p.T_q * 4), 0, (unsigned)(p.rows_g * p.T_q * 4), 0x00020000);
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int q = q_w + n * q_step + l31;
-        const bool qok = q < p.T_q && q < q_end;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int chunk = ((co_w + m * 32) >> 4) + (rg >> 1);
-          const unsigned off = (qok && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (rg & 1)) * p.T_q + q) * 16 + 8 * lh) : 0x80000000u;
-          const uint4 hv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 0, 0));   // narrowed to 8 bytes (the b64 builtin of this hipcc loads one dword)
-          const unsigned hv[2] = {hv4.x, hv4.y};
-          const uint4 lv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * p.T_q * 16, 0));
-          const unsigned lv[2] = {lv4.x, lv4.y};
-          rpre[m][n][4 * rg + 0] = __builtin_bit_cast(float, hv[0]);
-          rpre[m][n][4 * rg + 1] = __builtin_bit_cast(float, hv[1]);
-          rpre[m][n][4 * rg + 2] = __builtin_bit_cast(float, lv[0]);
-          rpre[m][n][4 * rg + 3] = __builtin_bit_cast(float, lv[1]);
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int row0 = co_w + m * 32 + 4 * lh;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int q = q_w + n * q_step + l31;
-      const bool qok = q < p.T_q && q < q_end;
-      const unsigned roff = qok ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : 0x80000000u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        rpre[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rrs, roff + ((r & 3) + 8 * (r >> 2)) * r_rb, 0, 0));
-    }
-  }
-}
-
-// raw plane words (hi01, hi23, lo01, lo23 of four consecutive rows) -> the four residual values
-__device__ __forceinline__ void decode_res16(float w0, float w1, float w2, float w3, float inv_slope, float (&out)[4]) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 h01 = __builtin_bit_cast(h2, w0), h23 = __builtin_bit_cast(h2, w1);
-  const h2 l01 = __builtin_bit_cast(h2, w2), l23 = __builtin_bit_cast(h2, w3);
-  out[0] = (float)h01[0] + (float)l01[0];
-  out[1] = (float)h01[1] + (float)l01[1];
-  out[2] = (float)h23[0] + (float)l23[0];
-  out[3] = (float)h23[1] + (float)l23[1];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) out[k] = out[k] > 0.f ? out[k] : out[k] * inv_slope;
-}
-
-template <int MT, int NT, bool RPRE = false>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NT], int b, int g, int co_w,
-                                              int q_w, int l31, int lh, int q_step = 32, int q_end = 0x7fffffff,
-                                              float (*rpre)[NT][16] = nullptr) {
-  const int up = p.up;
-  if (p.fast_epi) {
-    // plain conv (up == 1): every row of this (utterance, group) sits behind one buffer descriptor
-    // whose range check masks rows >= rows_g; lanes past T_q get an out-of-range offset.  Loads of
-    // a 32x32 sub-tile (residual, accumulator) are issued back to back before the arithmetic, so
-    // the epilogue pays one memory round trip per sub-tile instead of one per element.
-    const unsigned OOB = 0x80000000u;
-    const long long yb = (long long)b * p.y_bs + (long long)(g * p.cout_g) * p.y_cs;
-    const __amdgpu_buffer_rsrc_t yrs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + yb), 0, (unsigned)(p.rows_g * p.y_cs * 4), 0x00020000);
-    const long long rb = (long long)b * p.r_bs + (long long)(g * p.cout_g) * p.r_cs;
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.res ? p.res + rb : p.y), 0, p.res ? (unsigned)(p.rows_g * p.r_cs * 4) : 0u, 0x00020000);
-    const unsigned chn = (unsigned)(p.rows_g * 4);
-    const int chb = g * p.cout_g;
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.bias ? p.bias + chb : p.y), 0, p.bias ? chn : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t scs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.ch_scale ? p.ch_scale + chb : p.y), 0, p.ch_scale ? chn : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t shs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.ch_shift ? p.ch_shift + chb : p.y), 0, p.ch_shift ? chn : 0u, 0x00020000);
-    const int y_rb = (int)p.y_cs * 4, r_rb = (int)p.r_cs * 4;  // bytes per row
-    const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.res16 ? (char*)p.res16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
-        p.res16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
-    const bool has_res = p.res != nullptr || p.res16 != nullptr;
-    const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.y16 ? (char*)p.y16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
-        p.y16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int row0 = co_w + m * 32 + 4 * lh;
-      float bi[16], sc[16], sh[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, row0 * 4 + ((r & 3) + 8 * (r >> 2)) * 4, 0, 0));
-      if (p.ch_scale) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ro = ((r & 3) + 8 * (r >> 2)) * 4;
-          sc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scs, row0 * 4 + ro, 0, 0));
-          sh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shs, row0 * 4 + ro, 0, 0));
-        }
-      }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int q = q_w + n * q_step + l31;
-        const bool qok = q < p.T_q && q < q_end;
-        const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
-        const unsigned roff = qok ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : OOB;
-        float rv[16], yv[16];
-        if (p.res16) {
-          float raw[16];
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            if constexpr (RPRE) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) raw[4 * rg + k] = rpre[m][n][4 * rg + k];
-            } else {
-              const int chunk = ((co_w + m * 32) >> 4) + (rg >> 1);
-              const unsigned off = (qok && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (rg & 1)) * p.T_q + q) * 16 + 8 * lh) : OOB;
-              const uint4 hv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 0, 0));   // narrowed to 8 bytes (the b64 builtin of this hipcc loads one dword)
-          const unsigned hv[2] = {hv4.x, hv4.y};
-              const uint4 lv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * p.T_q * 16, 0));
-          const unsigned lv[2] = {lv4.x, lv4.y};
-              raw[4 * rg + 0] = __builtin_bit_cast(float, hv[0]);
-              raw[4 * rg + 1] = __builtin_bit_cast(float, hv[1]);
-              raw[4 * rg + 2] = __builtin_bit_cast(float, lv[0]);
-              raw[4 * rg + 3] = __builtin_bit_cast(float, lv[1]);
-            }
-          }
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            float o[4];
-            decode_res16(raw[4 * rg], raw[4 * rg + 1], raw[4 * rg + 2], raw[4 * rg + 3], p.res16_inv, o);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) rv[4 * rg + k] = o[k];
-          }
-        } else if (p.res) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if constexpr (RPRE)
-              rv[r] = rpre[m][n][r];
-            else
-              rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                    rrs, roff + ((r & 3) + 8 * (r >> 2)) * r_rb, 0, 0));
-          }
-        }
-        if (p.accum) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                  yrs, yoff + ((r & 3) + 8 * (r >> 2)) * y_rb, 0, 0));
-        }
-        // one wave-uniform branch per option around a 16-element pass (not per element: the per-element
-        // form cost ~20k cycles of scalar branching per block); the order of operations is the desc's
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[m][n][r] + bi[r];
-        if (has_res && !p.res_after) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += p.res_scale * rv[r];
-        }
-        if (p.relu && p.relu_first) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-        }
-        if (p.ch_scale) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = v[r] * sc[r] + sh[r];
-        }
-        if (p.relu && !p.relu_first) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-        }
-        if (p.gelu) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            v[r] = v[r] * 0.5f * (1.0f + erff(v[r] * 0.70710678118654752440f));
-          }
-        }
-        if (has_res && p.res_after) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += p.res_scale * rv[r];
-        }
-        if (p.accum) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = yv[r] + v[r];
-        }
-        if (p.accum_div != 0.f) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = v[r] / p.accum_div;
-        }
-        if (!p.no_y) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs,
-                                                  yoff + ((r & 3) + 8 * (r >> 2)) * y_rb, 0, 0);
-        }
-        if (p.y16) {
-          // D layout: rows 8*rg + 4*lh + k (k < 4) of this lane = 8 bytes of the 16-byte unit
-          // (chunk = row/16, half = rg & 1) at its column
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int chunk = ((co_w + m * 32) >> 4) + (rg >> 1);
-            if (chunk * 16 >= p.rows_g) continue;   // wave-uniform: padding rows of a 32-row tile
-            float u[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float t = v[4 * rg + k];
-              u[k] = t > 0.f ? t : t * p.y16_slope;
-            }
-            const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
-            const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-            const unsigned off = qok ? (unsigned)(((chunk * 4 + (rg & 1)) * p.T_q + q) * 16 + 8 * lh) : OOB;
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            u32x2 hv;
-            hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
-            __builtin_amdgcn_raw_buffer_store_b64(hv, y16rs, off, 0, 0);
-            if (p.y16_f8) {
-              // planes 2 / 3 of the chunk: one byte per channel, these four channels = bytes 8*(rg&1) + 4*lh ..
-              const float hf0 = (float)h01[0], hf1 = (float)h01[1], hf2 = (float)h23[0], hf3 = (float)h23[1];
-              const unsigned x8h = pack_e4m3x4(hf0, hf1, hf2, hf3);
-              const unsigned x8l = pack_e4m3x4((u[0] - hf0) * F8_XLO_SCALE, (u[1] - hf1) * F8_XLO_SCALE,
-                                               (u[2] - hf2) * F8_XLO_SCALE, (u[3] - hf3) * F8_XLO_SCALE);
-              const unsigned off8 = qok ? (unsigned)(((chunk * 4 + 2) * p.T_q + q) * 16 + 8 * (rg & 1) + 4 * lh) : OOB;
-              __builtin_amdgcn_raw_buffer_store_b32(x8h, y16rs, off8, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b32(x8l, y16rs, off8, p.T_q * 16, 0);
-            } else {
-              const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-              const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
-              u32x2 lv;
-              lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
-              __builtin_amdgcn_raw_buffer_store_b64(lv, y16rs, off, 2 * p.T_q * 16, 0);
-            }
-          }
-        }
-      }
-    }
-    return;
-  }
-  // general path: polyphase rows (transposed conv) or tensors too large for 32-bit row offsets
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = co_w + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // row inside group
-      if (row >= p.rows_g) continue;
-      int co_l, ph;
-      if (up == 1) {
-        co_l = row;
-        ph = 0;
-      } else {
-        co_l = row / up;
-        ph = row - co_l * up;
-      }
-      const int co = g * p.cout_g + co_l;
-      const float bias = p.bias ? p.bias[co] : 0.f;
-      float sc = 1.f, sh = 0.f;
-      if (p.ch_scale) {
-        sc = p.ch_scale[co];
-        sh = p.ch_shift[co];
-      }
-      float* __restrict__ yrow = p.y + (long long)b * p.y_bs + (long long)co * p.y_cs;
-      const float* __restrict__ rrow =
-          p.res ? p.res + (long long)b * p.r_bs + (long long)co * p.r_cs : nullptr;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int q = q_w + n * q_step + l31;
-        if (q >= p.T_q || q >= q_end) continue;
-        const int t = q * up + ph;
-        float v = acc[m][n][r] + bias;
-        if (rrow && !p.res_after) v += p.res_scale * rrow[(long long)t * p.res_tstride + p.res_toff];
-        if (p.relu && p.relu_first) v = v > 0.f ? v : 0.f;
-        if (p.ch_scale) v = v * sc + sh;
-        if (p.relu && !p.relu_first) v = v > 0.f ? v : 0.f;
-        if (p.gelu) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-        if (rrow && p.res_after) v += p.res_scale * rrow[(long long)t * p.res_tstride + p.res_toff];
-        if (p.accum) v = yrow[t] + v;
-        if (p.accum_div != 0.f) v = v / p.accum_div;
-        yrow[t] = v;
-      }
-    }
-  }
-}
+// sat_conv_set_option("k1_gemm", v): 1x1 convs on split planes through 0 = the conv tile, 1 = conv1d_f16x3_k1_kernel,
+// 2 = gemm_f16x3_ring_kernel where its 256-column tiles fit (else 1)
+static int g_k1_gemm = 2;
 
 template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1, int XWI>
 __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
@@ -589,7 +222,6 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
 // so every A and B fragment is one conflict-free ds_read_b128 and the main loop issues no global
 // loads.  Weights arrive packed as w16[g][chunk][tap][hi|lo][half][co_pad][8] f16.
 // ------------------------------------------------------------------------------------------------
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 template <int MT, int NT, int KS, int XWI>
 __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) {
@@ -2035,8 +1667,13 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;   // bytes per group
     // 1x1 on split planes with enough rows: the GEMM kernel (activation fragments straight from the planes)
     if (a.x16 && a.ksize == 1 && !a.f8 && !a.poly_planes && a.fast_epi && d->groups == 1 && a.rows_g >= 128 &&
-        (a.cin_pad / CI_CHUNK) % 4 == 0 && g_k1_gemm)
+        (a.cin_pad / CI_CHUNK) % 4 == 0 && g_k1_gemm) {
+      // ring kernel: whole 128-row weight tiles, and 256-column tiles that pad the time axis (nearly) no more than
+      // 128-column ones (249 frames: 256 either way; 49 frames: the 128-column kernel)
+      const long long c256 = (long long)ceil_div(a.T_q, 256) * 256, c128 = (long long)ceil_div(a.T_q, 128) * 128;
+      if (g_k1_gemm >= 2 && a.co_pad % 128 == 0 && c256 * 8 <= c128 * 9) return launch_f16x3_ring(a, d->B, s);
       return launch_f16x3_k1(a, d->B, s);
+    }
     // few blocks (TDNNF linearB: 128 rows x 250 frames x 32 utterances = 64 tiles of 64 x 256 on 256 CUs): half-width
     // tiles double the blocks of these latency-bound launches
     if (a.x16 && a.ksize == 3 && !a.f8 && !a.poly_planes && a.rows_g > 32 && a.T_q > 128 &&
@@ -2140,7 +1777,7 @@ extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, in
 
 extern "C" int sat_conv_set_option(const char* name, int value) {
   SAT_REQUIRE(name, "conv_set_option: null name");
-  if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value != 0; return SAT_OK; }
+  if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 2 ? 2 : value; return SAT_OK; }
   set_error("conv_set_option: unknown option '%s'", name);
   return SAT_ERR_INVALID;
 }

@@ -1,0 +1,179 @@
+// LDS-DMA ring GEMM for 1x1 convolutions on split planes (wav2vec2 Linear layers, TDNNF linearA, output affines).
+#include "conv_common.h"
+
+#include <type_traits>
+
+namespace sat {
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution on split planes, ring form: BOTH operands go global -> LDS by LDS-DMA (`buffer_load ... lds`,
+// 16 bytes per lane, no staging registers, no ds_write pass) into a ring of six one-chunk buffers, with the loads of
+// four chunks in flight across the barriers: per 16-channel chunk ONE raw s_barrier behind a COUNTED s_waitcnt vmcnt
+// (never 0 before the tail; hipcc keeps ds_reads clear of pending LDS-DMA of other buffers as long as all LDS is one
+// array — MI355X guide, "Pipelining across barriers"), and the barrier stands between a chunk's fragment reads and
+// its MFMAs: a wave arrives with 12 MFMAs' operands already in registers, passes, issues the next chunk's loads and
+// fragment reads and only then multiplies — the matrix pipe never waits for an LDS round trip behind a barrier.
+// Block = 8 waves as 2 (rows) x 4 (columns) over a 128-row x 256-column tile, wave tile 64 x 64 (A and B fragment
+// reuse 2 each: 8 ds_read_b128 per 12 MFMAs), per chunk:
+//   A  [hi|lo][half][128 rows]    x 16 B    8 KB — the packed weights as they lie in memory
+//   B  [hi|lo][half][256 columns] x 16 B   16 KB — the planes as they lie in memory
+// Both images are lane-linear (a wave-instruction = 64 consecutive 16-byte units of one segment), which is what
+// LDS-DMA needs and what makes every fragment read a conflict-free ds_read_b128.  6 x 24 KB of LDS, one block per
+// CU; 1024-row layers at 249 frames x 32 utterances = 256 blocks = one per CU, 4096 rows = 4 per CU.
+// Per-accumulator arithmetic (chunk order, lo*hi, hi*lo, hi*hi) is that of conv1d_f16x3_k1_kernel: same bits.
+// Against that kernel (weights through registers + ds_write, activations straight to registers, 128 x 128 tile,
+// two blocks per CU): half the L2 -> CU bytes per MFMA, no VGPRs spent on staging, loads four chunks ahead.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 2) gemm_f16x3_ring_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  constexpr int CO_B = 128, T_B = 256, MT = 2, NT = 2, RING = 6;
+  constexpr int A_UNITS = 4 * CO_B, B_UNITS = 4 * T_B, ST_UNITS = A_UNITS + B_UNITS;     // 16-byte units of a chunk
+  constexpr int A_PIECES = A_UNITS / 64, PIECES = ST_UNITS / 64, PPW = PIECES / 8;       // 1 KB wave-instructions
+  static_assert(PIECES % 8 == 0 && PPW == 3 && RING == 6, "the vmcnt literals below assume three pieces per wave and chunk, six buffers");
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // block -> (co tile, time tile, utterance): the co tiles of one (utterance, time tile) share an XCD (its L2 serves
+  // the activations to all of them); division results kept scalar (conv1d_f16x3_k1_kernel)
+  const int n_co = p.co_tiles_g, n_tt = p.pp_tiles_t;
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int co_t = __builtin_amdgcn_readfirstlane(rest % n_co);
+  const int g = __builtin_amdgcn_readfirstlane((rest / n_co) * 8 + xcd);
+  if (g >= p.pp_total) return;
+  const int b = __builtin_amdgcn_readfirstlane(g / n_tt);
+  const int co_b = co_t * CO_B;
+  const int q_b = (g - b * n_tt) * T_B;
+  const int nch = p.cin_pad / CI_CHUNK;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.x16 + (long long)b * p.cin_g * p.T_in * 4), 0, (unsigned)(p.cin_g * p.T_in * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
+  const int seg_bytes = p.co_pad * 16;
+  const int x_chunk_bytes = 4 * p.T_in * 16;
+
+  // this wave's three pieces of a chunk: per-lane byte offset, scalar step per chunk, LDS unit
+  unsigned voff[PPW];
+  int sstep[PPW], lunit[PPW];
+  bool is_a[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int u = wave * PPW + j;
+    is_a[j] = u < A_PIECES;
+    if (is_a[j]) {
+      const int seg = u >> 1, half = u & 1;
+      voff[j] = (unsigned)((co_b + half * 64 + lane) * 16 + seg * seg_bytes);
+      sstep[j] = 4 * seg_bytes;
+      lunit[j] = seg * CO_B + half * 64;
+    } else {
+      const int v = u - A_PIECES;
+      const int plane = v >> 2, cq = v & 3;
+      const int xi = q_b + cq * 64 + lane - p.pad_left;
+      voff[j] = (xi >= 0 && xi < p.T_in) ? (unsigned)((plane * p.T_in + xi) * 16) : 0x80000000u;
+      sstep[j] = x_chunk_bytes;
+      lunit[j] = A_UNITS + plane * T_B + cq * 64;
+    }
+    // wave-uniform by construction; made PROVABLY scalar, or every LDS-DMA below sits in a waterfall loop over its
+    // scalar offset (a v_readfirstlane / s_and_saveexec round per piece)
+    sstep[j] = __builtin_amdgcn_readfirstlane(sstep[j]);
+    lunit[j] = __builtin_amdgcn_readfirstlane(lunit[j]);
+  }
+  auto issue = [&](int ch, int ring) {
+    uint4* dst = lds4 + ring * ST_UNITS;
+    // device pass only: in the host pass this target builtin is a deferred error that silently drops the kernel's
+    // host stub (the handle stays an undefined external and the fat binary is not embedded)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int j = 0; j < PPW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a[j] ? wrs : xrs, (__attribute__((address_space(3))) void*)(uintptr_t)(dst + lunit[j]), 16,
+                                               voff[j], ch * sstep[j], 0, 0);
+#else
+    (void)dst;
+#endif
+  };
+  h8 fa[2][MT][2], fb[2][NT][2];          // fragments of the chunk being multiplied and of the next one
+  auto read_frags = [&](int buf, int ring) {
+    const uint4* wb = lds4 + ring * ST_UNITS + lh * CO_B + wm * 64 + l31;
+    const uint4* xb = lds4 + ring * ST_UNITS + A_UNITS + lh * T_B + wn * 64 + l31;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      fa[buf][m][0] = __builtin_bit_cast(h8, wb[0 * CO_B + m * 32]);
+      fa[buf][m][1] = __builtin_bit_cast(h8, wb[2 * CO_B + m * 32]);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      fb[buf][n][0] = __builtin_bit_cast(h8, xb[0 * T_B + n * 32]);
+      fb[buf][n][1] = __builtin_bit_cast(h8, xb[2 * T_B + n * 32]);
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // prologue: chunks 0..4 in flight, chunk 0 landed and visible, its fragments read
+#pragma unroll
+  for (int c = 0; c < RING - 1; ++c)
+    if (c < nch) issue(c, c);
+  if (nch > RING - 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // all but the four youngest chunks = chunk 0
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  read_frags(0, 0);
+  int ring = 0;                              // buffer of chunk c
+  auto body = [&](int c, auto cur) {
+    constexpr int CUR = decltype(cur)::value;
+    // hand-over point: chunk c + 1 landed (this wave's pieces: all but the three youngest chunks c+2..c+4), this wave's
+    // reads of chunk c are back; then everybody's are, and everybody's chunk c + 1 is visible
+    if (c + 1 < nch) {
+      if (c + RING - 2 < nch) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      const int nxt = ring == RING - 1 ? 0 : ring + 1;
+      if (c + RING - 1 < nch) issue(c + RING - 1, ring == 0 ? RING - 1 : ring - 1);   // buffer of chunk c - 1: every wave has left it
+      read_frags(CUR ^ 1, nxt);
+      ring = nxt;
+    }
+    __builtin_amdgcn_sched_barrier(0);       // the reads above stay ahead of these MFMAs (they feed the NEXT chunk)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][m][1], fb[CUR][n][0], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][m][0], fb[CUR][n][1], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][m][0], fb[CUR][n][0], acc[m][n], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int c = 0;
+  for (; c + 1 < nch; c += 2) {              // two chunks per trip: the fragment register sets alternate statically
+    body(c, std::integral_constant<int, 0>{});
+    body(c + 1, std::integral_constant<int, 1>{});
+  }
+  if (c < nch) body(c, std::integral_constant<int, 0>{});
+  conv_epilogue<MT, NT>(p, acc, b, 0, co_b + wm * 64, q_b + wn * 64, l31, lh);
+}
+
+int launch_f16x3_ring(const ConvArgs& a, int B, hipStream_t s) {
+  ConvArgs p = a;
+  p.xw = 256;
+  p.co_tiles_g = ceil_div(p.rows_g, 128);
+  p.pp_tiles_t = ceil_div(p.T_q, 256);
+  p.pp_total = p.pp_tiles_t * B;
+  const size_t lds_bytes = (size_t)6 * (4 * 128 + 4 * 256) * 16;
+  auto kern = gemm_f16x3_ring_kernel;
+  static std::atomic<uint64_t> attr_done{0};      // per device
+  int dev;
+  if (attr_needed_on_current_device(attr_done, &dev)) {
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done_on_device(attr_done, dev);
+  }
+  dim3 grid(8 * p.co_tiles_g * ceil_div(p.pp_total, 8), 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, s, p);
+  SAT_LAUNCH_CHECK("gemm_f16x3_ring_kernel");
+  return SAT_OK;
+}
+
+}  // namespace sat

@@ -7,7 +7,7 @@
 
 namespace sat {
 
-__device__ __forceinline__ float gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float v) { return gelu_fast(v); }
 
 // y[b][c][t] = bias[c] + sum_j w[c][j] * x[b][t*stride + j]      (C <= 512, k <= 16)
 __global__ void __launch_bounds__(256) w2v2_conv0_kernel(const float* __restrict__ x, const float* __restrict__ w,

@@ -259,3 +259,19 @@ def test_asr_forward_matches_reference(model, gold):
     assert (torch.logsumexp(xent.cpu(), dim=2) - torch.from_numpy(fx["harm01_16000/xent_lse"])).abs().max() < 1e-3
     x = (torch.arange(2 * 32000, dtype=torch.float32).reshape(2, 32000) / 64000.0).to(DEV)
     assert list(model.bn_extractor(x)[0].shape) == gold.json("fx_shapes_w2v2.json")["forward_2x32000"] == [2, 66, 3280]
+
+
+def test_fast_gelu_accuracy():
+    """the GELU of the epilogues (branch-free erf: Abramowitz-Stegun 7.1.26 above |x| = 0.6, Taylor below) against
+    torch's exact-erf GELU in float64, isolated from every matrix product: LayerNorm+GELU kernel vs GELU of the same
+    kernel's plain LayerNorm output"""
+    from satools_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(2, 512, 400, generator=g) * 2.5).to(DEV)
+    gamma, beta = (1 + 0.5 * torch.randn(512, generator=g)).to(DEV), (0.5 * torch.randn(512, generator=g)).to(DEV)
+    ln = ops.layernorm_ch(x, gamma, beta)
+    got = ops.layernorm_ch(x, gamma, beta, gelu=True).cpu().double()
+    ref = F.gelu(ln.cpu().double())
+    err = (got - ref).abs().max().item()
+    print("fast GELU max abs error vs float64 exact GELU:", err, "(inputs up to", ln.abs().max().item(), ")")
+    assert err < 6e-7

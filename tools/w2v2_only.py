@@ -1,20 +1,35 @@
-"""time the wav2vec2-tag bottleneck extractor alone (batch 32 x 5 s)"""
+"""time the wav2vec2-tag bottleneck extractor alone (batch 32 x 5 s); with `ab`: the 1x1 GEMM kernels interleaved in
+one process (k1_gemm = 1: 128 x 128 register-staged kernel, 2: LDS-DMA ring kernel), five rounds of five forwards each"""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import satools_amd
-from satools_amd import synthetic
+from satools_amd import _lib, synthetic
 
 model = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_wav2vec2_vq_48_v1")
 model.to("cuda")
 wav = synthetic.harm_batch(list(range(32))).to("cuda")
-for _ in range(2):
-    model.get_bn(wav)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(5):
-    model.get_bn(wav)
-e1.record()
-torch.cuda.synchronize()
-print("wav2vec2-tag get_bn %.2f ms" % (e0.elapsed_time(e1) / 5))
+
+
+def run(n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        model.get_bn(wav)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+run(2)
+if len(sys.argv) > 1 and sys.argv[1] == "ab":
+    res = {1: [], 2: []}
+    for rnd in range(5):
+        for opt in (1, 2):
+            _lib.check(_lib.lib().sat_conv_set_option(b"k1_gemm", opt), "set_option")
+            res[opt].append(run(5))
+    for opt in (1, 2):
+        print(f"k1_gemm={opt}: get_bn ms per batch, five rounds: " + " ".join(f"{v:.2f}" for v in res[opt]) + f"   median {sorted(res[opt])[2]:.2f}")
+else:
+    print("wav2vec2-tag get_bn %.2f ms" % run(5))
