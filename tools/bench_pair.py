@@ -3,7 +3,7 @@ split-plane activations: the fused pair kernel vs two launches of the planes con
   python tools/bench_pair.py [f8] [stage indices]"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import satools_amd
 from satools_amd import ops, packing
 

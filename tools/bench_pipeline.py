@@ -8,7 +8,7 @@ import time
 import types
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 sys.path.insert(0, "tests")
 import numpy as np
 import torch

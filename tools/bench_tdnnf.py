@@ -1,7 +1,7 @@
 """micro-benchmark of the TDNNF layer shapes (linearB 1024x3 -> 128, linearA 128 -> 1024 + BN + ReLU + bypass)"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import satools_amd
 from satools_amd import ops, packing
 

@@ -1,7 +1,7 @@
 """micro-benchmark of the five polyphase upsamplers (split planes in, f32 out) and the split pass that follows"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import satools_amd
 from satools_amd import ops, packing
 

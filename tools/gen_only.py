@@ -1,7 +1,7 @@
 """run only the generator forward (batch 32 x 250 frames) a few times: for rocprofv3 --kernel-trace --stats"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import satools_amd
 
 model = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1")

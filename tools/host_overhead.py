@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import satools_amd
 from satools_amd import synthetic
 m = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1"); m.to("cuda"); m.eval()

@@ -4,7 +4,7 @@ import os
 import sys
 import time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import satools_amd
 from satools_amd import synthetic

@@ -1,5 +1,5 @@
 import sys, torch, numpy as np, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import satools_amd
 from satools_amd import synthetic, asrbn
 fx = np.load("tests/golden/fx_tdnnf.npz")

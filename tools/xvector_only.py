@@ -1,7 +1,7 @@
 """time the x-vector extractor (ECAPA-TDNN) on 5 s utterances at batch 1 and 32, both arithmetic settings"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import satools_amd
 from satools_amd import synthetic, xvector
 
