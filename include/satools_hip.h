@@ -68,8 +68,11 @@ int sat_device_info(char* name, int name_len, int* cu_count);
  * ------------------------------------------------------------------------------------------ */
 /* arithmetic of the matrix products:
  *   SAT_CONV_F32   v_mfma_f32_32x32x2_f32, exact f32 (bit-for-bit a k-ordered fma chain)
- *   SAT_CONV_F16X3 operands split as hi + lo f16 (22 significand bits), products hi*hi + hi*lo + lo*hi
- *                  on v_mfma_f32_32x32x16_f16 with f32 accumulation (~2^-21 relative per product);
+ *   SAT_CONV_F16X3 operands split as hi + lo f16, products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with
+ *                  f32 accumulation.  hi + lo carries 22 significand bits (~2^-21 relative per product) while lo is a
+ *                  normal f16, i.e. for |x| above ~0.125 (lo >= 2^-14); below that lo is subnormal and the split is an
+ *                  ABSOLUTE error of 2^-25; operands must stay inside the f16 range (|x| < 65504: larger values are
+ *                  not supported, they would saturate hi).  Generator and encoder activations are O(1) - O(30).
  *                  weights packed as w16[g][cin_pad/16][ksize][hi|lo][channel half][co_pad][8] f16; stride 1;
  *                  ksize in {1, 2, 3, 7, 11} with f32 input, {1, 3, 7, 11} with split-plane input (x_split);
  *                  operands must lie inside the f16 range (|x| < 65504). */

@@ -37,6 +37,15 @@ inline int check_hip(hipError_t e, const char* what) {
     }                                   \
   } while (0)
 
+// a caller-owned workspace smaller than sat_*_workspace_bytes() asked for: its own status code (satools_hip.h)
+#define SAT_REQUIRE_WORKSPACE(cond, ...)  \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::sat::set_error(__VA_ARGS__);      \
+      return SAT_ERR_WORKSPACE;           \
+    }                                     \
+  } while (0)
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: a launcher that raises it remembers which
 // devices it has done so on.  `done` = one bit per device ordinal; the bit is published only after the attribute
 // calls have returned (they are idempotent, so two host threads racing here both make them).

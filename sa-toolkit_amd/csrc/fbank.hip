@@ -224,7 +224,7 @@ extern "C" int sat_fbank_cmvn_pad_f32(const float* wav, float* feats, const floa
   // reference asserts 2 <= window_size <= len(waveform) (kaldifeature.py:189-191)
   SAT_REQUIRE(n >= FB_WIN, "fbank: choose a window size %d that is [2, %d]", FB_WIN, n);
   const int m = (n + FB_SHIFT / 2) / FB_SHIFT;
-  SAT_REQUIRE(workspace_bytes >= (size_t)B * n_mel * (m + 1) * sizeof(float), "fbank: workspace too small");
+  SAT_REQUIRE_WORKSPACE(workspace_bytes >= (size_t)B * n_mel * (m + 1) * sizeof(float), "fbank: workspace too small");
   float* raw = (float*)workspace;
   float* means = raw + (size_t)B * n_mel * m;
   dim3 grid(ceil_div(m, FB_FRAMES_PER_BLOCK), B);

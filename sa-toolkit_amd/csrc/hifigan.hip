@@ -278,7 +278,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
   SAT_REQUIRE(B > 0 && T > 0, "hifigan_forward: empty batch");
   for (size_t i = 0; i < h->convs.size(); ++i)
     SAT_REQUIRE(h->convs[i].w && h->convs[i].bias, "hifigan_forward: conv %zu has no weights", i);
-  SAT_REQUIRE(workspace_bytes >= sat_hifigan_workspace_bytes(h, B, T), "hifigan_forward: workspace too small");
+  SAT_REQUIRE_WORKSPACE(workspace_bytes >= sat_hifigan_workspace_bytes(h, B, T), "hifigan_forward: workspace too small");
   const size_t slot = align_up(hifigan_max_elems(h, B, T) * sizeof(float), 256);
   float* buf[6];
   for (int i = 0; i < 6; ++i) buf[i] = (float*)((char*)workspace + i * slot);

@@ -1061,7 +1061,7 @@ static int yaapt_run(const sat_yaapt_plan* plan, const float* wav, const int32_t
   SAT_REQUIRE(P.median_value >= 1 && P.median_value <= 7 && (P.median_value & 1), "yaapt: median_value must be odd <= 7");
   SAT_REQUIRE(P.nframes >= 4 && P.nframes <= 2048, "yaapt: %d frames not supported (4..2048, i.e. up to ~40 s)", P.nframes);
   SAT_REQUIRE(P.tda_nframes == P.nframes, "yaapt: tda frame count differs from the analysis frame count");
-  SAT_REQUIRE(workspace_bytes >= sat_yaapt_workspace_bytes(plan, B), "yaapt: workspace too small");
+  SAT_REQUIRE_WORKSPACE(workspace_bytes >= sat_yaapt_workspace_bytes(plan, B), "yaapt: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const size_t nf = P.nframes;
   float* w = (float*)workspace;

@@ -52,7 +52,27 @@ def split_dict(a, n):
 
 # ---- utils/kaldi.py:85-128 (torchaudio.load restated) ---------------------------------------------
 def _decode_wav(fileobj):
+    """RIFF wav through scipy; anything else (the reference reads flac through torchaudio.load: LibriSpeech and
+    LibriTTS ship as flac) through `soundfile` when it is installed, else a clear error naming the shell-pipe entry
+    that always works"""
     from scipy.io import wavfile
+    head = b""
+    if isinstance(fileobj, (str, os.PathLike)):
+        with open(fileobj, "rb") as f:
+            head = f.read(4)
+    else:
+        head = fileobj.read(4)
+        fileobj.seek(0)
+    if head != b"RIFF":
+        try:
+            import soundfile
+        except ImportError:
+            kind = "flac" if head == b"fLaC" else repr(head)
+            raise IOError(f"{fileobj if isinstance(fileobj, (str, os.PathLike)) else 'piped audio'}: not a RIFF wav ({kind}) and "
+                          "the `soundfile` package is not installed; write the wav.scp entry as a decoding pipe, e.g. "
+                          "`flac -c -d -s /path/utt.flac |`")
+        data, sr = soundfile.read(fileobj, dtype="float32", always_2d=True)
+        return torch.from_numpy(np.ascontiguousarray(data.T)), int(sr)
     sr, data = wavfile.read(fileobj)
     if data.dtype == np.int16:
         x = data.astype(np.float32) / 32768.0
@@ -89,7 +109,10 @@ def load_wav_from_scp(wav, frame_offset=0, num_frames=-1):
 
 
 def save_pcm16(path, wav, freq):
-    """torchaudio.save(path, wav, freq, encoding='PCM_S', bits_per_sample=16) restated: [channels, n] f32 -> RIFF"""
+    """torchaudio.save(path, wav, freq, encoding='PCM_S', bits_per_sample=16) restated: [channels, n] f32 -> RIFF.
+    UNPINNED against torchaudio (third party, not installable here): round-half-even of x * 32768 with clipping; a sox
+    / ffmpeg backend that truncates or scales by 32767 differs by at most 1 LSB (3e-5 of full scale, below the
+    path's 1e-4 RMS bar)"""
     from scipy.io import wavfile
     x = wav.detach().cpu().numpy().astype(np.float64)
     pcm = np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16)

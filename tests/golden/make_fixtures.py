@@ -379,6 +379,13 @@ def main():
             out["harm01_16000/xent_lse"] = torch.logsumexp(xent, dim=2).numpy()
             out["harm01_16000/after0_sub"] = acts2["after0"][..., ::16].numpy()
             out["harm01_16000/vq_layer_sub"] = acts2["vq_layer"][..., ::16].numpy()
+            # configs[3]: the wav2vec2 tag with option f0-transformation=quant_16_awgn_2 (a second Net built with that arg)
+            net4 = build_reference_model(ref, name2, f0_transformation="quant_16_awgn_2")
+            net4.load_state_dict(st2["base_model_state_dict"], strict=True)
+            net4.eval()
+            torch.manual_seed(1234)
+            out["harm01_16000/convert_quant16_awgn2_seed1234"] = net4.convert(w.clone(), target=[net4.spk[3], net4.spk[10]]).numpy()
+            del net4
             shapes2 = {"forward_2x32000": list(bx2(torch.arange(2 * 32000, dtype=torch.float32).reshape(2, 32000) / 64000.0)[0].shape)}
             for n in (16000, 32000, 80000):
                 ww = synthetic.harm_batch([2], n)

@@ -650,3 +650,69 @@ def test_weight_caches_follow_in_place_updates():
         y1 = m.hifigan(x)[0].clone()
         p.div_(1.5)
     assert not torch.equal(y0, y1)
+
+
+def test_c_abi_reports_errors_as_status_codes():
+    """the C ABI never throws: a too-small workspace comes back as SAT_ERR_WORKSPACE (-3), bad arguments / unsupported
+    shapes as SAT_ERR_INVALID (-1), each with a message behind sat_last_error(); the Python layer turns them into
+    SatError"""
+    import ctypes as C
+    from satools_amd import _lib, f0 as f0_hip, synthetic
+    from satools_amd._lib import lib, ptr, stream
+    l = lib()
+    # YAAPT with a workspace one byte short
+    wav = synthetic.harm_batch([0], 16000).to(DEV)
+    P = f0_hip.make_plan(16000, {"frame_length": 35.0, "frame_space": 20.0, "nccf_thresh1": 0.25, "tda_frame_length": 25.0})
+    hann, kaiser, tw = f0_hip._get_tables(P, wav.device)
+    need = l.sat_yaapt_workspace_bytes(C.byref(P), 1)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=DEV)
+    f0 = torch.empty(1, P.nframes, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    rc = l.sat_yaapt_f32(C.byref(P), ptr(wav), ptr(f0), ptr(status), ptr(hann), ptr(kaiser), ptr(tw), ptr(ws), need - 1, 1, stream())
+    assert rc == -3, rc
+    assert b"workspace" in l.sat_last_error()
+    assert l.sat_yaapt_f32(C.byref(P), ptr(wav), ptr(f0), ptr(status), ptr(hann), ptr(kaiser), ptr(tw), ptr(ws), need, 1, stream()) == 0
+    # generator with a workspace that is too small
+    m = _model()
+    x = torch.randn(1, m.hifigan.imput_dim, 20, device=DEV)
+    m.hifigan(x)
+    g = m.hifigan
+    need = l.sat_hifigan_workspace_bytes(g._handle, 1, 20)
+    small = torch.empty(16, dtype=torch.float32, device=DEV)
+    y = torch.empty(1, 1, 20 * 320 + 1, device=DEV)
+    rc = l.sat_hifigan_forward_f32(g._handle, ptr(x), ptr(y), ptr(small), 64, 1, 20, stream())
+    assert rc == -3, rc
+    assert need > 64 and l.sat_last_error()
+    # null pointers / unsupported values -> SAT_ERR_INVALID
+    assert l.sat_f0_stats_f32(None, 10, None, stream()) == -1
+    assert l.sat_f0_mean_reversion_f32(ptr(f0), ptr(f0), P.nframes, C.c_float(0.5), 32, stream()) == -1      # out == in
+    assert l.sat_conv_set_option(b"no_such_option", 1) == -1 and b"no_such_option" in l.sat_last_error()
+    # and through the Python layer
+    with pytest.raises(_lib.SatError):
+        _lib.check(l.sat_conv_set_option(b"no_such_option", 1), "sat_conv_set_option")
+
+
+@pytest.mark.parametrize("T,dil", [(129, 3), (200, 5), (256, 1)])
+def test_half_width_tiles_of_the_3_tap_planes_conv(T, dil):
+    """the 64-row x 128-column tile of the 3-tap planes conv is only dispatched for launches of fewer than 256 blocks
+    (rows 128, 129..256 frames, few utterances): pinned here with dilation, residual from planes and MRF-style
+    accumulation, against the same conv on the exact-f32 kernel and against torch in float64"""
+    ops, packing = _ops()
+    B, C = 2, 128
+    x, w, b = _rand(B, C, T, seed=1), _rand(C, C, 3, seed=2, scale=0.05), _rand(C, seed=3, scale=0.1)
+    r, acc0 = _rand(B, C, T, seed=4), _rand(B, C, T, seed=5)
+    xd, rd = x.to(DEV), r.to(DEV)
+    xs = ops.act_split(xd, 0.1)
+    rs = ops.act_split(rd, 0.1)
+    ref = F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), dilation=dil, padding=dil) + r.double()
+    ref = (acc0.double() + ref) / 3.0
+    out = acc0.clone().to(DEV)
+    y = ops.conv1d(xd, packing.pack_conv_weight_f16x3(w.to(DEV)), C, 3, bias=b.to(DEV), dilation=dil, pad_left=dil, mode=1,
+                   x_split=xs, res_split=rs, res_split_slope=0.1, out=out, accum=True, accum_div=3.0)
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < 3e-5, err
+    # the same launch with the f32 residual: the planes residual reproduces it to 2^-19
+    out2 = acc0.clone().to(DEV)
+    y2 = ops.conv1d(xd, packing.pack_conv_weight_f16x3(w.to(DEV)), C, 3, bias=b.to(DEV), dilation=dil, pad_left=dil, mode=1,
+                    x_split=xs, res=rd, out=out2, accum=True, accum_div=3.0)
+    assert (y2 - y).abs().max().item() <= 2.0 ** -19 * float(r.abs().max())

@@ -275,3 +275,52 @@ def test_fast_gelu_accuracy():
     err = (got - ref).abs().max().item()
     print("fast GELU max abs error vs float64 exact GELU:", err, "(inputs up to", ln.abs().max().item(), ")")
     assert err < 6e-7
+
+
+def test_full_size_batch_properties_w2v2_tag(model):
+    """BASELINE configs[2] at full size (32 x 5 s; grids, the 31-bit fast-epilogue addressing switch and the 1 GB conv-0
+    tensor differ from the B <= 2 cases): (1) the bottleneck extractor treats utterances independently up to the
+    reference's own `pad_input` batch mixing — the wav2vec2 features of any slice equal those rows of the full batch,
+    bit for bit; (2) `convert` is deterministic, finite, in range, of the right shape; (3) VQ indices of three
+    utterances equal those of one-utterance calls wherever the padding frames cannot reach (frames 3 .. T - 4)."""
+    from satools_amd import synthetic
+    from satools_amd.wav2vec2 import CONV_LAYERS
+    seeds = list(range(32))
+    wav = synthetic.harm_batch(seeds).to(DEV)
+    targets = synthetic.targets(model.spk, seeds)
+    y = model.convert(wav, target=targets)
+    assert y.shape == (32, 1, 80001) and bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 1.0
+    assert torch.equal(y, model.convert(wav, target=targets))
+    ext = model.bn_extractor
+    lens, t = [], 80000
+    for _, k, s in CONV_LAYERS:
+        t = (t - k) // s + 1
+        lens.append(t)
+    ext._fe_len = lens
+    full = ext.w2v2_features(wav).clone()                  # [32, 1024, 249]
+    assert full.shape == (32, 1024, 249)
+    for sl in (slice(0, 1), slice(5, 9), slice(29, 32)):
+        assert torch.equal(ext.w2v2_features(wav[sl].contiguous()), full[sl])
+    _, (z, idx, dist) = ext.extract_bn(wav.clone(), want_aux=True)
+    assert idx.shape == (32, 250)
+    for i in (0, 17, 31):
+        _, (_, idx1, _) = ext.extract_bn(wav[i:i + 1].clone(), want_aux=True)
+        assert torch.equal(idx1[0, 3:-3], idx[i, 3:-3]), i
+
+
+def test_convert_w2v2_tag_quant_awgn_matches_fixture(gold):
+    """BASELINE configs[3]: wav2vec2 tag + f0-transformation=quant_16_awgn_2, F0 computed on the path, against the
+    reference's own `convert` run under torch.manual_seed(1234)"""
+    import satools_amd
+    from satools_amd import synthetic
+    fx = gold.npz("fx_w2v2.npz")
+    m = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_wav2vec2_vq_48_v1", option_args={"f0_transformation": "quant_16_awgn_2"})
+    m.to(DEV)
+    m.eval()
+    torch.manual_seed(1234)
+    y = m.convert(synthetic.harm_batch([0, 1], 16000).to(DEV), target=[m.spk[3], m.spk[10]])
+    ref = fx["harm01_16000/convert_quant16_awgn2_seed1234"]
+    assert y.shape == ref.shape == (2, 1, 16001)
+    err = rms(y.cpu().numpy() - ref)
+    print("wav2vec2-tag convert quant_16_awgn_2 RMS error vs reference run:", err)
+    assert err < 1e-4

@@ -92,3 +92,20 @@ def test_pipe_entries_and_unknown_algorithm(tmp_path):
     assert sr == 16000 and torch.equal(a, b) and a.shape == (1, 3000)
     with pytest.raises(ValueError):
         pl.TargetSelector("nearest", ["a"], {})
+
+
+def test_non_riff_audio_gives_a_clear_error(tmp_path):
+    """wav.scp entries that point straight at a flac file (the reference reads them through torchaudio.load): decoded by
+    `soundfile` when installed, else an IOError that names the `flac -c -d -s f |` pipe entry"""
+    from satools_amd import pipeline as P
+    f = tmp_path / "utt.flac"
+    f.write_bytes(b"fLaC" + b"\0" * 64)
+    try:
+        import soundfile  # noqa: F401
+        have = True
+    except ImportError:
+        have = False
+    if not have:
+        import pytest
+        with pytest.raises(IOError, match="flac -c -d -s"):
+            P.load_wav_from_scp(str(f))
