@@ -4,20 +4,21 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
 A "step" = one `model.convert` over one batch of 32 synthetic 5 s @ 16 kHz utterances per rank, everything on
-the path (YAAPT F0, bottleneck extractor, one-hot, generator), inputs resident in HBM.  Rank 0 prints one JSON
-line per measured BASELINE.json config; the LAST line is the headline (configs[1]: tag
-hifigan_bn_tdnnf_600h_vq_48_v1) the driver records, the lines before it are the other configs:
+the path (YAAPT F0, bottleneck extractor, one-hot, generator), inputs resident in HBM.  Rank 0 prints ONE JSON line
+on stdout: the headline (BASELINE configs[1]: tag hifigan_bn_tdnnf_600h_vq_48_v1).  The other BASELINE configs are
+measured in the same run, before it; their full lines (same schema) go to stderr prefixed `CONFIG_LINE ` and their
+value / roofline / cpu_baseline, condensed, into the headline's `configs` object:
 
   N = 1   configs[2] (wav2vec2 tag), configs[3] (wav2vec2 tag + f0-transformation=quant_16_awgn_2), then the
-          headline; every line carries its own `roofline` and `cpu_baseline`.
+          headline; each with its own `roofline` and `cpu_baseline`.
   N > 1   one process per GPU under torch.distributed (RCCL).  `python bench.py --gpus N` typed as is starts
           `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (the parent never
           touches the GPU) and relays its output and exit code; under the driver's own torch.distributed.run
           launch the ranks are used as they are.  Workload per line = the sharded job of SURVEY §8(d)/(e):
           N x K x 32 utterances, contiguous shards of K x 32 per rank, batches of 32 in index order
           (satools_amd.dist.convert_sharded), ONE all_gather_into_tensor of the [K*32, 1, 80001] shards at the
-          end, inside the timed region.  First line = BASELINE configs[4] (wav2vec2 tag; K = 16 at N = 8 is exactly
-          its 4096 utterances), last line = the headline tag through the same code (weak scaling: the per-GPU
+          end, inside the timed region.  BASELINE configs[4] (wav2vec2 tag; K = 16 at N = 8 is exactly its 4096
+          utterances) is measured first, then the headline tag through the same code (weak scaling: the per-GPU
           work is fixed, so the driver's N = 1, 2, 4, 8 values are comparable).
 
 The CPU leg (`cpu_baseline`, rank 0 at N = 1 only) times the oracle — a port of the reference's PyTorch CPU path —
@@ -485,14 +486,29 @@ def main():
         if rank == 0:
             lines.append(out)
     if rank == 0:
+        # the contract is ONE JSON line on stdout: the headline.  The full lines of the other configs go to stderr
+        # (prefixed CONFIG_LINE) and, condensed, into the headline's `configs` object
         head = lines[-1]
         if len(lines) > 1:
-            head["configs"] = {o["config"]["workload"].split(":")[0]: {
-                "value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "roofline_frac": o["roofline"]["frac"],
-                **({"all_gather_ms": o["config"]["all_gather_ms"]} if "all_gather_ms" in o["config"] else {}),
-                **({"cpu_value": o["cpu_baseline"]["value"]} if "cpu_baseline" in o else {})} for o in lines[:-1]}
-        for o in lines:
-            print(json.dumps(o), flush=True)
+            def brief(o):
+                r, c = o["roofline"], o["config"]
+                d = {"workload": c["workload"].split(" model.convert")[0], "value": o["value"], "unit": "x real-time", "ms_per_step": o["ms_per_step"],
+                     "steps": o["steps"], "n_gpus": o["n_gpus"],
+                     "roofline": {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+                                  "kernel": r["kernel"].split(":")[0],
+                                  "dominant_kernel_frac": (r.get("dominant_kernel") or {}).get("frac")}}
+                for k in ("all_gather_ms", "ranks_seen_by_rccl", "utterances"):
+                    if k in c:
+                        d[k] = c[k]
+                if "cpu_baseline" in o:
+                    cb = o["cpu_baseline"]
+                    d["cpu_baseline"] = {"value": cb["value"], "cores": cb["cores"], "threads1": cb["threads1"]["value"],
+                                         "threadsN": cb["threadsN"]["value"], "threadsN_cores": cb["threadsN"]["threads"], "kind": cb["kind"]}
+                return d
+            head["configs"] = {o["config"]["workload"].split(":")[0]: brief(o) for o in lines[:-1]}
+            for o in lines[:-1]:
+                print("CONFIG_LINE " + json.dumps(o), file=sys.stderr, flush=True)
+        print(json.dumps(head), flush=True)
     if use_pg:
         dist.destroy_process_group()
 

@@ -45,6 +45,9 @@ int sat_abi_version(void);
 const char* sat_last_error(void);
 /* name of device 0 and its CU count; SAT_ERR_NO_DEVICE without a GPU. `name` is a host buffer. */
 int sat_device_info(char* name, int name_len, int* cu_count);
+/* diagnostic (tools/clock_probe.py): one wave records n pairs (shader cycle counter, 100 MHz wall counter) every
+ * period_us into samples[2 n] while the caller runs other work on other streams: the clock the chip holds under it */
+int sat_clock_probe(int64_t* samples, int n, int period_us, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused 1-D convolution as an implicit GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32;

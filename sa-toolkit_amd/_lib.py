@@ -99,6 +99,7 @@ _PROTOS = {
                                                     C.c_void_p]),
     "sat_w2v2_conv0_layernorm_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "sat_conv_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "sat_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sat_attention_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_float, C.c_void_p]),
     "sat_softmax_columns_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),

@@ -34,3 +34,28 @@ extern "C" int sat_device_info(char* name, int name_len, int* cu_count) {
   if (cu_count) *cu_count = prop.multiProcessorCount;
   return SAT_OK;
 }
+
+
+// ---- diagnostic: the shader clock the chip holds while other work runs ------------------------------------------
+// One wave samples (s_memtime, s_memrealtime) every `period_us` for `n` samples; clock between two samples =
+// d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X guide, "DVFS give-back" item 6).  Launched on its own stream beside
+// the path's kernels by tools/clock_probe.py; occupies one wave slot of one CU and issues almost nothing (s_sleep).
+namespace sat {
+__global__ void __launch_bounds__(64) clock_probe_kernel(long long* out, int n, int period_ticks) {
+  if (threadIdx.x != 0) return;
+  long long next = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < n; ++i) {
+    while ((long long)__builtin_amdgcn_s_memrealtime() < next) __builtin_amdgcn_s_sleep(32);
+    out[2 * i] = (long long)__builtin_amdgcn_s_memtime();
+    out[2 * i + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    next += period_ticks;
+  }
+}
+}  // namespace sat
+
+extern "C" int sat_clock_probe(int64_t* samples, int n, int period_us, void* stream) {
+  SAT_REQUIRE(samples && n > 1 && period_us > 0, "clock_probe: bad arguments");
+  hipLaunchKernelGGL(sat::clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)samples, n, period_us * 100);
+  SAT_LAUNCH_CHECK("clock_probe_kernel");
+  return SAT_OK;
+}
