@@ -123,36 +123,71 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring_kernel(const ConvArgs 
   asm volatile("s_barrier" ::: "memory");
   read_frags(0, 0);
   int ring = 0;                              // buffer of chunk c
-  auto body = [&](int c, auto cur) {
+  // The two waves that share a SIMD (k and k + 4) run the same program behind the same barrier: left alone they do their
+  // loads / fragment reads at the same time and then queue their MFMAs behind each other, and the matrix pipe idles
+  // through every hand-over (s_memtime stamps: 1 180 cycles per chunk against 768 of MFMAs, waves 0-3 waiting a third
+  // of the loop at the barrier for waves 4-7).  Waves 4-7 therefore take their hand-over work AFTER the first half
+  // of the chunk's MFMAs: one partner multiplies while the other issues its DMA and reads (MI355X guide, "Two waves
+  // that run the SAME program with one barrier per block: try a stagger").
+  // The loop is instantiated per role (LATE) and the last chunk is peeled (MORE), so that which register set a
+  // fragment read fills is static everywhere: with runtime conditions around the reads hipcc keeps the two sets apart
+  // by copying them (32 v_mov_b64 per chunk and wave).
+  auto body = [&](int c, auto cur, auto late_c, auto more_c) {
     constexpr int CUR = decltype(cur)::value;
-    // hand-over point: chunk c + 1 landed (this wave's pieces: all but the three youngest chunks c+2..c+4), this wave's
-    // reads of chunk c are back; then everybody's are, and everybody's chunk c + 1 is visible
-    if (c + 1 < nch) {
+    constexpr bool LATE = decltype(late_c)::value, MORE = decltype(more_c)::value;
+    int nxt = ring;
+    if constexpr (MORE) {
+      // hand-over point: chunk c + 1 landed (this wave's pieces: all but the three youngest chunks c+2..c+4), this wave's
+      // reads of chunk c are back; then everybody's are, and everybody's chunk c + 1 is visible
       if (c + RING - 2 < nch) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
-      const int nxt = ring == RING - 1 ? 0 : ring + 1;
+      nxt = ring == RING - 1 ? 0 : ring + 1;
+    }
+    auto handover_work = [&]() {
       if (c + RING - 1 < nch) issue(c + RING - 1, ring == 0 ? RING - 1 : ring - 1);   // buffer of chunk c - 1: every wave has left it
       read_frags(CUR ^ 1, nxt);
-      ring = nxt;
-    }
+    };
+    if constexpr (MORE && !LATE) handover_work();
     __builtin_amdgcn_sched_barrier(0);       // the reads above stay ahead of these MFMAs (they feed the NEXT chunk)
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+      if (m == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE && LATE) handover_work();
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][m][1], fb[CUR][n][0], acc[m][n], 0, 0, 0);
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][m][0], fb[CUR][n][1], acc[m][n], 0, 0, 0);
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][m][0], fb[CUR][n][0], acc[m][n], 0, 0, 0);
       }
+    }
     __builtin_amdgcn_sched_barrier(0);
+    ring = nxt;
   };
-  int c = 0;
-  for (; c + 1 < nch; c += 2) {              // two chunks per trip: the fragment register sets alternate statically
-    body(c, std::integral_constant<int, 0>{});
-    body(c + 1, std::integral_constant<int, 1>{});
-  }
-  if (c < nch) body(c, std::integral_constant<int, 0>{});
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto loop = [&](auto late_c) {
+    using L = decltype(late_c);
+    int c = 0;
+    for (; c + 2 < nch; c += 2) {            // two chunks per trip: the fragment register sets alternate statically
+      body(c, I0{}, L{}, std::true_type{});
+      body(c + 1, I1{}, L{}, std::true_type{});
+    }
+    if (c + 1 < nch) {                       // an even number of chunks is left: the last one is peeled
+      body(c, I0{}, L{}, std::true_type{});
+      body(c + 1, I1{}, L{}, std::false_type{});
+    } else if (c < nch) {
+      body(c, I0{}, L{}, std::false_type{});
+    }
+  };
+  // The two waves that share a SIMD (k and k + 4) run the same program behind the same barrier: waves 4-7 take their
+  // hand-over work (DMA issue, fragment reads) AFTER the first half of the chunk's MFMAs, waves 0-3 before them (MI355X
+  // guide, "Two waves that run the SAME program with one barrier per block: try a stagger").
+  if (wave >= 4) loop(std::true_type{});
+  else loop(std::false_type{});
   conv_epilogue<MT, NT>(p, acc, b, 0, co_b + wm * 64, q_b + wn * 64, l31, lh);
 }
 
