@@ -188,7 +188,11 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring_kernel(const ConvArgs 
   // guide, "Two waves that run the SAME program with one barrier per block: try a stagger").
   if (wave >= 4) loop(std::true_type{});
   else loop(std::false_type{});
-  conv_epilogue<MT, NT>(p, acc, b, 0, co_b + wm * 64, q_b + wn * 64, l31, lh);
+  // the residual of the whole 64 x 64 wave tile is requested in one go (the fragment registers are dead by now): one
+  // memory round trip in the exposed epilogue of a one-block-per-CU kernel instead of one per 32 x 32 sub-tile
+  float rpre[MT][NT][16];
+  if (p.res || p.res16) epilogue_prefetch_res<MT, NT>(p, rpre, b, 0, co_b + wm * 64, q_b + wn * 64, l31, lh);
+  conv_epilogue<MT, NT, true>(p, acc, b, 0, co_b + wm * 64, q_b + wn * 64, l31, lh, 32, 0x7fffffff, rpre);
 }
 
 int launch_f16x3_ring(const ConvArgs& a, int B, hipStream_t s) {
