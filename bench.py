@@ -410,6 +410,15 @@ def dryrun(a, rank, world):
     dist.destroy_process_group()
 
 
+def flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -463,6 +472,12 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+        # RCCL writes a version banner to the C stdout of rank 0, which leaves its buffer only at exit — AFTER the JSON
+        # line unless it is flushed now: build the communicator with one small collective, then flush C stdio
+        t = torch.zeros(1, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        flush_c_stdio()
 
     want_cpu = (not a.no_cpu_baseline) and world == 1 and not use_pg
     lines = []
@@ -508,9 +523,12 @@ def main():
             head["configs"] = {o["config"]["workload"].split(":")[0]: brief(o) for o in lines[:-1]}
             for o in lines[:-1]:
                 print("CONFIG_LINE " + json.dumps(o), file=sys.stderr, flush=True)
-        print(json.dumps(head), flush=True)
     if use_pg:
+        dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()            # whatever native libraries buffered on stdout comes out BEFORE the line
+    if rank == 0:
+        print(json.dumps(lines[-1]), flush=True)       # the ONE JSON line, last on stdout
 
 
 if __name__ == "__main__":
