@@ -19,8 +19,9 @@
 namespace sat {
 
 // sat_conv_set_option("k1_gemm", v): 1x1 convs on split planes through 0 = the conv tile, 1 = conv1d_f16x3_k1_kernel,
-// 2 = gemm_f16x3_ring_kernel where its 256-column tiles fit (else 1)
-static int g_k1_gemm = 2;
+// 2 = gemm_f16x3_ring_kernel where its 256-column tiles fit (else 1), 3 = the 16x16x32-shape ring kernel where its
+// epilogue subset covers the call (else 2)
+static int g_k1_gemm = 3;
 
 template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1, int XWI>
 __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
@@ -1671,7 +1672,8 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
       // ring kernel: whole 128-row weight tiles, and 256-column tiles that pad the time axis (nearly) no more than
       // 128-column ones (249 frames: 256 either way; 49 frames: the 128-column kernel)
       const long long c256 = (long long)ceil_div(a.T_q, 256) * 256, c128 = (long long)ceil_div(a.T_q, 128) * 128;
-      if (g_k1_gemm >= 2 && a.co_pad % 128 == 0 && c256 * 8 <= c128 * 9) return launch_f16x3_ring(a, d->B, s);
+      if (g_k1_gemm >= 2 && a.co_pad % 128 == 0 && c256 * 8 <= c128 * 9)
+        return g_k1_gemm >= 3 && ring16_supports(a) ? launch_f16x3_ring16(a, d->B, s) : launch_f16x3_ring(a, d->B, s);
       return launch_f16x3_k1(a, d->B, s);
     }
     // few blocks (TDNNF linearB: 128 rows x 250 frames x 32 utterances = 64 tiles of 64 x 256 on 256 CUs): half-width
@@ -1777,7 +1779,7 @@ extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, in
 
 extern "C" int sat_conv_set_option(const char* name, int value) {
   SAT_REQUIRE(name, "conv_set_option: null name");
-  if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 2 ? 2 : value; return SAT_OK; }
+  if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }
   set_error("conv_set_option: unknown option '%s'", name);
   return SAT_ERR_INVALID;
 }

@@ -381,5 +381,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 
 // 1x1 convolution on split planes through the LDS-DMA ring GEMM (gemm_ring.hip)
 int launch_f16x3_ring(const ConvArgs& a, int B, hipStream_t s);
+int launch_f16x3_ring16(const ConvArgs& a, int B, hipStream_t s);   // the same ring on v_mfma_f32_16x16x32_f16
+bool ring16_supports(const ConvArgs& a);
 
 }  // namespace sat

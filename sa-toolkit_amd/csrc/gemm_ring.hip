@@ -195,6 +195,316 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring_kernel(const ConvArgs 
   conv_epilogue<MT, NT, true>(p, acc, b, 0, co_b + wm * 64, q_b + wn * 64, l31, lh, 32, 0x7fffffff, rpre);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same ring on the 16x16x32 MFMA shape.  A bare loop of the three split products holds a ~20 % higher clock on
+// v_mfma_f32_16x16x32_f16 than on v_mfma_f32_32x32x16_f16 at the same cycles per FLOP (tools/mfma_rate: 731 against
+// 608 useful TFLOP/s; the chip's power management gives less back to the cheaper shape — MI355X guide, DVFS give-back),
+// and the LDS images need no change: K = 32 of one instruction = the two halves of TWO consecutive chunks, lane
+// (i = lane & 15, g = lane >> 4) reads the 16-byte unit (chunk g >> 1, half g & 1, row / column i) of each operand.
+// One step = two chunks: one barrier, six DMA pieces and sixteen ds_read_b128 per wave and 48 MFMAs (768 cycles);
+// three two-chunk buffers, two steps of loads in flight across the barriers.  The wave tile stays 64 x 64 = 4 x 4
+// accumulators of 16 x 16; D: row 4 g + r, column i.  A sum over K = 32 inside one instruction associates differently
+// from two K = 16 instructions: results agree with the 32x32 kernels to f32 rounding of the accumulation (~1e-7
+// relative), not bit for bit.
+// Epilogue subset: bias, f32 residual (before / after the activation), folded BatchNorm, ReLU, GELU, f32 and split
+// plane stores; everything else (res16, accum, e4m3 planes) stays on the 32x32 kernel (launch_f16x3_ring).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  constexpr int CO_B = 128, T_B = 256, MT = 4, NT = 4, RING = 6;
+  constexpr int A_UNITS = 4 * CO_B, B_UNITS = 4 * T_B, ST_UNITS = A_UNITS + B_UNITS;
+  constexpr int A_PIECES = A_UNITS / 64, PIECES = ST_UNITS / 64, PPW = PIECES / 8;
+  static_assert(PPW == 3 && RING == 6, "the vmcnt literals below assume six pieces per wave and step, three step buffers");
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int n_co = p.co_tiles_g, n_tt = p.pp_tiles_t;
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int co_t = __builtin_amdgcn_readfirstlane(rest % n_co);
+  const int g = __builtin_amdgcn_readfirstlane((rest / n_co) * 8 + xcd);
+  if (g >= p.pp_total) return;
+  const int b = __builtin_amdgcn_readfirstlane(g / n_tt);
+  const int co_b = co_t * CO_B;
+  const int q_b = (g - b * n_tt) * T_B;
+  const int nst = p.cin_pad / (2 * CI_CHUNK);          // steps of two chunks
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.x16 + (long long)b * p.cin_g * p.T_in * 4), 0, (unsigned)(p.cin_g * p.T_in * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
+  const int seg_bytes = p.co_pad * 16;
+  const int x_chunk_bytes = 4 * p.T_in * 16;
+
+  unsigned voff[PPW];
+  int sstep[PPW], lunit[PPW];
+  bool is_a[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int u = wave * PPW + j;
+    is_a[j] = u < A_PIECES;
+    if (is_a[j]) {
+      const int seg = u >> 1, half = u & 1;
+      voff[j] = (unsigned)((co_b + half * 64 + lane) * 16 + seg * seg_bytes);
+      sstep[j] = 4 * seg_bytes;
+      lunit[j] = seg * CO_B + half * 64;
+    } else {
+      const int v = u - A_PIECES;
+      const int plane = v >> 2, cq = v & 3;
+      const int xi = q_b + cq * 64 + lane - p.pad_left;
+      voff[j] = (xi >= 0 && xi < p.T_in) ? (unsigned)((plane * p.T_in + xi) * 16) : 0x80000000u;
+      sstep[j] = x_chunk_bytes;
+      lunit[j] = A_UNITS + plane * T_B + cq * 64;
+    }
+    sstep[j] = __builtin_amdgcn_readfirstlane(sstep[j]);
+    lunit[j] = __builtin_amdgcn_readfirstlane(lunit[j]);
+  }
+  // step st -> chunk buffers 2 * sb, 2 * sb + 1 (sb = st mod 3)
+  auto issue = [&](int st, int sb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint4* dst = lds4 + (2 * sb + h) * ST_UNITS;
+#pragma unroll
+      for (int j = 0; j < PPW; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a[j] ? wrs : xrs, (__attribute__((address_space(3))) void*)(uintptr_t)(dst + lunit[j]), 16,
+                                                 voff[j], (2 * st + h) * sstep[j], 0, 0);
+    }
+#else
+    (void)st; (void)sb;
+#endif
+  };
+  // B fragments of the step being multiplied and of the next one; A fragments flow: row m's pair is dead after row
+  // m's MFMAs, so the next step's rows are read one row behind the multiplication (5 pairs live, not 8)
+  h8 fa[MT][2], fb[2][NT][2];
+  auto frag_base = [&](int sb) { return lds4 + (2 * sb + (lg >> 1)) * ST_UNITS; };
+  auto read_a = [&](h8 (&dst)[2], int sb, int m) __attribute__((always_inline)) {
+    const uint4* wb = frag_base(sb) + (lg & 1) * CO_B + wm * 64 + li + m * 16;
+    dst[0] = __builtin_bit_cast(h8, wb[0 * CO_B]);
+    dst[1] = __builtin_bit_cast(h8, wb[2 * CO_B]);
+  };
+  auto read_b = [&](int buf, int sb) __attribute__((always_inline)) {
+    const uint4* xb = frag_base(sb) + A_UNITS + (lg & 1) * T_B + wn * 64 + li;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      fb[buf][n][0] = __builtin_bit_cast(h8, xb[0 * T_B + n * 16]);
+      fb[buf][n][1] = __builtin_bit_cast(h8, xb[2 * T_B + n * 16]);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: steps 0..2 in flight, step 0 landed and visible, its fragments read
+#pragma unroll
+  for (int st = 0; st < 3; ++st)
+    if (st < nst) issue(st, st);
+  if (nst > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nst == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  int sb = 0;                                // buffer of step st
+  // Waves k and k + 4 share a SIMD: waves 4-7 take their hand-over work (DMA issue, fragment reads) after the first
+  // half of the step's MFMAs, waves 0-3 before them (see gemm_f16x3_ring_kernel).  The loop is instantiated per role
+  // and the last step peeled, so that the register set of every fragment read is static.
+  auto body = [&](int st, auto cur, auto late_c, auto more_c) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(cur)::value;
+    constexpr bool LATE = decltype(late_c)::value, MORE = decltype(more_c)::value;
+    constexpr int M_HAND = LATE ? 2 : 0;     // the hand-over work stands in front of this row's MFMAs
+    int nxt = sb;
+    if constexpr (MORE) {
+      // hand-over: step st + 1 landed (this wave's pieces: all but the youngest step), this wave's reads of step st are
+      // back; behind the barrier everybody's are, and step st's buffer is free for step st + 3
+      if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      nxt = sb == 2 ? 0 : sb + 1;
+    }
+    h8 an[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MORE) {
+        if (m == M_HAND) {
+          if (st + 3 < nst) issue(st + 3, sb);
+          read_b(CUR ^ 1, nxt);
+#pragma unroll
+          for (int k = 0; k <= M_HAND; ++k) read_a(an[k], nxt, k);
+        } else if (m > M_HAND) {
+          read_a(an[m], nxt, m);             // row m - 1 has been multiplied: a pair of registers is free
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m][1], fb[CUR][n][0], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m][0], fb[CUR][n][1], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m][0], fb[CUR][n][0], acc[m][n], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MORE) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fa[m][0] = an[m][0], fa[m][1] = an[m][1];
+    }
+    sb = nxt;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto loop = [&](auto late_c) __attribute__((always_inline)) {
+    using L = decltype(late_c);
+    read_b(0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) read_a(fa[m], 0, m);
+    int st = 0;
+    for (; st + 2 < nst; st += 2) {
+      body(st, I0{}, L{}, std::true_type{});
+      body(st + 1, I1{}, L{}, std::true_type{});
+    }
+    if (st + 1 < nst) {
+      body(st, I0{}, L{}, std::true_type{});
+      body(st + 1, I1{}, L{}, std::false_type{});
+    } else if (st < nst) {
+      body(st, I0{}, L{}, std::false_type{});
+    }
+  };
+  if (wave >= 4) loop(std::true_type{});
+  else loop(std::false_type{});
+
+  // ---- epilogue: lane (li, lg) holds rows co_w + 16 m + 4 lg + r (r < 4) at column q_w + 16 n + li ----
+  const unsigned OOB = 0x80000000u;
+  const int co_w = co_b + wm * 64, q_w = q_b + wn * 64;
+  const unsigned chn = (unsigned)(p.rows_g * 4);
+  const __amdgpu_buffer_rsrc_t yrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)b * p.y_bs), 0, (unsigned)(p.rows_g * p.y_cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res ? p.res + (long long)b * p.r_bs : p.y), 0, p.res ? (unsigned)(p.rows_g * p.r_cs * 4) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : p.y), 0, p.bias ? chn : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t scs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ch_scale ? p.ch_scale : p.y), 0, p.ch_scale ? chn : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t shs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ch_shift ? p.ch_shift : p.y), 0, p.ch_shift ? chn : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y16 ? (char*)p.y16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
+      p.y16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
+  const int y_rb = (int)p.y_cs * 4, r_rb = (int)p.r_cs * 4;
+  // the residual of the whole wave tile is requested in one go (the fragment registers are dead by now): one memory
+  // round trip in the exposed epilogue of a one-block-per-CU kernel
+  f32x4 rv[MT][NT];
+  if (p.res) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row0 = co_w + m * 16 + 4 * lg;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int q = q_w + n * 16 + li;
+        const unsigned roff = q < p.T_q ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : OOB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          rv[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, roff + r * r_rb, 0, 0));
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row0 = co_w + m * 16 + 4 * lg;
+    float bi[4], sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (row0 + r) * 4, 0, 0));
+    if (p.ch_scale) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scs, (row0 + r) * 4, 0, 0));
+        sh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shs, (row0 + r) * 4, 0, 0));
+      }
+    }
+    const bool rows_ok = co_w + m * 16 < p.rows_g;       // wave-uniform: padding rows of a 128-row tile
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int q = q_w + n * 16 + li;
+      const bool qok = q < p.T_q;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[m][n][r] + bi[r];
+      if (p.res && !p.res_after) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p.res_scale * rv[m][n][r];
+      }
+      if (p.relu && p.relu_first) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      }
+      if (p.ch_scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+      }
+      if (p.relu && !p.relu_first) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      }
+      if (p.gelu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+      }
+      if (p.res && p.res_after) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p.res_scale * rv[m][n][r];
+      }
+      if (!p.no_y) {
+        const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs, yoff + r * y_rb, 0, 0);
+      }
+      if (p.y16 && rows_ok) {
+        // rows 16 m + 4 lg + r = chunk m of this wave tile, half lg >> 1, bytes 8 (lg & 1) .. of the 16-byte unit
+        const int chunk = (co_w >> 4) + m;
+        float u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = v[r] > 0.f ? v[r] : v[r] * p.y16_slope;
+        const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+        const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+        const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+        const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+        const unsigned off = qok ? (unsigned)(((chunk * 4 + (lg >> 1)) * p.T_q + q) * 16 + 8 * (lg & 1)) : OOB;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 hv, lv;
+        hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
+        lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
+        __builtin_amdgcn_raw_buffer_store_b64(hv, y16rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(lv, y16rs, off, 2 * p.T_q * 16, 0);
+      }
+    }
+  }
+}
+
+// options the 16x16 kernel's epilogue carries (the rest stays on the 32x32 kernel)
+bool ring16_supports(const ConvArgs& a) {
+  return a.fast_epi && !a.res16 && !a.accum && a.accum_div == 0.f && !a.y16_f8 && a.up == 1 && a.rows_g % 4 == 0 &&
+         (a.cin_pad / CI_CHUNK) % 2 == 0;
+}
+
+int launch_f16x3_ring16(const ConvArgs& a, int B, hipStream_t s) {
+  ConvArgs p = a;
+  p.xw = 256;
+  p.co_tiles_g = ceil_div(p.rows_g, 128);
+  p.pp_tiles_t = ceil_div(p.T_q, 256);
+  p.pp_total = p.pp_tiles_t * B;
+  const size_t lds_bytes = (size_t)6 * (4 * 128 + 4 * 256) * 16;
+  auto kern = gemm_f16x3_ring16_kernel;
+  static std::atomic<uint64_t> attr_done{0};      // per device
+  int dev;
+  if (attr_needed_on_current_device(attr_done, &dev)) {
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done_on_device(attr_done, dev);
+  }
+  dim3 grid(8 * p.co_tiles_g * ceil_div(p.pp_total, 8), 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, s, p);
+  SAT_LAUNCH_CHECK("gemm_f16x3_ring16_kernel");
+  return SAT_OK;
+}
+
 int launch_f16x3_ring(const ConvArgs& a, int B, hipStream_t s) {
   ConvArgs p = a;
   p.xw = 256;

@@ -716,3 +716,53 @@ def test_half_width_tiles_of_the_3_tap_planes_conv(T, dil):
     y2 = ops.conv1d(xd, packing.pack_conv_weight_f16x3(w.to(DEV)), C, 3, bias=b.to(DEV), dilation=dil, pad_left=dil, mode=1,
                     x_split=xs, res=rd, out=out2, accum=True, accum_div=3.0)
     assert (y2 - y).abs().max().item() <= 2.0 ** -19 * float(r.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,T", [(128, 1024, 249), (1024, 1024, 250), (512, 3280, 130), (1024, 256, 500), (64, 1024, 513)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("variant", ["plain", "res", "gelu_planes", "bn_relu_postres"])
+def test_1x1_gemm_kernels_on_split_planes(cin, cout, T, variant):
+    """the three kernels behind a 1x1 conv on split planes (sat_conv_set_option "k1_gemm": 1 = 128 x 128 register-staged,
+    2 = LDS-DMA ring on the 32x32x16 MFMA shape, 3 = the ring on the 16x16x32 shape, the default): 1 and 2 accumulate in
+    the same order and agree bit for bit; 3 sums K = 32 inside one instruction and agrees with them to f32 rounding of
+    the accumulation; all three against torch in float64 at the split-f16 tolerance.  Ragged time tiles (T not a
+    multiple of 256), rows not a multiple of 128, every epilogue the 16x16 kernel carries."""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    B = 3
+    x, w, b = _rand(B, cin, T, seed=1), _rand(cout, cin, 1, seed=2, scale=cin ** -0.5), _rand(cout, seed=3)
+    r, sc, sh = _rand(B, cout, T, seed=4), torch.rand(cout, generator=torch.Generator().manual_seed(5)) + 0.5, _rand(cout, seed=6)
+    xd, rd = x.to(DEV), r.to(DEV)
+    xs = ops.act_split(xd, 1.0)
+    wp = packing.pack_conv_weight_f16x3(w.to(DEV))
+    lin = torch.einsum("oc,bct->bot", w[:, :, 0].double(), x.double()) + b.double()[None, :, None]
+    if variant == "plain":
+        ref, kw = lin, {}
+    elif variant == "res":
+        ref, kw = lin + r.double(), dict(res=rd)
+    elif variant == "gelu_planes":
+        ref, kw = F.gelu(lin), dict(gelu=True)
+    else:
+        ref, kw = r.double() + F.relu(lin * sc.double()[None, :, None] + sh.double()[None, :, None]), dict(
+            post_res=rd, ch_scale=sc.to(DEV), ch_shift=sh.to(DEV), relu=True)
+    out = {}
+    try:
+        for opt in (1, 2, 3):
+            _lib.check(_lib.lib().sat_conv_set_option(b"k1_gemm", opt), "sat_conv_set_option")
+            ys = ops.split_like(B, cout, T, xd.device) if variant == "gelu_planes" else None
+            y = ops.conv1d(xd, wp, cout, 1, bias=b.to(DEV), mode=1, x_split=xs, y_split=ys, **kw)
+            out[opt] = (y, ys)
+    finally:
+        _lib.check(_lib.lib().sat_conv_set_option(b"k1_gemm", 3), "sat_conv_set_option")
+    scale = float(ref.abs().max())
+    for opt, (y, ys) in out.items():
+        assert (y.cpu().double() - ref).abs().max().item() < 1e-5 * scale, (opt, variant)
+    assert torch.equal(out[1][0], out[2][0])
+    assert (out[3][0] - out[1][0]).abs().max().item() < 2e-6 * scale
+    if variant == "gelu_planes":
+        # the planes written next to y are split(y): hi + lo reproduces y to 2^-21 (read back through a 1x1 identity product)
+        assert torch.equal(out[1][1], out[2][1])
+        eye = torch.eye(cout)[:128].reshape(128, cout, 1).contiguous().to(DEV)
+        y3, ys3 = out[3]
+        back = ops.conv1d(y3, packing.pack_conv_weight_f16x3(eye), 128, 1, mode=1, x_split=ys3)
+        assert (back - y3[:, :128]).abs().max().item() <= 2.0 ** -20 * float(y3.abs().max())

@@ -1,5 +1,5 @@
 """time the wav2vec2-tag bottleneck extractor alone (batch 32 x 5 s); with `ab`: the 1x1 GEMM kernels interleaved in
-one process (k1_gemm = 1: 128 x 128 register-staged kernel, 2: LDS-DMA ring kernel), five rounds of five forwards each"""
+one process (k1_gemm = 1: 128 x 128 register-staged kernel, 2: LDS-DMA ring kernel, 3: the ring on the 16x16x32 MFMA shape), five rounds of five forwards each"""
 import os
 import sys
 import torch
@@ -24,12 +24,13 @@ def run(n):
 
 run(2)
 if len(sys.argv) > 1 and sys.argv[1] == "ab":
-    res = {1: [], 2: []}
+    res = {1: [], 2: [], 3: []}
     for rnd in range(5):
-        for opt in (1, 2):
+        for opt in (1, 2, 3):
             _lib.check(_lib.lib().sat_conv_set_option(b"k1_gemm", opt), "set_option")
             res[opt].append(run(5))
-    for opt in (1, 2):
+    for opt in (1, 2, 3):
         print(f"k1_gemm={opt}: get_bn ms per batch, five rounds: " + " ".join(f"{v:.2f}" for v in res[opt]) + f"   median {sorted(res[opt])[2]:.2f}")
+    _lib.check(_lib.lib().sat_conv_set_option(b"k1_gemm", 3), "set_option")
 else:
     print("wav2vec2-tag get_bn %.2f ms" % run(5))
