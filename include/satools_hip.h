@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 1
+#define SAT_ABI_VERSION 2
 
 typedef enum {
   SAT_OK = 0,
@@ -131,6 +131,11 @@ typedef struct {
   int32_t y_split_format;  /* 0 = the format this mode reads (F16X3: SAT_SPLIT_F16, F16F8: SAT_SPLIT_F8),
                               1 = SAT_SPLIT_F16, 2 = SAT_SPLIT_F8 */
   int32_t relu_first;      /* apply the ReLU BEFORE ch_scale / ch_shift (conv -> relu -> BatchNorm, ECAPA-TDNN) */
+  int32_t x_wrap_channels; /* 0, or (1x1 conv on split planes, SAT_CONV_F16X3): x_split holds only this many channels and
+                              input channel c >= x_wrap_channels reads channel c - x_wrap_channels one position LATER:
+                              y[t] = W[:, :Cw] x[:, t] + W[:, Cw:] x[:C_in - Cw, t + 1].  A stride-2 3-tap conv over
+                              [even | odd] phase-split input is this with Cw = 2 C, C_in = 3 C (no zero taps, one GEMM).
+                              Multiples of 32; rows %% 128 == 0; positions t + 1 >= T_in read as zero */
 } sat_conv1d_desc;
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,

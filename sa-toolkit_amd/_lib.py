@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("x_split", C.c_void_p), ("y_split", C.c_void_p), ("y_split_slope", C.c_float), ("no_y", C.c_int32),
         ("res_split", C.c_void_p), ("res_split_slope", C.c_float), ("y_split_format", C.c_int32),
         ("relu_first", C.c_int32),
+        ("x_wrap_channels", C.c_int32),
     ]
 
 
@@ -130,7 +131,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.sat_abi_version() != 1:
+        if l.sat_abi_version() != 2:
             raise SatError("libsatools_hip.so ABI version mismatch")
         _lib = l
     return _lib

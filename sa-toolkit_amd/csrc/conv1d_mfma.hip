@@ -1644,6 +1644,14 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     if (a.x16)
       SAT_REQUIRE(d->groups == 1 && a.cin_g % 16 == 0 && (long long)a.cin_g * a.T_in * 4 < (1LL << 31),
                   "conv1d(f16x3): x_split needs groups 1, C_in %% 16 == 0 and a slab below 2 GiB");
+    if (d->x_wrap_channels) {
+      SAT_REQUIRE(a.x16 && !a.f8 && d->ksize == 1 && d->groups == 1 && d->x_wrap_channels > 0 && d->x_wrap_channels % 32 == 0 &&
+                      d->x_wrap_channels < d->C_in && d->C_in <= 2 * d->x_wrap_channels && d->C_in % 32 == 0 && a.rows_g % 128 == 0,
+                  "conv1d: x_wrap_channels needs a 1x1 split-f16 conv on split planes, channel counts multiples of 32 with "
+                  "x_wrap < C_in <= 2 x_wrap, C_out %% 128 == 0");
+      a.k1_wrap = d->x_wrap_channels / CI_CHUNK;
+      a.cin_g = d->x_wrap_channels;            // channels behind x_split (the descriptor range of the planes)
+    }
     if (d->res_split) {
       SAT_REQUIRE(!d->res && a.fast_epi && d->groups == 1 && a.rows_g % 16 == 0 && d->res_split_slope > 0.f &&
                   (long long)a.rows_g * a.T_q * 4 < (1LL << 31), "conv1d(f16x3): res_split needs up 1, groups 1, C_out %% 16 == 0, no f32 res");
@@ -1672,10 +1680,15 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
       // ring kernel: whole 128-row weight tiles, and 256-column tiles that pad the time axis (nearly) no more than
       // 128-column ones (249 frames: 256 either way; 49 frames: the 128-column kernel)
       const long long c256 = (long long)ceil_div(a.T_q, 256) * 256, c128 = (long long)ceil_div(a.T_q, 128) * 128;
+      if (a.k1_wrap) {                         // only the 16x16x32 ring kernel reads wrapped K chunks
+        SAT_REQUIRE(ring16_supports(a), "conv1d: x_wrap_channels needs the epilogue of the ring GEMM (up 1, split-f16 planes)");
+        return launch_f16x3_ring16(a, d->B, s);
+      }
       if (g_k1_gemm >= 2 && a.co_pad % 128 == 0 && c256 * 8 <= c128 * 9)
         return g_k1_gemm >= 3 && ring16_supports(a) ? launch_f16x3_ring16(a, d->B, s) : launch_f16x3_ring(a, d->B, s);
       return launch_f16x3_k1(a, d->B, s);
     }
+    SAT_REQUIRE(!a.k1_wrap, "conv1d: x_wrap_channels is only served by the 1x1 GEMM path (C_in %% 64 == 0, up 1, 31-bit slabs)");
     // few blocks (TDNNF linearB: 128 rows x 250 frames x 32 utterances = 64 tiles of 64 x 256 on 256 CUs): half-width
     // tiles double the blocks of these latency-bound launches
     if (a.x16 && a.ksize == 3 && !a.f8 && !a.poly_planes && a.rows_g > 32 && a.T_q > 128 &&

@@ -58,6 +58,7 @@ struct ConvArgs {
   int f8;                // planes kernels: cross terms hi*lo + lo*hi on the block-scaled e4m3 MFMA
   int poly_planes;       // up > 1, planes only: the LDS-transposed polyphase epilogue
   int y16_f8;            // output planes carry (hi f16 | e4m3(hi) | e4m3(lo * 2^10)) instead of (hi f16 | lo f16)
+  int k1_wrap;           // ring16 GEMM: K chunks >= k1_wrap read plane chunk (c - k1_wrap) one position later; 0 = none
   int pp_tiles_t, pp_total, pp_per_xcd, pp_nslots;   // persistent pair kernel: tiles per utterance / in all / per XCD, blocks per XCD
 #ifdef SAT_STAMPS
   long long* dbg;        // diagnostic build (tools/stamp_conv.hip): per-block, per-chunk phase time stamps
@@ -379,9 +380,168 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 }
 
 
+// ---- the same epilogue for kernels on the 16x16x32 MFMA shape (gemm_ring.hip), fast path only
+// (up == 1, 31-bit slab offsets, split-f16 planes).  D layout of a 16 x 16 tile: lane (li = lane & 15, lg = lane >> 4)
+// holds rows 4 lg + r (r < 4) at column li, i.e. of the wave tile rows co_w + 16 m + 4 lg + r at q_w + 16 n + li: four
+// consecutive channels = 8 bytes of the plane unit (chunk co / 16, half lg >> 1) at byte 8 (lg & 1).
+// The order of operations is conv_epilogue's.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue16_prefetch_res(const ConvArgs& p, f32x4 (&rpre)[MT][NT], int b, int co_w, int q_w,
+                                                        int li, int lg) {
+  const unsigned OOB = 0x80000000u;
+  if (p.res16) {
+    const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.res16 + (long long)b * p.rows_g * p.T_q * 4), 0, (unsigned)(p.rows_g * p.T_q * 4), 0x00020000);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int chunk = (co_w >> 4) + m;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int q = q_w + n * 16 + li;
+        const unsigned off = (q < p.T_q && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (lg >> 1)) * p.T_q + q) * 16 + 8 * (lg & 1)) : OOB;
+        // narrowed to 8 bytes each (the b64 load builtin of this hipcc loads one dword)
+        const uint4 hv = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 0, 0));
+        const uint4 lv = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * p.T_q * 16, 0));
+        rpre[m][n] = f32x4{__builtin_bit_cast(float, hv.x), __builtin_bit_cast(float, hv.y),
+                           __builtin_bit_cast(float, lv.x), __builtin_bit_cast(float, lv.y)};
+      }
+    }
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res ? p.res + (long long)b * p.r_bs : p.y), 0, p.res ? (unsigned)(p.rows_g * p.r_cs * 4) : 0u, 0x00020000);
+  const int r_rb = (int)p.r_cs * 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row0 = co_w + m * 16 + 4 * lg;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int q = q_w + n * 16 + li;
+      const unsigned roff = q < p.T_q ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : OOB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        rpre[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, roff + r * r_rb, 0, 0));
+    }
+  }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[MT][NT], f32x4 (&rpre)[MT][NT], int b, int co_w,
+                                                int q_w, int li, int lg) {
+  const unsigned OOB = 0x80000000u;
+  const unsigned chn = (unsigned)(p.rows_g * 4);
+  const __amdgpu_buffer_rsrc_t yrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)b * p.y_bs), 0, (unsigned)(p.rows_g * p.y_cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : p.y), 0, p.bias ? chn : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t scs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ch_scale ? p.ch_scale : p.y), 0, p.ch_scale ? chn : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t shs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ch_shift ? p.ch_shift : p.y), 0, p.ch_shift ? chn : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y16 ? (char*)p.y16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
+      p.y16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
+  const int y_rb = (int)p.y_cs * 4;
+  const bool has_res = p.res != nullptr || p.res16 != nullptr;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row0 = co_w + m * 16 + 4 * lg;
+    float bi[4], sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (row0 + r) * 4, 0, 0));
+    if (p.ch_scale) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scs, (row0 + r) * 4, 0, 0));
+        sh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shs, (row0 + r) * 4, 0, 0));
+      }
+    }
+    const bool rows_ok = co_w + m * 16 < p.rows_g;       // wave-uniform: padding rows of the block's tile
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int q = q_w + n * 16 + li;
+      const bool qok = q < p.T_q;
+      const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
+      float rv[4], yv[4], v[4];
+      if (p.res16) {
+        decode_res16(rpre[m][n][0], rpre[m][n][1], rpre[m][n][2], rpre[m][n][3], p.res16_inv, rv);
+      } else if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rpre[m][n][r];
+      }
+      if (p.accum) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yoff + r * y_rb, 0, 0));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[m][n][r] + bi[r];
+      if (has_res && !p.res_after) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p.res_scale * rv[r];
+      }
+      if (p.relu && p.relu_first) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      }
+      if (p.ch_scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+      }
+      if (p.relu && !p.relu_first) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      }
+      if (p.gelu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+      }
+      if (has_res && p.res_after) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p.res_scale * rv[r];
+      }
+      if (p.accum) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = yv[r] + v[r];
+      }
+      if (p.accum_div != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] / p.accum_div;
+      }
+      if (!p.no_y) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs, yoff + r * y_rb, 0, 0);
+      }
+      if (p.y16 && rows_ok) {
+        const int chunk = (co_w >> 4) + m;
+        float u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = v[r] > 0.f ? v[r] : v[r] * p.y16_slope;
+        const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+        const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+        const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+        const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+        const unsigned off = qok ? (unsigned)(((chunk * 4 + (lg >> 1)) * p.T_q + q) * 16 + 8 * (lg & 1)) : OOB;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 hv, lv;
+        hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
+        lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
+        __builtin_amdgcn_raw_buffer_store_b64(hv, y16rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(lv, y16rs, off, 2 * p.T_q * 16, 0);
+      }
+    }
+  }
+}
+
+// what conv_epilogue16 carries
+inline bool epilogue16_supports(const ConvArgs& a) {
+  return a.fast_epi && !a.y16_f8 && a.up == 1 && !a.poly_planes && a.rows_g % 4 == 0;
+}
+
 // 1x1 convolution on split planes through the LDS-DMA ring GEMM (gemm_ring.hip)
 int launch_f16x3_ring(const ConvArgs& a, int B, hipStream_t s);
 int launch_f16x3_ring16(const ConvArgs& a, int B, hipStream_t s);   // the same ring on v_mfma_f32_16x16x32_f16
 bool ring16_supports(const ConvArgs& a);
+
 
 }  // namespace sat

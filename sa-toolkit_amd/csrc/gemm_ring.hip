@@ -206,11 +206,8 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring_kernel(const ConvArgs 
 // accumulators of 16 x 16; D: row 4 g + r, column i.  A sum over K = 32 inside one instruction associates differently
 // from two K = 16 instructions: results agree with the 32x32 kernels to f32 rounding of the accumulation (~1e-7
 // relative), not bit for bit.
-// Epilogue subset: bias, f32 residual (before / after the activation), folded BatchNorm, ReLU, GELU, f32 and split
-// plane stores; everything else (res16, accum, e4m3 planes) stays on the 32x32 kernel (launch_f16x3_ring).
+// Epilogue: conv_epilogue16 (everything but e4m3 planes, which stay on the 32x32 kernel, launch_f16x3_ring).
 // ------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   constexpr int CO_B = 128, T_B = 256, MT = 4, NT = 4, RING = 6;
@@ -236,7 +233,10 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
   const int seg_bytes = p.co_pad * 16;
   const int x_chunk_bytes = 4 * p.T_in * 16;
 
-  unsigned voff[PPW];
+  // K chunks past p.k1_wrap read the planes again from chunk 0 on, one position later (x_wrap_channels of the desc:
+  // the third tap of a stride-2 3-tap conv over phase-split input); voff1 = a B piece's offsets at that shift
+  const int nwrap = p.k1_wrap > 0 ? p.k1_wrap : 0x7fffffff;
+  unsigned voff[PPW], voff1[PPW];
   int sstep[PPW], lunit[PPW];
   bool is_a[PPW];
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
     is_a[j] = u < A_PIECES;
     if (is_a[j]) {
       const int seg = u >> 1, half = u & 1;
-      voff[j] = (unsigned)((co_b + half * 64 + lane) * 16 + seg * seg_bytes);
+      voff[j] = voff1[j] = (unsigned)((co_b + half * 64 + lane) * 16 + seg * seg_bytes);
       sstep[j] = 4 * seg_bytes;
       lunit[j] = seg * CO_B + half * 64;
     } else {
@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
       const int plane = v >> 2, cq = v & 3;
       const int xi = q_b + cq * 64 + lane - p.pad_left;
       voff[j] = (xi >= 0 && xi < p.T_in) ? (unsigned)((plane * p.T_in + xi) * 16) : 0x80000000u;
+      voff1[j] = (xi + 1 >= 0 && xi + 1 < p.T_in) ? (unsigned)((plane * p.T_in + xi + 1) * 16) : 0x80000000u;
       sstep[j] = x_chunk_bytes;
       lunit[j] = A_UNITS + plane * T_B + cq * 64;
     }
@@ -265,10 +266,13 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       uint4* dst = lds4 + (2 * sb + h) * ST_UNITS;
+      const int ch = 2 * st + h;
+      const bool wrapped = ch >= nwrap;                  // wave-uniform (and the same for both chunks of a step: nwrap is even)
+      const int ch_b = wrapped ? ch - nwrap : ch;
 #pragma unroll
       for (int j = 0; j < PPW; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a[j] ? wrs : xrs, (__attribute__((address_space(3))) void*)(uintptr_t)(dst + lunit[j]), 16,
-                                                 voff[j], (2 * st + h) * sstep[j], 0, 0);
+                                                 wrapped ? voff1[j] : voff[j], (is_a[j] ? ch : ch_b) * sstep[j], 0, 0);
     }
 #else
     (void)st; (void)sb;
@@ -374,116 +378,15 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
   if (wave >= 4) loop(std::true_type{});
   else loop(std::false_type{});
 
-  // ---- epilogue: lane (li, lg) holds rows co_w + 16 m + 4 lg + r (r < 4) at column q_w + 16 n + li ----
-  const unsigned OOB = 0x80000000u;
-  const int co_w = co_b + wm * 64, q_w = q_b + wn * 64;
-  const unsigned chn = (unsigned)(p.rows_g * 4);
-  const __amdgpu_buffer_rsrc_t yrs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)b * p.y_bs), 0, (unsigned)(p.rows_g * p.y_cs * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res ? p.res + (long long)b * p.r_bs : p.y), 0, p.res ? (unsigned)(p.rows_g * p.r_cs * 4) : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : p.y), 0, p.bias ? chn : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t scs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ch_scale ? p.ch_scale : p.y), 0, p.ch_scale ? chn : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t shs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ch_shift ? p.ch_shift : p.y), 0, p.ch_shift ? chn : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.y16 ? (char*)p.y16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
-      p.y16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
-  const int y_rb = (int)p.y_cs * 4, r_rb = (int)p.r_cs * 4;
   // the residual of the whole wave tile is requested in one go (the fragment registers are dead by now): one memory
   // round trip in the exposed epilogue of a one-block-per-CU kernel
-  f32x4 rv[MT][NT];
-  if (p.res) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int row0 = co_w + m * 16 + 4 * lg;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int q = q_w + n * 16 + li;
-        const unsigned roff = q < p.T_q ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : OOB;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          rv[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, roff + r * r_rb, 0, 0));
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int row0 = co_w + m * 16 + 4 * lg;
-    float bi[4], sc[4], sh[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (row0 + r) * 4, 0, 0));
-    if (p.ch_scale) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scs, (row0 + r) * 4, 0, 0));
-        sh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shs, (row0 + r) * 4, 0, 0));
-      }
-    }
-    const bool rows_ok = co_w + m * 16 < p.rows_g;       // wave-uniform: padding rows of a 128-row tile
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int q = q_w + n * 16 + li;
-      const bool qok = q < p.T_q;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[m][n][r] + bi[r];
-      if (p.res && !p.res_after) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p.res_scale * rv[m][n][r];
-      }
-      if (p.relu && p.relu_first) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-      }
-      if (p.ch_scale) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
-      }
-      if (p.relu && !p.relu_first) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-      }
-      if (p.gelu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-      }
-      if (p.res && p.res_after) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p.res_scale * rv[m][n][r];
-      }
-      if (!p.no_y) {
-        const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs, yoff + r * y_rb, 0, 0);
-      }
-      if (p.y16 && rows_ok) {
-        // rows 16 m + 4 lg + r = chunk m of this wave tile, half lg >> 1, bytes 8 (lg & 1) .. of the 16-byte unit
-        const int chunk = (co_w >> 4) + m;
-        float u[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = v[r] > 0.f ? v[r] : v[r] * p.y16_slope;
-        const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
-        const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-        const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-        const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
-        const unsigned off = qok ? (unsigned)(((chunk * 4 + (lg >> 1)) * p.T_q + q) * 16 + 8 * (lg & 1)) : OOB;
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 hv, lv;
-        hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
-        lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
-        __builtin_amdgcn_raw_buffer_store_b64(hv, y16rs, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(lv, y16rs, off, 2 * p.T_q * 16, 0);
-      }
-    }
-  }
+  f32x4 rpre[MT][NT];
+  if (p.res || p.res16) epilogue16_prefetch_res<MT, NT>(p, rpre, b, co_b + wm * 64, q_b + wn * 64, li, lg);
+  conv_epilogue16<MT, NT>(p, acc, rpre, b, co_b + wm * 64, q_b + wn * 64, li, lg);
 }
 
 // options the 16x16 kernel's epilogue carries (the rest stays on the 32x32 kernel)
-bool ring16_supports(const ConvArgs& a) {
-  return a.fast_epi && !a.res16 && !a.accum && a.accum_div == 0.f && !a.y16_f8 && a.up == 1 && a.rows_g % 4 == 0 &&
-         (a.cin_pad / CI_CHUNK) % 2 == 0;
-}
+bool ring16_supports(const ConvArgs& a) { return epilogue16_supports(a) && (a.cin_pad / CI_CHUNK) % 2 == 0 && a.k1_wrap % 2 == 0; }
 
 int launch_f16x3_ring16(const ConvArgs& a, int B, hipStream_t s) {
   ConvArgs p = a;

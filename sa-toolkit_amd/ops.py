@@ -26,15 +26,19 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
            up=1, in_lrelu=None, res=None, res_scale=1.0, res_toff=0, res_tstride=1, ch_scale=None, ch_shift=None,
            relu=False, gelu=False, post_res=None, out=None, accum=False, accum_div=0.0, mode=0, t_out=None,
            x_split=None, y_split=None, y_split_slope=1.0, no_y=False, y_split_format=0, res_split=None,
-           res_split_slope=1.0, relu_first=False):
+           res_split_slope=1.0, relu_first=False, x_wrap_channels=0, c_in=None):
     """Fused conv (see include/satools_hip.h sat_conv1d_f32).  `pad_right` defaults to the
     'same'-style value implied by pad_left for stride 1; T_q is derived like torch does:
     T_q = (T_in + pad_left + pad_right - dilation*(ksize-1) - 1)//stride + 1 (`t_out` caps it).
     `post_res` is a residual added AFTER the activation (y = post_res + act(conv(x))).
     Split planes (mode=CONV_F16X3): `x_split` = act_split(pre(x)) replaces the staging of x (x then only
     gives the shape); `y_split` (a split_like buffer) also receives split(lrelu(y, y_split_slope));
-    `no_y` skips the f32 store; `res_split` takes the residual from SPLIT_F16 planes of lrelu(r, res_split_slope)."""
+    `no_y` skips the f32 store; `res_split` takes the residual from SPLIT_F16 planes of lrelu(r, res_split_slope).
+    `x_wrap_channels` = Cw (1x1 conv on split planes): the planes hold Cw channels and the weight's input channels
+    c >= Cw read channel c - Cw one position later (sat_conv1d_desc.x_wrap_channels); `x` gives [B, Cw, T] and
+    `c_in` the weight's input channels."""
     x = _strided3(x)
+    c_in_w = c_in
     B, c_in, t_in = x.shape
     if pad_right is None:
         pad_right = dilation * (ksize - 1) - pad_left if up == 1 and stride == 1 else 0
@@ -52,7 +56,7 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
         assert res is None
         res = post_res
     d = ConvDesc()
-    d.B, d.C_in, d.T_in, d.C_out, d.T_q = B, c_in, t_in, c_out, t_q
+    d.B, d.C_in, d.T_in, d.C_out, d.T_q = B, (c_in if c_in_w is None else int(c_in_w)), t_in, c_out, t_q
     d.ksize, d.dilation, d.stride, d.pad_left, d.groups, d.up = ksize, dilation, stride, pad_left, groups, up
     d.mode = int(mode)
     d.in_lrelu = 0 if in_lrelu is None else 1
@@ -74,6 +78,7 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
     d.y_split_slope, d.no_y, d.y_split_format = float(y_split_slope), int(no_y), int(y_split_format)
     d.res_split, d.res_split_slope = ptr(res_split), float(res_split_slope)
     d.relu_first = int(relu_first)
+    d.x_wrap_channels = int(x_wrap_channels)
     check(lib().sat_conv1d_f32(C.byref(d), ptr(x, strided=True), ptr(w_packed), ptr(out, strided=True), stream()),
           "sat_conv1d_f32")
     return out

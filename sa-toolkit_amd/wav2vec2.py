@@ -159,6 +159,8 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
     #: product; with it also the fused attention kernel and the positional conv as chained 11-tap pieces) or "f32"
     #: (exact f32 MFMA everywhere, attention as scores GEMM + softmax + apply GEMM).
     w2v2_precision = os.environ.get("SATOOLS_AMD_W2V2_PRECISION", "f16x3")
+    #: the feature extractor's stride-2 3-tap convs as one wrapped 1x1 product on the ring GEMM (0: two-tap polyphase conv)
+    fe_wrapped_gemm = int(os.environ.get("SATOOLS_AMD_W2V2_FE_WRAPPED_GEMM", "1"))
 
     def _prepare_w2v2(self, device):
         key = (self.w2v2_precision,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.preprocessor.parameters())
@@ -181,6 +183,10 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             else:
                 wc, kp = _polyphase_stride2_weight(w)
                 ent["w"], ent["k"] = pack_mm(wc), kp
+                if split and w.shape[2] == 3 and self.fe_wrapped_gemm:
+                    # 3 taps, stride 2 on [even | odd] planes as ONE product over 3 C input channels, the last C of them
+                    # (tap 2) reading the even phase one frame later (sat_conv1d_desc.x_wrap_channels): no zero tap
+                    ent["w_wrap"] = pack_mm(torch.cat([w[:, :, 0], w[:, :, 1], w[:, :, 2]], 1).unsqueeze(-1).contiguous())
             W["fe"].append(ent)
         fp = pre.encoder.feature_projection
         W["fp"] = {"g": f32(fp.layer_norm.weight), "beta": f32(fp.layer_norm.bias),
@@ -240,8 +246,12 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
                 x, xs = ops.layernorm_ch(x, e["g"], e["beta"], gelu=True, split_phases=not last), None
             if not last:
                 nxt = W["fe"][i + 1]
-                x = ops.conv1d(x, nxt["w"], 512, nxt["k"], bias=nxt["b"], pad_left=0, pad_right=0, t_out=self._fe_len[i + 1], mode=mm,
-                               x_split=xs)
+                if xs is not None and "w_wrap" in nxt:
+                    x = ops.conv1d(x, nxt["w_wrap"], 512, 1, bias=nxt["b"], t_out=self._fe_len[i + 1], mode=mm, x_split=xs,
+                                   x_wrap_channels=x.shape[1], c_in=3 * x.shape[1] // 2)
+                else:
+                    x = ops.conv1d(x, nxt["w"], 512, nxt["k"], bias=nxt["b"], pad_left=0, pad_right=0, t_out=self._fe_len[i + 1], mode=mm,
+                                   x_split=xs)
         T = x.shape[2]
         # feature projection
         if planes:

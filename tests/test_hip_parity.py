@@ -718,7 +718,7 @@ def test_half_width_tiles_of_the_3_tap_planes_conv(T, dil):
     assert (y2 - y).abs().max().item() <= 2.0 ** -19 * float(r.abs().max())
 
 
-@pytest.mark.parametrize("cin,cout,T", [(128, 1024, 249), (1024, 1024, 250), (512, 3280, 130), (1024, 256, 500), (64, 1024, 513)],
+@pytest.mark.parametrize("cin,cout,T", [(128, 1024, 249), (1024, 1024, 250), (512, 3280, 130), (1024, 256, 500), (64, 1024, 700)],
                          ids=lambda v: str(v))
 @pytest.mark.parametrize("variant", ["plain", "res", "gelu_planes", "bn_relu_postres"])
 def test_1x1_gemm_kernels_on_split_planes(cin, cout, T, variant):
@@ -766,3 +766,36 @@ def test_1x1_gemm_kernels_on_split_planes(cin, cout, T, variant):
         y3, ys3 = out[3]
         back = ops.conv1d(y3, packing.pack_conv_weight_f16x3(eye), 128, 1, mode=1, x_split=ys3)
         assert (back - y3[:, :128]).abs().max().item() <= 2.0 ** -20 * float(y3.abs().max())
+
+
+@pytest.mark.parametrize("C,T", [(64, 701), (512, 1000), (128, 256)], ids=lambda v: str(v))
+def test_stride2_three_tap_conv_as_one_wrapped_product(C, T):
+    """sat_conv1d_desc.x_wrap_channels: a stride-2 3-tap conv over [even | odd] phase-split planes as ONE 1x1 product
+    over 3 C input channels, the last C of them (tap 2) reading the even phase one frame later — against
+    torch.nn.functional.conv1d(stride=2) in float64 and against the two-tap polyphase form (one zero tap) the other
+    kernels run; odd and even input lengths (the last even frame exists / is the zero pad)."""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    from satools_amd.wav2vec2 import _polyphase_stride2_weight
+    B, cout = 2, 128
+    x, w, b = _rand(B, C, T, seed=1), _rand(cout, C, 3, seed=2, scale=(3 * C) ** -0.5), _rand(cout, seed=3)
+    ref = F.conv1d(x.double(), w.double(), b.double(), stride=2)
+    Tq = ref.shape[2]
+    Th = (T + 1) // 2
+    ph = torch.zeros(B, 2 * C, Th)
+    ph[:, :C, :] = x[:, :, 0::2]
+    ph[:, C:, :T // 2] = x[:, :, 1::2]
+    phd = ph.to(DEV)
+    xs = ops.act_split(phd, 1.0)
+    ww = packing.pack_conv_weight_f16x3(torch.cat([w[:, :, 0], w[:, :, 1], w[:, :, 2]], 1).unsqueeze(-1).contiguous().to(DEV))
+    y = ops.conv1d(phd, ww, cout, 1, bias=b.to(DEV), t_out=Tq, mode=1, x_split=xs, x_wrap_channels=2 * C, c_in=3 * C)
+    assert y.shape == ref.shape
+    scale = float(ref.abs().max())
+    assert (y.cpu().double() - ref).abs().max().item() < 1e-5 * scale
+    wc, kp = _polyphase_stride2_weight(w.to(DEV))
+    y2 = ops.conv1d(phd, packing.pack_conv_weight_f16x3(wc), cout, kp, bias=b.to(DEV), pad_left=0, pad_right=0, t_out=Tq, mode=1, x_split=xs)
+    assert (y - y2).abs().max().item() < 2e-6 * scale
+    # refused where the GEMM path cannot serve it: rows not a multiple of 128
+    w96 = packing.pack_conv_weight_f16x3(torch.cat([w[:96, :, 0], w[:96, :, 1], w[:96, :, 2]], 1).unsqueeze(-1).contiguous().to(DEV))
+    with pytest.raises(_lib.SatError):
+        ops.conv1d(phd, w96, 96, 1, bias=b[:96].to(DEV), t_out=Tq, mode=1, x_split=xs, x_wrap_channels=2 * C, c_in=3 * C)
