@@ -3,6 +3,10 @@
 
 #include <type_traits>
 
+#ifndef SAT_RING_ABLATE
+#define SAT_RING_ABLATE 0
+#endif
+
 namespace sat {
 
 // ------------------------------------------------------------------------------------------------
@@ -324,7 +328,9 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
       // back; behind the barrier everybody's are, and step st's buffer is free for step st + 3
       if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if !(SAT_RING_ABLATE & 1)                     // tools/ablate_ring.hip (diagnostic builds: 1 no barrier, 2 no DMA issue, 4 no fragment reads in the loop; results are wrong)
       asm volatile("s_barrier" ::: "memory");
+#endif
       nxt = sb == 2 ? 0 : sb + 1;
     }
     h8 an[MT][2];
@@ -333,12 +339,22 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (MORE) {
         if (m == M_HAND) {
+#if !(SAT_RING_ABLATE & 2)
           if (st + 3 < nst) issue(st + 3, sb);
+#endif
+#if !(SAT_RING_ABLATE & 4)
           read_b(CUR ^ 1, nxt);
 #pragma unroll
           for (int k = 0; k <= M_HAND; ++k) read_a(an[k], nxt, k);
+#else
+          fb[CUR ^ 1][0][0] = fb[CUR][0][0]; fb[CUR ^ 1][0][1] = fb[CUR][0][1]; fb[CUR ^ 1][1][0] = fb[CUR][1][0]; fb[CUR ^ 1][1][1] = fb[CUR][1][1];
+          fb[CUR ^ 1][2][0] = fb[CUR][2][0]; fb[CUR ^ 1][2][1] = fb[CUR][2][1]; fb[CUR ^ 1][3][0] = fb[CUR][3][0]; fb[CUR ^ 1][3][1] = fb[CUR][3][1];
+          for (int k = 0; k < MT; ++k) an[k][0] = fa[k][0], an[k][1] = fa[k][1];
+#endif
         } else if (m > M_HAND) {
+#if !(SAT_RING_ABLATE & 4)
           read_a(an[m], nxt, m);             // row m - 1 has been multiplied: a pair of registers is free
+#endif
         }
       }
       __builtin_amdgcn_sched_barrier(0);
