@@ -335,7 +335,7 @@ def roofline_w2v2(model, dev, reps):
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": None,
             "kernel": f"wav2vec2-large + TDNNF tail bottleneck extractor (get_bn): all launches, {ext_ms:.3f} ms per batch of {BATCH}",
-            "dominant_kernel": {"name": "conv1d_f16x3_k1_kernel (1x1 GEMM on split planes), FFN 1024 -> 4096 + GELU, 249 frames, batch 32",
+            "dominant_kernel": {"name": "gemm_f16x3_ring16_kernel (1x1 GEMM on split planes, LDS-DMA ring, v_mfma_f32_16x16x32_f16), FFN 1024 -> 4096 + GELU, 249 frames, batch 32",
                                 "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
                                 "frac": round(flop / us / 1e6 / peak, 4)},
             "arithmetic": "f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 MFMA peak / 3",
