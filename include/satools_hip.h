@@ -148,10 +148,12 @@ int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packe
  * Weights: SAT_CONV_F16X3 packing. */
 int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
                             const float* bias1, const void* w2_packed, float* y, void* stream);
-/* f32 [B][C][T] -> split planes of lrelu(x, slope) in `format` (SAT_SPLIT_*); C % 16 == 0 */
-/* process-wide switches of the conv dispatch (A/B measurements): "k1_gemm" (default 1) sends 1x1 convs on split
- * planes with >= 128 output rows to the GEMM kernel (activation fragments straight from the planes). */
+/* process-wide switches of the conv dispatch (A/B measurements): "k1_gemm" sends 1x1 convs on split planes through
+ * 0 = the conv tile, 1 = the 128 x 128 GEMM kernel, 2 = the LDS-DMA ring GEMM (32x32x16 MFMA shape) where its
+ * 256-column tiles fit, 3 (default) = the ring GEMM on the 16x16x32 shape (results of 3 agree with 0-2 to f32 rounding
+ * of the accumulation, 0-2 agree bit for bit).  Unknown names return SAT_ERR_INVALID. */
 int sat_conv_set_option(const char* name, int value);
+/* f32 [B][C][T] -> split planes of lrelu(x, slope) in `format` (SAT_SPLIT_*); C % 16 == 0 */
 int sat_act_split_f32(const float* x, void* x_split, int B, int C, int T, float slope, int format, void* stream);
 /* cin_pad / co_pad the packed layout must use for this shape (host-side helper, no GPU needed) */
 int sat_conv1d_packed_dims(int C_in, int C_out, int up, int groups, int* cin_pad, int* co_pad);
