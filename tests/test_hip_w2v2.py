@@ -308,6 +308,27 @@ def test_full_size_batch_properties_w2v2_tag(model):
         assert torch.equal(idx1[0, 3:-3], idx[i, 3:-3]), i
 
 
+def test_converts_in_flight_on_separate_streams_equal_serial(model):
+    """the benchmark's mode on the wav2vec2 tag (bench.py run_steps, the reference's jobs_per_compute_device): eight convert() batches issued
+    round-robin onto four HIP streams from one host thread, different inputs per batch, against the same calls made
+    one after the other on the default stream — same bits (per-stream workspaces, the F0 side streams and the
+    weight caches are shared state that concurrent jobs must not trample)"""
+    from satools_amd import synthetic
+    batches = [synthetic.harm_batch(list(range(4 * j, 4 * j + 4)), 16000 + 1600 * (j % 3)).to(DEV) for j in range(8)]
+    tg = [synthetic.targets(model.spk, list(range(4 * j, 4 * j + 4))) for j in range(8)]
+    serial = [model.convert(w, target=t).clone() for w, t in zip(batches, tg)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(4)]
+    for rnd in range(2):                       # the first round also allocates the per-stream workspaces
+        outs = []
+        for j, (w, t) in enumerate(zip(batches, tg)):
+            with torch.cuda.stream(streams[j % 4]):
+                outs.append(model.convert(w, target=t))
+        torch.cuda.synchronize()
+        for j in range(8):
+            assert torch.equal(outs[j], serial[j]), (rnd, j)
+
+
 def test_convert_w2v2_tag_quant_awgn_matches_fixture(gold):
     """BASELINE configs[3]: wav2vec2 tag + f0-transformation=quant_16_awgn_2, F0 computed on the path, against the
     reference's own `convert` run under torch.manual_seed(1234)"""
