@@ -275,6 +275,9 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) oa[m2][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;          // running maximum and sum of this lane's query column
+  // softmax through the hardware exp2 (one quarter-rate instruction) instead of expf's ~15-instruction expansion: 256
+  // exponentials per lane and key block were the longest VALU stretch of the kernel
+  const float scale2 = scale * 1.44269504088896340736f;
   float* vl = (float*)at_lds;
   const float* vb = v + ((size_t)b * C + (size_t)h * 64) * v_pitch;
 
@@ -320,18 +323,18 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jk = k0 + 32 * m + 8 * (r >> 2) + 4 * lh + (r & 3);
-        const float t = jk < T ? st[m][r] * scale : -INFINITY;
+        const float t = jk < T ? st[m][r] * scale2 : -INFINITY;     // scores in units of log2: exp(x) = exp2(x log2 e)
         st[m][r] = t;
         mx = fmaxf(mx, t);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float alpha = expf(m_run - mx);          // 0 on the first block (m_run = -inf)
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mx);   // 0 on the first block (m_run = -inf); v_exp_f32, 1 ulp
     float sum = 0.f;
 #pragma unroll
     for (int m = 0; m < 8; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = expf(st[m][r] - mx);       // masked keys: exp(-inf) = 0
+        const float e = __builtin_amdgcn_exp2f(st[m][r] - mx);     // masked keys: exp2(-inf) = 0
         st[m][r] = e;
         sum += e;
       }
