@@ -135,7 +135,7 @@ typedef struct {
                               input channel c >= x_wrap_channels reads channel c - x_wrap_channels one position LATER:
                               y[t] = W[:, :Cw] x[:, t] + W[:, Cw:] x[:C_in - Cw, t + 1].  A stride-2 3-tap conv over
                               [even | odd] phase-split input is this with Cw = 2 C, C_in = 3 C (no zero taps, one GEMM).
-                              Multiples of 32; rows %% 128 == 0; positions t + 1 >= T_in read as zero */
+                              Multiples of 32; C_out % 128 == 0; positions t + 1 >= T_in read as zero */
 } sat_conv1d_desc;
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
