@@ -1305,15 +1305,22 @@ static int launch_pair16(const ConvArgs& a, int B, hipStream_t s) {
 // planes again, L2-resident) prefetched under the last one.
 // ------------------------------------------------------------------------------------------------
 template <int KS>
-__global__ void __launch_bounds__(256, 2) resblock_pair32_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(256, 3) resblock_pair32_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   constexpr int CO_B = 32;
   constexpr int XWI = 5, XWP = 64 * XWI;
   constexpr int W_UNITS = KS * 4 * CO_B;
   constexpr int W_IT = (W_UNITS + 255) / 256;
-  uint4* ldsx = lds4;                       // [4][XWP]       input chunk
-  uint4* ldsw = lds4 + 4 * XWP;             // [KS][4][32]    weight chunk
-  uint4* ldst = ldsw + W_UNITS;             // [2][4][FP_W1]  t1, both chunks
+  // Three blocks per CU (168 VGPRs allow it; the kernel waits on memory 45 % of its cycles at two): the t1 image lies
+  // OVER the input chunk, which is dead once conv1's last MFMA phase has read it (one barrier in between), and for 11
+  // taps the t1 window is trimmed to the 234 columns conv2 reads — 22.5 KB of weights + 29.5 KB = 52 KB per block.
+  constexpr int W1 = KS == 11 ? 236 : FP_W1;      // t1 window [t0 - OFF, t0 - OFF + W1)
+  constexpr int OFF = KS == 11 ? 6 : FP_OFF;
+  static_assert(OFF >= (KS - 1) / 2 && OFF - (KS - 1) / 2 + FP_TO + KS - 1 <= W1, "conv2 reads t1 columns OFF - h2 .. OFF - h2 + 224 + 2 h2");
+  uint4* ldsw = lds4;                       // [KS][4][32]    weight chunk
+  uint4* ldsx = lds4 + W_UNITS;             // [4][XWP]       input chunk
+  uint4* ldst = ldsx;                       // [2][4][W1]     t1, both chunks (over the input chunk)
+  static_assert(2 * 4 * W1 >= 4 * XWP, "the LDS size of the launcher is that of the t1 image");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1323,7 +1330,7 @@ __global__ void __launch_bounds__(256, 2) resblock_pair32_kernel(const ConvArgs 
   const int b = blockIdx.z;
   const int t0 = blockIdx.x * FP_TO;
   const int h2 = (KS - 1) / 2;
-  const int xi0 = t0 - FP_OFF - p.pad_left;
+  const int xi0 = t0 - OFF - p.pad_left;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.x16 + (long long)b * 32 * p.T_in * 4), 0, (unsigned)(32 * p.T_in * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_gs, 0x00020000);
@@ -1406,11 +1413,12 @@ __global__ void __launch_bounds__(256, 2) resblock_pair32_kernel(const ConvArgs 
   issue_w(w2rs, 0);
   __builtin_amdgcn_sched_barrier(0);
   mfma_chunk(xbase, XWP, p.dil, false);
+  __syncthreads();                          // every wave is done reading the input chunk: t1 goes over it
   // t1 -> LDS as conv2's B operand (hi|lo planes of both chunks)
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = (wave + 4 * n) * 32 + l31;
-    const int pos = t0 - FP_OFF + col;
+    const int pos = t0 - OFF + col;
     const bool inside = pos >= 0 && pos < p.T_in;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -1425,10 +1433,12 @@ __global__ void __launch_bounds__(256, 2) resblock_pair32_kernel(const ConvArgs 
       const auto h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
       const auto l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
       const auto l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
-      ((uint2*)(ldst + (((rg >> 1) * 4 + 0 + (rg & 1)) * FP_W1 + col)))[lh] =
-          make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-      ((uint2*)(ldst + (((rg >> 1) * 4 + 2 + (rg & 1)) * FP_W1 + col)))[lh] =
-          make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+      if (col < W1) {
+        ((uint2*)(ldst + (((rg >> 1) * 4 + 0 + (rg & 1)) * W1 + col)))[lh] =
+            make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+        ((uint2*)(ldst + (((rg >> 1) * 4 + 2 + (rg & 1)) * W1 + col)))[lh] =
+            make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+      }
     }
   }
   // ---- conv2, chunk 0 and 1 ----
@@ -1438,15 +1448,15 @@ __global__ void __launch_bounds__(256, 2) resblock_pair32_kernel(const ConvArgs 
   __syncthreads();
   issue_w(w2rs, 1);
   __builtin_amdgcn_sched_barrier(0);
-  const uint4* tbase = ldst + lh * FP_W1 + FP_OFF - h2 + wave * 32 + l31;
-  mfma_chunk(tbase, FP_W1, 1, true);
+  const uint4* tbase = ldst + lh * W1 + OFF - h2 + wave * 32 + l31;
+  mfma_chunk(tbase, W1, 1, true);
   __syncthreads();
   publish_w();
   __syncthreads();
   float rpre[1][2][16];
   epilogue_prefetch_res<1, 2>(p, rpre, b, 0, 0, t0 + wave * 32, l31, lh, 128, t0 + FP_TO);
   __builtin_amdgcn_sched_barrier(0);
-  mfma_chunk(tbase + 4 * FP_W1, FP_W1, 1, true);
+  mfma_chunk(tbase + 4 * W1, W1, 1, true);
   conv_epilogue<1, 2, true>(p, acc, b, 0, 0, t0 + wave * 32, l31, lh, 128, t0 + FP_TO, rpre);
 }
 
@@ -1457,7 +1467,7 @@ static int launch_pair32(const ConvArgs& a, int B, hipStream_t s) {
     set_error("resblock_pair: dilation %d too large", p.dil);
     return SAT_ERR_INVALID;
   }
-  const size_t lds_bytes = ((size_t)4 * 320 + (size_t)KS * 4 * 32 + (size_t)2 * 4 * FP_W1) * 16;
+  const size_t lds_bytes = ((size_t)KS * 4 * 32 + (size_t)2 * 4 * (KS == 11 ? 236 : FP_W1)) * 16;   // weights + t1 (over the input chunk)
   auto kern = resblock_pair32_kernel<KS>;
   if (lds_bytes > 64 * 1024)
     SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
