@@ -22,6 +22,9 @@ namespace sat {
 // 2 = gemm_f16x3_ring_kernel where its 256-column tiles fit (else 1), 3 = the 16x16x32-shape ring kernel where its
 // epilogue subset covers the call (else 2)
 static int g_k1_gemm = 3;
+// sat_conv_set_option("lean3", v): 3-tap convs on split planes through the three-blocks-per-CU form of the tile (1) or the
+// two-block form with two sub-chunks per stage (0)
+static int g_lean3 = 1;
 
 template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1, int XWI>
 __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
@@ -423,8 +426,11 @@ __device__ __forceinline__ void polyphase_planes_epilogue(const ConvArgs& p, f32
 // S: 16-channel sub-chunks per pipeline stage.  With few taps the matrix work of a 16-channel chunk (1152
 // cycles at 3 taps) is dwarfed by the ~2800 cycles of barriers, LDS stores and load issue around it: S = 2
 // halves the number of stages.
-template <int MT, int NT, int KS, int XWI, bool F8, int S>
-__global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvArgs p) {
+// LEAN: three blocks per CU instead of two for the layers whose launches wait on memory most of the time (3 taps: 18-32 %
+// MFMA-busy): fragments single-buffered, no residual prefetch registers, so that the kernel fits 168 VGPRs; the third
+// co-resident block covers the latencies the deeper pipelining of the two-block form was there to hide.
+template <int MT, int NT, int KS, int XWI, bool F8, int S, bool LEAN = false>
+__global__ void __launch_bounds__(256, LEAN ? 3 : 2) conv1d_f16x3_planes_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   constexpr int CO_B = 32 * MT;
   constexpr int T_B = 128 * NT;
@@ -502,7 +508,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvA
   const int sc_a = lh ? F8_E_WHI : F8_E_WLO;
   const int sc_b = lh ? F8_E_XLO : F8_E_XHI;
   auto mfma_phase = [&]() {
-   if constexpr (!F8) {
+   if constexpr (!F8 && !LEAN) {
     // fragments of tap idx + 1 are read from LDS ahead of tap idx's MFMAs (double-buffered registers; the
     // scheduler would otherwise sink the reads to their first use and every tap would start on an LDS round trip)
     h8 fa[2][MT][2], fb[2][NT][2];
@@ -637,6 +643,15 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvA
   SAT_STAMP(2);
   __syncthreads();
   SAT_STAMP(3);
+  if constexpr (LEAN) {
+    mfma_phase();
+    if (p.poly_planes) {
+      polyphase_planes_epilogue<MT, NT>(p, acc, (float*)lds4, b, co_w, q_b, wave, l31, lh);
+      return;
+    }
+    conv_epilogue<MT, NT, false, false>(p, acc, b, 0, co_w, q_w, l31, lh);
+    return;
+  }
   float rpre[MT][NT][16];
   if (p.res || p.res16) epilogue_prefetch_res<MT, NT>(p, rpre, b, 0, co_w, q_w, l31, lh);
   __builtin_amdgcn_sched_barrier(0);
@@ -681,6 +696,12 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
       if (!p.f8 && (p.cin_pad / CI_CHUNK) % 2 == 0) {
         kern = conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 2>;
         lds_bytes *= 2;
+      }
+    }
+    if constexpr (KS == 3 && MT == 2 && NT == 2) {
+      if (!p.f8 && g_lean3 && !p.ch_scale && p.fast_epi) {   // three blocks per CU (32 KB of LDS each); its epilogue carries no folded BatchNorm
+        kern = conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 1, true>;
+        lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * CO_B) * 16;
       }
     }
     if constexpr (KS == 1 || KS == 2) {
@@ -1802,6 +1823,7 @@ extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, in
 
 extern "C" int sat_conv_set_option(const char* name, int value) {
   SAT_REQUIRE(name, "conv_set_option: null name");
+  if (!strcmp(name, "lean3")) { g_lean3 = value != 0; return SAT_OK; }
   if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }
   set_error("conv_set_option: unknown option '%s'", name);
   return SAT_ERR_INVALID;

@@ -149,7 +149,9 @@ __device__ __forceinline__ void decode_res16(float w0, float w1, float w2, float
   for (int k = 0; k < 4; ++k) out[k] = out[k] > 0.f ? out[k] : out[k] * inv_slope;
 }
 
-template <int MT, int NT, bool RPRE = false>
+// HAS_BN = false compiles the folded-BatchNorm step out of the fast path (32 registers of scale / shift per row tile):
+// for kernels that must fit 168 VGPRs and are only dispatched without ch_scale
+template <int MT, int NT, bool RPRE = false, bool HAS_BN = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NT], int b, int g, int co_w,
                                               int q_w, int l31, int lh, int q_step = 32, int q_end = 0x7fffffff,
                                               float (*rpre)[NT][16] = nullptr) {
@@ -189,7 +191,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, row0 * 4 + ((r & 3) + 8 * (r >> 2)) * 4, 0, 0));
-      if (p.ch_scale) {
+      if (HAS_BN && p.ch_scale) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ro = ((r & 3) + 8 * (r >> 2)) * 4;
@@ -260,7 +262,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
-        if (p.ch_scale) {
+        if (HAS_BN && p.ch_scale) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = v[r] * sc[r] + sh[r];
         }
