@@ -241,12 +241,13 @@ __global__ void __launch_bounds__(1024) softmax_cols_kernel(float* __restrict__ 
 //   query, so the softmax is an in-lane reduction plus one exchange between the two lane halves.
 //   P feeds the second product from the same registers: MFMA k-slot e of lane half lh is given the key
 //   32m + 16hh + 8(e>>2) + 4lh + (e&3) — the key the accumulator register 8hh + e of tile m holds — and V's A
-//   fragments (two float4 of a row of V^T, split to f16 on the fly) follow that order, so no data moves.
-//   Block = 4 waves = 128 queries; the head's K planes (64 KB), then its V (f32, 65 KB), are staged in LDS.
+//   fragments (split to f16 once, when the head's V is staged) are laid out in that order, so no data moves.
+//   Block = 4 waves = 128 queries; the head's K planes (64 KB), then its V (split to f16 in fragment order, 66 KB), are
+//   staged in LDS.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int AT_VP = 260;      // LDS row pitch of V in floats: rows 4 banks apart -> conflict-free 16-byte reads
+constexpr int AT_VU = 33;       // LDS row pitch of the split V image in 16-byte units: rows 4 banks apart -> conflict-free 16-byte reads
 
 __device__ __forceinline__ void split8(const float (&a)[8], h8& hi, h8& lo) {
 #pragma unroll
@@ -278,7 +279,6 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
   // softmax through the hardware exp2 (one quarter-rate instruction) instead of expf's ~15-instruction expansion: 256
   // exponentials per lane and key block were the longest VALU stretch of the kernel
   const float scale2 = scale * 1.44269504088896340736f;
-  float* vl = (float*)at_lds;
   const float* vb = v + ((size_t)b * C + (size_t)h * 64) * v_pitch;
 
   // keys in blocks of 256 (one block for T <= 256); longer utterances keep a running softmax over the blocks
@@ -346,7 +346,11 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) oa[m2][r] *= alpha;
 
-    // ---- V of the head (f32 [64][v_pitch]), keys k0 .. -> LDS [64][AT_VP], keys >= T zero ----
+    // ---- V of the head (f32 [64][v_pitch]), keys k0 .. -> LDS, split to hi | lo f16 ONCE and laid out as the A
+    // fragments of the second product: unit [part][d][16 k-steps x 2 lane halves] (row pitch AT_VU units: 4 banks apart,
+    // conflict-free 16-byte reads down a column of d) holding the keys 16 ks + 4 lh + {0..3} and 16 ks + 8 + 4 lh + {0..3}
+    // — the k-slot order of the P registers.  (Before: f32 rows in LDS and every wave of both query blocks split the
+    // same V on the fly, ~770 VALU instructions per wave and key block next to 96 MFMAs.)  Keys >= T zero.
     __syncthreads();                        // every wave is done with K
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -358,7 +362,14 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
       if (jg + 1 >= T) w.y = 0.f;
       if (jg + 2 >= T) w.z = 0.f;
       if (jg + 3 >= T) w.w = 0.f;
-      *(float4*)(vl + d * AT_VP + j4) = w;
+      const auto h01 = __builtin_amdgcn_cvt_pkrtz(w.x, w.y);
+      const auto h23 = __builtin_amdgcn_cvt_pkrtz(w.z, w.w);
+      const auto l01 = __builtin_amdgcn_cvt_pkrtz(w.x - (float)h01[0], w.y - (float)h01[1]);
+      const auto l23 = __builtin_amdgcn_cvt_pkrtz(w.z - (float)h23[0], w.w - (float)h23[1]);
+      // keys j4 .. j4 + 3 of the block: k-step j4 / 16, lane half (j4 / 4) & 1, first or second 8 bytes of the unit
+      uint2* dst = (uint2*)(at_lds + d * AT_VU + (j4 >> 4) * 2 + ((j4 >> 2) & 1)) + ((j4 >> 3) & 1);
+      dst[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+      dst[2 * 64 * AT_VU] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
     }
     __syncthreads();
 
@@ -374,11 +385,9 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
         split8(pv, b_hi, b_lo);
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2) {
-          const float* row = vl + (32 * m2 + l31) * AT_VP + 32 * m + 16 * hh + 4 * lh;
-          const float4 va = *(const float4*)row, vc = *(const float4*)(row + 8);
-          const float av[8] = {va.x, va.y, va.z, va.w, vc.x, vc.y, vc.z, vc.w};
-          h8 a_hi, a_lo;
-          split8(av, a_hi, a_lo);
+          const uint4* vu = at_lds + (32 * m2 + l31) * AT_VU + (2 * m + hh) * 2 + lh;
+          const h8 a_hi = __builtin_bit_cast(h8, vu[0]);
+          const h8 a_lo = __builtin_bit_cast(h8, vu[64 * AT_VU]);
           oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, oa[m2], 0, 0, 0);
           oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, oa[m2], 0, 0, 0);
           oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, oa[m2], 0, 0, 0);
@@ -519,7 +528,7 @@ extern "C" int sat_attention_f16x3(const void* q_split, const void* k_split, con
   SAT_REQUIRE(B > 0 && heads > 0 && T > 0, "attention: empty shape");
   SAT_REQUIRE(head_dim == 64, "attention: head dimension 64 only (got %d)", head_dim);
   SAT_REQUIRE(v_pitch >= T && v_pitch % 4 == 0, "attention: v needs a row pitch >= T that is a multiple of 4 floats (got %d)", v_pitch);
-  const size_t lds_bytes = (size_t)64 * AT_VP * 4;       // V [64][260] f32 >= K planes (16 x 256 x 16 B)
+  const size_t lds_bytes = (size_t)2 * 64 * AT_VU * 16;  // split V image [hi|lo][64][33 units] >= K planes (16 x 256 x 16 B)
   SAT_HIP(hipFuncSetAttribute((const void*)attention_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   dim3 grid(ceil_div(T, 128), heads, B);
   hipLaunchKernelGGL(attention_f16x3_kernel, grid, dim3(256), lds_bytes, (hipStream_t)stream, (const uint4*)q_split,
