@@ -280,6 +280,7 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
   // exponentials per lane and key block were the longest VALU stretch of the kernel
   const float scale2 = scale * 1.44269504088896340736f;
   const float* vb = v + ((size_t)b * C + (size_t)h * 64) * v_pitch;
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (unsigned)(64 * v_pitch * 4), 0x00020000);
 
   // keys in blocks of 256 (one block for T <= 256); longer utterances keep a running softmax over the blocks
   for (int k0 = 0; k0 < T; k0 += 256) {
@@ -305,15 +306,25 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
     for (int m = 0; m < 8; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[m][r] = 0.f;
+    {
+      // K fragments of tile i + 1 are read ahead of tile i's MFMAs (second register pair, fenced: left alone the
+      // scheduler sinks each read to its first use and every three MFMAs start on an LDS round trip)
+      h8 ka[2][2];
+      auto ldk = [&](int buf, int i) __attribute__((always_inline)) {
+        const int cl = i >> 3, m = i & 7;
+        ka[buf][0] = __builtin_bit_cast(h8, at_lds[(cl * 4 + 0 + lh) * 256 + 32 * m + l31]);
+        ka[buf][1] = __builtin_bit_cast(h8, at_lds[(cl * 4 + 2 + lh) * 256 + 32 * m + l31]);
+      };
+      ldk(0, 0);
 #pragma unroll
-    for (int cl = 0; cl < 4; ++cl) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const h8 a_hi = __builtin_bit_cast(h8, at_lds[(cl * 4 + 0 + lh) * 256 + 32 * m + l31]);
-        const h8 a_lo = __builtin_bit_cast(h8, at_lds[(cl * 4 + 2 + lh) * 256 + 32 * m + l31]);
-        st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, qh[cl], st[m], 0, 0, 0);
-        st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, ql[cl], st[m], 0, 0, 0);
-        st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, qh[cl], st[m], 0, 0, 0);
+      for (int i = 0; i < 32; ++i) {
+        const int cl = i >> 3, m = i & 7;
+        if (i + 1 < 32) ldk((i + 1) & 1, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[i & 1][1], qh[cl], st[m], 0, 0, 0);
+        st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[i & 1][0], ql[cl], st[m], 0, 0, 0);
+        st[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[i & 1][0], qh[cl], st[m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- softmax over keys: register r of tile m is key k0 + 32m + 8(r>>2) + 4lh + (r&3) ----
@@ -352,12 +363,23 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
     // — the k-slot order of the P registers.  (Before: f32 rows in LDS and every wave of both query blocks split the
     // same V on the fly, ~770 VALU instructions per wave and key block next to 96 MFMAs.)  Keys >= T zero.
     __syncthreads();                        // every wave is done with K
+    // two batches of eight 16-byte loads per lane, each batch in flight at once (a buffer descriptor's range check
+    // instead of a branch around every load: the branchy form ran sixteen global round trips one after the other)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int u = tid + 256 * i;          // float4 index: row d = u / 64, keys k0 + 4 (u % 64) ..
+    for (int hb = 0; hb < 2; ++hb) {
+    float4 wv[8];
+#pragma unroll
+    for (int i8 = 0; i8 < 8; ++i8) {
+      const int u = tid + 256 * (8 * hb + i8);
+      const int d = u >> 6, jg = k0 + (u & 63) * 4;
+      const unsigned off = jg < v_pitch ? (unsigned)((d * v_pitch + jg) * 4) : 0x80000000u;
+      wv[i8] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(vrs, off, 0, 0));
+    }
+#pragma unroll
+    for (int i8 = 0; i8 < 8; ++i8) {
+      const int u = tid + 256 * (8 * hb + i8);   // float4 index: row d = u / 64, keys k0 + 4 (u % 64) ..
       const int d = u >> 6, j4 = (u & 63) * 4, jg = k0 + j4;
-      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (jg < v_pitch) w = *(const float4*)(vb + (size_t)d * v_pitch + jg);
+      float4 w = wv[i8];
       if (jg + 0 >= T) w.x = 0.f;
       if (jg + 1 >= T) w.y = 0.f;
       if (jg + 2 >= T) w.z = 0.f;
@@ -371,27 +393,38 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
       dst[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
       dst[2 * 64 * AT_VU] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
     }
+    }
     __syncthreads();
 
     // ---- O += V P: 2 row tiles (64 head dims) x 16 k-steps of 16 keys ----
+    {
+      h8 va[2][2][2];                       // [buffer][row tile][hi | lo]: the next k-step's V fragments are read ahead
+      auto ldv = [&](int buf, int ks) __attribute__((always_inline)) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+        for (int m2 = 0; m2 < 2; ++m2) {
+          const uint4* vu = at_lds + (32 * m2 + l31) * AT_VU + ks * 2 + lh;
+          va[buf][m2][0] = __builtin_bit_cast(h8, vu[0]);
+          va[buf][m2][1] = __builtin_bit_cast(h8, vu[64 * AT_VU]);
+        }
+      };
+      ldv(0, 0);
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
+      for (int ks = 0; ks < 16; ++ks) {     // k-step ks = keys 16 ks .. 16 ks + 15 = registers 8 (ks & 1) .. of tile ks / 2
+        const int m = ks >> 1, hh = ks & 1;
+        if (ks + 1 < 16) ldv((ks + 1) & 1, ks + 1);
         float pv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) pv[e] = st[m][8 * hh + e];
         h8 b_hi, b_lo;
         split8(pv, b_hi, b_lo);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2) {
-          const uint4* vu = at_lds + (32 * m2 + l31) * AT_VU + (2 * m + hh) * 2 + lh;
-          const h8 a_hi = __builtin_bit_cast(h8, vu[0]);
-          const h8 a_lo = __builtin_bit_cast(h8, vu[64 * AT_VU]);
-          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, oa[m2], 0, 0, 0);
-          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, oa[m2], 0, 0, 0);
-          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, oa[m2], 0, 0, 0);
+          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[ks & 1][m2][1], b_hi, oa[m2], 0, 0, 0);
+          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[ks & 1][m2][0], b_lo, oa[m2], 0, 0, 0);
+          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[ks & 1][m2][0], b_hi, oa[m2], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
