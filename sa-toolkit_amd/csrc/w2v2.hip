@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(1024) softmax_cols_kernel(float* __restrict__ 
 //   P feeds the second product from the same registers: MFMA k-slot e of lane half lh is given the key
 //   32m + 16hh + 8(e>>2) + 4lh + (e&3) — the key the accumulator register 8hh + e of tile m holds — and V's A
 //   fragments (split to f16 once, when the head's V is staged) are laid out in that order, so no data moves.
-//   Block = 4 waves = 128 queries; the head's K planes (64 KB), then its V (split to f16 in fragment order, 66 KB), are
+//   Block = NW waves = 32 NW queries; the head's K planes (64 KB), then its V (split to f16 in fragment order, 66 KB), are
 //   staged in LDS.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -259,13 +259,18 @@ __device__ __forceinline__ void split8(const float (&a)[8], h8& hi, h8& lo) {
   }
 }
 
-__global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __restrict__ qs, const uint4* __restrict__ ks,
+// NW waves per block = 32 NW queries: 8 (one block per head at 249 frames: K and V are fetched and staged ONCE per head — with
+// four-wave blocks the two query blocks of a head each did it, and the kernel moves ~130 MB per launch at 2-3 TB/s) or 4
+// (utterances of up to 128 frames).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 2) attention_f16x3_kernel(const uint4* __restrict__ qs, const uint4* __restrict__ ks,
                                                                 const float* __restrict__ v, float* __restrict__ o,
                                                                 uint4* __restrict__ os, int C, int T, int v_pitch, float scale) {
   extern __shared__ __attribute__((aligned(16))) uint4 at_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;          // this lane's query column
+  constexpr int NTHR = 64 * NW;
+  const int q = blockIdx.x * (32 * NW) + wave * 32 + l31;     // this lane's query column
   const bool qok = q < T;
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   const size_t ub = (size_t)b * (C / 4) * T;                 // units per utterance: C * T * 4 bytes
@@ -287,8 +292,10 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
     // ---- K planes of the head, keys k0 .. k0 + 255 -> LDS [chunk*4 + plane][256] (keys >= T zero) ----
     __syncthreads();                        // the previous block's V is no longer read
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      at_lds[r * 256 + tid] = k0 + tid < T ? ks[ub + (size_t)((4 * h + (r >> 2)) * 4 + (r & 3)) * T + k0 + tid] : zero4;
+    for (int r = 0; r < 4096 / NTHR; ++r) {
+      const int i = r * NTHR + tid, row = i >> 8, col = i & 255;     // unit (plane row, key)
+      at_lds[i] = k0 + col < T ? ks[ub + (size_t)((4 * h + (row >> 2)) * 4 + (row & 3)) * T + k0 + col] : zero4;
+    }
     // Q fragments of the wave's 32 queries (re-read per key block from L2: holding them across the V product
     // would spill registers)
     h8 qh[4], ql[4];
@@ -363,21 +370,21 @@ __global__ void __launch_bounds__(256, 2) attention_f16x3_kernel(const uint4* __
     // — the k-slot order of the P registers.  (Before: f32 rows in LDS and every wave of both query blocks split the
     // same V on the fly, ~770 VALU instructions per wave and key block next to 96 MFMAs.)  Keys >= T zero.
     __syncthreads();                        // every wave is done with K
-    // two batches of eight 16-byte loads per lane, each batch in flight at once (a buffer descriptor's range check
+    // batches of eight 16-byte loads per lane, each batch in flight at once (a buffer descriptor's range check
     // instead of a branch around every load: the branchy form ran sixteen global round trips one after the other)
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
+    for (int hb = 0; hb < 512 / NTHR; ++hb) {
     float4 wv[8];
 #pragma unroll
     for (int i8 = 0; i8 < 8; ++i8) {
-      const int u = tid + 256 * (8 * hb + i8);
+      const int u = tid + NTHR * (8 * hb + i8);
       const int d = u >> 6, jg = k0 + (u & 63) * 4;
       const unsigned off = jg < v_pitch ? (unsigned)((d * v_pitch + jg) * 4) : 0x80000000u;
       wv[i8] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(vrs, off, 0, 0));
     }
 #pragma unroll
     for (int i8 = 0; i8 < 8; ++i8) {
-      const int u = tid + 256 * (8 * hb + i8);   // float4 index: row d = u / 64, keys k0 + 4 (u % 64) ..
+      const int u = tid + NTHR * (8 * hb + i8);  // float4 index: row d = u / 64, keys k0 + 4 (u % 64) ..
       const int d = u >> 6, j4 = (u & 63) * 4, jg = k0 + j4;
       float4 w = wv[i8];
       if (jg + 0 >= T) w.x = 0.f;
@@ -562,9 +569,11 @@ extern "C" int sat_attention_f16x3(const void* q_split, const void* k_split, con
   SAT_REQUIRE(head_dim == 64, "attention: head dimension 64 only (got %d)", head_dim);
   SAT_REQUIRE(v_pitch >= T && v_pitch % 4 == 0, "attention: v needs a row pitch >= T that is a multiple of 4 floats (got %d)", v_pitch);
   const size_t lds_bytes = (size_t)2 * 64 * AT_VU * 16;  // split V image [hi|lo][64][33 units] >= K planes (16 x 256 x 16 B)
-  SAT_HIP(hipFuncSetAttribute((const void*)attention_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  dim3 grid(ceil_div(T, 128), heads, B);
-  hipLaunchKernelGGL(attention_f16x3_kernel, grid, dim3(256), lds_bytes, (hipStream_t)stream, (const uint4*)q_split,
+  const int nw = T > 128 ? 8 : 4;
+  auto kern = nw == 8 ? attention_f16x3_kernel<8> : attention_f16x3_kernel<4>;
+  SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  dim3 grid(ceil_div(T, 32 * nw), heads, B);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds_bytes, (hipStream_t)stream, (const uint4*)q_split,
                      (const uint4*)k_split, v, o, (uint4*)o_split, heads * head_dim, T, v_pitch, scale);
   SAT_LAUNCH_CHECK("attention_f16x3_kernel");
   return SAT_OK;
