@@ -25,6 +25,7 @@ static int g_k1_gemm = 3;
 // sat_conv_set_option("lean3", v): 3-tap convs on split planes through the three-blocks-per-CU form of the tile (1) or the
 // two-block form with two sub-chunks per stage (0)
 static int g_lean3 = 1;
+static int g_lean7 = 1;
 
 template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1, int XWI>
 __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
@@ -698,8 +699,8 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
         lds_bytes *= 2;
       }
     }
-    if constexpr (KS == 3 && MT == 2 && NT == 2) {
-      if (!p.f8 && g_lean3 && !p.ch_scale && p.fast_epi) {   // three blocks per CU (32 KB of LDS each); its epilogue carries no folded BatchNorm
+    if constexpr ((KS == 3 || KS == 7) && MT == 2 && NT == 2) {
+      if (!p.f8 && (KS == 3 ? g_lean3 : g_lean7) && !p.ch_scale && p.fast_epi) {   // three blocks per CU (32 / 48 KB of LDS each); its epilogue carries no folded BatchNorm
         kern = conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 1, true>;
         lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * CO_B) * 16;
       }
@@ -1824,6 +1825,7 @@ extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, in
 extern "C" int sat_conv_set_option(const char* name, int value) {
   SAT_REQUIRE(name, "conv_set_option: null name");
   if (!strcmp(name, "lean3")) { g_lean3 = value != 0; return SAT_OK; }
+  if (!strcmp(name, "lean7")) { g_lean7 = value != 0; return SAT_OK; }
   if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }
   set_error("conv_set_option: unknown option '%s'", name);
   return SAT_ERR_INVALID;

@@ -822,30 +822,30 @@ def test_stride2_three_tap_conv_as_one_wrapped_product(C, T):
         ops.conv1d(phd, w96, 96, 1, bias=b[:96].to(DEV), t_out=Tq, mode=1, x_split=xs, x_wrap_channels=2 * C, c_in=3 * C)
 
 
-@pytest.mark.parametrize("C,T,dil", [(64, 700, 1), (128, 513, 5), (256, 250, 3)], ids=lambda v: str(v))
-def test_three_blocks_per_cu_form_of_the_3_tap_tile_gives_the_same_bits(C, T, dil):
-    """sat_conv_set_option("lean3"): the 3-tap conv on split planes through the two-block form (two sub-chunks per stage,
-    double-buffered fragments, residual prefetch) and through the three-blocks-per-CU form (the default): same
+@pytest.mark.parametrize("C,T,dil,k", [(64, 700, 1, 3), (128, 513, 5, 3), (256, 250, 3, 3), (64, 700, 5, 7), (256, 250, 1, 7)], ids=lambda v: str(v))
+def test_three_blocks_per_cu_form_of_the_conv_tile_gives_the_same_bits(C, T, dil, k):
+    """sat_conv_set_option("lean3" / "lean7"): the 3- and 7-tap convs on split planes through the two-block form
+    (double-buffered fragments, residual prefetch) and through the three-blocks-per-CU form (the default): same
     accumulation order, same epilogue arithmetic — same bits, with the generator's conv2 epilogue (residual from
     planes, MRF accumulate / 3, f32 + planes out)"""
     ops, packing = _ops()
     from satools_amd import _lib
     B = 3
-    x, w, b = _rand(B, C, T, seed=1).to(DEV), _rand(C, C, 3, seed=2, scale=(3 * C) ** -0.5).to(DEV), _rand(C, seed=3).to(DEV)
+    x, w, b = _rand(B, C, T, seed=1).to(DEV), _rand(C, C, k, seed=2, scale=(k * C) ** -0.5).to(DEV), _rand(C, seed=3).to(DEV)
     r, acc0 = _rand(B, C, T, seed=4).to(DEV), _rand(B, C, T, seed=5).to(DEV)
     xs, rs = ops.act_split(x, 0.1), ops.act_split(r, 0.1)
     wp = packing.pack_conv_weight_f16x3(w)
     out = {}
     try:
         for v in (0, 1):
-            _lib.check(_lib.lib().sat_conv_set_option(b"lean3", v), "sat_conv_set_option")
+            _lib.check(_lib.lib().sat_conv_set_option(b"lean%d" % k, v), "sat_conv_set_option")
             ys = ops.split_like(B, C, T, DEV)
-            y = ops.conv1d(x, wp, C, 3, bias=b, dilation=dil, pad_left=dil, mode=1, x_split=xs, res_split=rs, res_split_slope=0.1,
+            y = ops.conv1d(x, wp, C, k, bias=b, dilation=dil, pad_left=dil * (k - 1) // 2, mode=1, x_split=xs, res_split=rs, res_split_slope=0.1,
                            out=acc0.clone(), accum=True, accum_div=3.0, y_split=ys, y_split_slope=0.1)
             out[v] = (y, ys)
     finally:
-        _lib.check(_lib.lib().sat_conv_set_option(b"lean3", 1), "sat_conv_set_option")
+        _lib.check(_lib.lib().sat_conv_set_option(b"lean%d" % k, 1), "sat_conv_set_option")
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
-    ref = (acc0.double().cpu() + F.conv1d(F.leaky_relu(x.double().cpu(), 0.1), w.double().cpu(), b.double().cpu(), dilation=dil, padding=dil)
+    ref = (acc0.double().cpu() + F.conv1d(F.leaky_relu(x.double().cpu(), 0.1), w.double().cpu(), b.double().cpu(), dilation=dil, padding=dil * (k - 1) // 2)
            + r.double().cpu()) / 3.0
     assert (out[1][0].cpu().double() - ref).abs().max().item() < 3e-5
