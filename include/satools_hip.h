@@ -151,8 +151,8 @@ int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void
 /* process-wide switches of the conv dispatch (A/B measurements): "k1_gemm" sends 1x1 convs on split planes through
  * 0 = the conv tile, 1 = the 128 x 128 GEMM kernel, 2 = the LDS-DMA ring GEMM (32x32x16 MFMA shape) where its
  * 256-column tiles fit, 3 (default) = the ring GEMM on the 16x16x32 shape (results of 3 agree with 0-2 to f32 rounding
- * of the accumulation, 0-2 agree bit for bit); "lean3" / "lean7" (default 1) run 3- / 7-tap convs on split planes
- * without folded BatchNorm through the three-blocks-per-CU form of the conv tile (same bits as 0).  Unknown names return
+ * of the accumulation, 0-2 agree bit for bit); "lean3" / "lean7" / "lean11" (default 1) run 3- / 7- / 11-tap convs on
+ * split planes without folded BatchNorm through the three-blocks-per-CU form of the conv tile (same bits as 0).  Unknown names return
  * SAT_ERR_INVALID. */
 int sat_conv_set_option(const char* name, int value);
 /* f32 [B][C][T] -> split planes of lrelu(x, slope) in `format` (SAT_SPLIT_*); C % 16 == 0 */

@@ -22,10 +22,9 @@ namespace sat {
 // 2 = gemm_f16x3_ring_kernel where its 256-column tiles fit (else 1), 3 = the 16x16x32-shape ring kernel where its
 // epilogue subset covers the call (else 2)
 static int g_k1_gemm = 3;
-// sat_conv_set_option("lean3", v): 3-tap convs on split planes through the three-blocks-per-CU form of the tile (1) or the
-// two-block form with two sub-chunks per stage (0)
-static int g_lean3 = 1;
-static int g_lean7 = 1;
+// sat_conv_set_option("lean3" | "lean7" | "lean11", v): 3- / 7- / 11-tap convs on split planes (no folded BatchNorm) through
+// the three-blocks-per-CU form of the tile (1, conv_lean.hip) or the two-block form (0)
+static int g_lean3 = 1, g_lean7 = 1, g_lean11 = 1;
 
 template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1, int XWI>
 __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
@@ -427,11 +426,8 @@ __device__ __forceinline__ void polyphase_planes_epilogue(const ConvArgs& p, f32
 // S: 16-channel sub-chunks per pipeline stage.  With few taps the matrix work of a 16-channel chunk (1152
 // cycles at 3 taps) is dwarfed by the ~2800 cycles of barriers, LDS stores and load issue around it: S = 2
 // halves the number of stages.
-// LEAN: three blocks per CU instead of two for the layers whose launches wait on memory most of the time (3 taps: 18-32 %
-// MFMA-busy): fragments single-buffered, no residual prefetch registers, so that the kernel fits 168 VGPRs; the third
-// co-resident block covers the latencies the deeper pipelining of the two-block form was there to hide.
-template <int MT, int NT, int KS, int XWI, bool F8, int S, bool LEAN = false>
-__global__ void __launch_bounds__(256, LEAN ? 3 : 2) conv1d_f16x3_planes_kernel(const ConvArgs p) {
+template <int MT, int NT, int KS, int XWI, bool F8, int S>
+__global__ void __launch_bounds__(256, 2) conv1d_f16x3_planes_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   constexpr int CO_B = 32 * MT;
   constexpr int T_B = 128 * NT;
@@ -509,7 +505,7 @@ __global__ void __launch_bounds__(256, LEAN ? 3 : 2) conv1d_f16x3_planes_kernel(
   const int sc_a = lh ? F8_E_WHI : F8_E_WLO;
   const int sc_b = lh ? F8_E_XLO : F8_E_XHI;
   auto mfma_phase = [&]() {
-   if constexpr (!F8 && !LEAN) {
+   if constexpr (!F8) {
     // fragments of tap idx + 1 are read from LDS ahead of tap idx's MFMAs (double-buffered registers; the
     // scheduler would otherwise sink the reads to their first use and every tap would start on an LDS round trip)
     h8 fa[2][MT][2], fb[2][NT][2];
@@ -644,15 +640,6 @@ __global__ void __launch_bounds__(256, LEAN ? 3 : 2) conv1d_f16x3_planes_kernel(
   SAT_STAMP(2);
   __syncthreads();
   SAT_STAMP(3);
-  if constexpr (LEAN) {
-    mfma_phase();
-    if (p.poly_planes) {
-      polyphase_planes_epilogue<MT, NT>(p, acc, (float*)lds4, b, co_w, q_b, wave, l31, lh);
-      return;
-    }
-    conv_epilogue<MT, NT, false, false>(p, acc, b, 0, co_w, q_w, l31, lh);
-    return;
-  }
   float rpre[MT][NT][16];
   if (p.res || p.res16) epilogue_prefetch_res<MT, NT>(p, rpre, b, 0, co_w, q_w, l31, lh);
   __builtin_amdgcn_sched_barrier(0);
@@ -697,12 +684,6 @@ static int launch_f16x3(const ConvArgs& a, int B, int groups, hipStream_t s) {
       if (!p.f8 && (p.cin_pad / CI_CHUNK) % 2 == 0) {
         kern = conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 2>;
         lds_bytes *= 2;
-      }
-    }
-    if constexpr ((KS == 3 || KS == 7) && MT == 2 && NT == 2) {
-      if (!p.f8 && (KS == 3 ? g_lean3 : g_lean7) && !p.ch_scale && p.fast_epi) {   // three blocks per CU (32 / 48 KB of LDS each); its epilogue carries no folded BatchNorm
-        kern = conv1d_f16x3_planes_kernel<MT, NT, KS, XWI, false, 1, true>;
-        lds_bytes = ((size_t)4 * 64 * XWI + (size_t)KS * 4 * CO_B) * 16;
       }
     }
     if constexpr (KS == 1 || KS == 2) {
@@ -1726,6 +1707,9 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     if (a.x16 && a.ksize == 3 && !a.f8 && !a.poly_planes && a.rows_g > 32 && a.T_q > 128 &&
         (long long)ceil_div(a.rows_g, 64) * ceil_div(a.T_q, 256) * d->B * d->groups < 256)
       return launch_f16x3<2, 1, 3>(a, d->B, d->groups, s);
+    // the generator's resblock convs: the three-blocks-per-CU form of the tile (conv_lean.hip)
+    if (d->groups == 1 && (a.ksize == 3 ? g_lean3 : a.ksize == 7 ? g_lean7 : g_lean11) && lean_supports(a))
+      return launch_f16x3_lean(a, d->B, s);
     if (a.rows_g > 32) return launch_f16x3_ks<2, 2>(a, d->B, d->groups, s);   // 64 rows x 256 positions
     return launch_f16x3_ks<1, 4>(a, d->B, d->groups, s);                       // 32 rows x 512 positions
   }
@@ -1826,6 +1810,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   SAT_REQUIRE(name, "conv_set_option: null name");
   if (!strcmp(name, "lean3")) { g_lean3 = value != 0; return SAT_OK; }
   if (!strcmp(name, "lean7")) { g_lean7 = value != 0; return SAT_OK; }
+  if (!strcmp(name, "lean11")) { g_lean11 = value != 0; return SAT_OK; }
   if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }
   set_error("conv_set_option: unknown option '%s'", name);
   return SAT_ERR_INVALID;

@@ -542,6 +542,9 @@ inline bool epilogue16_supports(const ConvArgs& a) {
 
 // 1x1 convolution on split planes through the LDS-DMA ring GEMM (gemm_ring.hip)
 int launch_f16x3_ring(const ConvArgs& a, int B, hipStream_t s);
+// three-blocks-per-CU form of the 3 / 7 / 11-tap conv tile on split planes (conv_lean.hip)
+int launch_f16x3_lean(const ConvArgs& a, int B, hipStream_t s);
+bool lean_supports(const ConvArgs& a);
 int launch_f16x3_ring16(const ConvArgs& a, int B, hipStream_t s);   // the same ring on v_mfma_f32_16x16x32_f16
 bool ring16_supports(const ConvArgs& a);
 

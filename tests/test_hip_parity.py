@@ -822,9 +822,9 @@ def test_stride2_three_tap_conv_as_one_wrapped_product(C, T):
         ops.conv1d(phd, w96, 96, 1, bias=b[:96].to(DEV), t_out=Tq, mode=1, x_split=xs, x_wrap_channels=2 * C, c_in=3 * C)
 
 
-@pytest.mark.parametrize("C,T,dil,k", [(64, 700, 1, 3), (128, 513, 5, 3), (256, 250, 3, 3), (64, 700, 5, 7), (256, 250, 1, 7)], ids=lambda v: str(v))
+@pytest.mark.parametrize("C,T,dil,k", [(64, 700, 1, 3), (128, 513, 5, 3), (256, 250, 3, 3), (64, 700, 5, 7), (256, 250, 1, 7), (64, 700, 5, 11), (256, 250, 1, 11), (128, 513, 3, 11)], ids=lambda v: str(v))
 def test_three_blocks_per_cu_form_of_the_conv_tile_gives_the_same_bits(C, T, dil, k):
-    """sat_conv_set_option("lean3" / "lean7"): the 3- and 7-tap convs on split planes through the two-block form
+    """sat_conv_set_option("lean3" / "lean7" / "lean11"): the 3-, 7- and 11-tap convs on split planes through the two-block form
     (double-buffered fragments, residual prefetch) and through the three-blocks-per-CU form (the default): same
     accumulation order, same epilogue arithmetic — same bits, with the generator's conv2 epilogue (residual from
     planes, MRF accumulate / 3, f32 + planes out)"""
