@@ -17,7 +17,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ------------------------------------------------------------------------------------------------
 // conv1d_f16x3_planes_kernel (conv1d_mfma.hip) holds 235 VGPRs — two fragment sets and 64 residual-prefetch registers —
 // and up to 65 KB of LDS: two blocks per CU, and its launches wait on memory 14-35 % of their cycles.  This form trades
-// the deeper per-wave pipelining for a third co-resident block: fragments single-buffered, the residual loaded in the
+// the deeper per-wave pipelining for a third co-resident block: one flowing fragment set, the residual loaded in the
 // epilogue, the folded-BatchNorm step compiled out (<= 168 VGPRs), and for 11 taps the weights of a chunk pass through
 // LDS in two tap groups (6 + 5: 24 KB instead of 45), so that a block needs 33 / 49 / 45 KB of LDS at 3 / 7 / 11 taps.
 // Same tile (64 rows x 256 positions, four waves of 64 x 64), same LDS images, same order of operations per
@@ -85,30 +85,52 @@ __global__ void __launch_bounds__(256, 3) conv1d_f16x3_planes_lean_kernel(const 
   };
   const uint4* xb0 = ldsx + lh * XWP + wave * (32 * NT) + l31;
   const uint4* wb0 = ldsw + lh * CO_B + l31;
+  // Fragments FLOW through one register set + one spare A pair (gemm_f16x3_ring16_kernel): the next tap's A pair of
+  // row m is read once row m - 1 has been multiplied, its B pair of column n once the last row has used column n, so
+  // no tap but a group's first starts on an LDS round trip — at 40 fragment registers instead of 64 for two full sets.
+  auto read_a = [&](h8 (&dst)[2], int tl, int m) __attribute__((always_inline)) {
+    dst[0] = __builtin_bit_cast(h8, wb0[(tl * 4 + 0) * CO_B + m * 32]);
+    dst[1] = __builtin_bit_cast(h8, wb0[(tl * 4 + 2) * CO_B + m * 32]);
+  };
+  auto read_b = [&](h8 (&dst)[2], int t, int n) __attribute__((always_inline)) {
+    const uint4* xt = xb0 + t * p.dil + n * 32;
+    dst[0] = __builtin_bit_cast(h8, xt[0]);
+    dst[1] = __builtin_bit_cast(h8, xt[2 * XWP]);
+  };
   auto mfma_group = [&](auto gc) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value, t0 = g * TG, nt = (KS - t0 < TG) ? KS - t0 : TG;
+    h8 fa[MT][2], fb[NT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) read_a(fa[m], 0, m);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) read_b(fb[n], t0, n);
 #pragma unroll
     for (int tl = 0; tl < nt; ++tl) {
-      h8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
+      h8 an[MT][2], bn[NT][2];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        a_hi[m] = __builtin_bit_cast(h8, wb0[(tl * 4 + 0) * CO_B + m * 32]);
-        a_lo[m] = __builtin_bit_cast(h8, wb0[(tl * 4 + 2) * CO_B + m * 32]);
-      }
-      const uint4* xt = xb0 + (t0 + tl) * p.dil;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        b_hi[n] = __builtin_bit_cast(h8, xt[n * 32]);
-        b_lo[n] = __builtin_bit_cast(h8, xt[2 * XWP + n * 32]);
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tl + 1 < nt) read_a(an[m], tl + 1, m);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[m], b_hi[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[m], b_lo[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[m], b_hi[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m][1], fb[n][0], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m][0], fb[n][1], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m][0], fb[n][0], acc[m][n], 0, 0, 0);
+          if (m == MT - 1 && tl + 1 < nt) {
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(bn[n], t0 + tl + 1, n);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tl + 1 < nt) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) fa[m][0] = an[m][0], fa[m][1] = an[m][1];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) fb[n][0] = bn[n][0], fb[n][1] = bn[n][1];
+      }
     }
   };
 
