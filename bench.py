@@ -283,7 +283,7 @@ def roofline_generator(model, dev, reps):
                                  y_split=ys, y_split_slope=0.1, res_split=rs, res_split_slope=0.1, no_y=True, out=xk)
         us = time_events(run, 20, warm=3) * 1e3
         flop = 2.0 * BATCH * C * C * k * T
-        dom = {"name": "conv1d_f16x3_planes_kernel, 11 taps, C=256, T=1250, dilation 5, batch 32 (18 launches per forward)",
+        dom = {"name": "conv1d_f16x3_planes_lean_kernel<11, 6> (split-f16 conv tile, three blocks per CU), 11 taps, C=256, T=1250, dilation 5, batch 32 (18 launches per forward)",
                "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
                "frac": round(flop / us / 1e6 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)}
     achieved = GEN_FLOP_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
