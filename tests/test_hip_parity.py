@@ -647,6 +647,25 @@ def test_converts_in_flight_on_separate_streams_equal_serial(model):
             assert torch.equal(outs[j], serial[j]), (rnd, j)
 
 
+def test_full_size_converts_in_flight_are_deterministic(model):
+    """BASELINE's batch (32 x 5 s) in the benchmark's mode: twenty convert() calls round-robin on four HIP streams, every
+    output bit-identical to the serial result (a race between jobs on shared state would show up as a differing batch)"""
+    from satools_amd import synthetic
+    seeds = list(range(32))
+    wav = synthetic.harm_batch(seeds).to(DEV)
+    targets = synthetic.targets(model.spk, seeds)
+    ref = model.convert(wav, target=targets).clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(4)]
+    outs = []
+    for j in range(20):
+        with torch.cuda.stream(streams[j % 4]):
+            outs.append(model.convert(wav, target=targets))
+    torch.cuda.synchronize()
+    bad = [j for j, o in enumerate(outs) if not torch.equal(o, ref)]
+    assert not bad, bad
+
+
 def test_weight_caches_follow_in_place_updates():
     """the packed-weight caches are keyed on (data_ptr, _version) of parameters and buffers looked up through a
     module walk done once: an in-place update of a parameter or of a BatchNorm buffer (which `.to()` had replaced

@@ -329,6 +329,25 @@ def test_converts_in_flight_on_separate_streams_equal_serial(model):
             assert torch.equal(outs[j], serial[j]), (rnd, j)
 
 
+def test_full_size_converts_in_flight_are_deterministic(model):
+    """BASELINE's batch (32 x 5 s) in the benchmark's mode: twenty convert() calls round-robin on four HIP streams, every
+    output bit-identical to the serial result (a race between jobs on shared state would show up as a differing batch)"""
+    from satools_amd import synthetic
+    seeds = list(range(32))
+    wav = synthetic.harm_batch(seeds).to(DEV)
+    targets = synthetic.targets(model.spk, seeds)
+    ref = model.convert(wav, target=targets).clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(4)]
+    outs = []
+    for j in range(20):
+        with torch.cuda.stream(streams[j % 4]):
+            outs.append(model.convert(wav, target=targets))
+    torch.cuda.synchronize()
+    bad = [j for j, o in enumerate(outs) if not torch.equal(o, ref)]
+    assert not bad, bad
+
+
 def test_convert_w2v2_tag_quant_awgn_matches_fixture(gold):
     """BASELINE configs[3]: wav2vec2 tag + f0-transformation=quant_16_awgn_2, F0 computed on the path, against the
     reference's own `convert` run under torch.manual_seed(1234)"""
