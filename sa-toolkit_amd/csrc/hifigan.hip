@@ -132,6 +132,7 @@ struct sat_hifigan {
   };
   std::vector<Conv> convs;
   int fuse_pairs = 1;
+  int fuse_pair64 = 1;       // the 3-tap ResBlock steps of the C = 64 stage as one launch each (resblock_pair64_k3_kernel)
   int split_acts = 1;
   int planes_residual = 1;
   int n_ups() const { return (int)up_rates.size(); }
@@ -248,6 +249,7 @@ static int hifigan_get_side(sat_hifigan* h, void* stream, hifigan_side** out) {
 extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int value) {
   SAT_REQUIRE(h && name, "hifigan_set_option: null pointer");
   if (std::string(name) == "fuse_pairs") { h->fuse_pairs = value; return SAT_OK; }
+  if (std::string(name) == "fuse_pair64") { h->fuse_pair64 = value; return SAT_OK; }
   if (std::string(name) == "split_acts") { h->split_acts = value; return SAT_OK; }
   if (std::string(name) == "planes_residual") { h->planes_residual = value; return SAT_OK; }
   if (std::string(name) == "branch_streams") { h->branch_streams = value; return SAT_OK; }
@@ -433,7 +435,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             if (fan && pair == 2 && j > 0) SAT_HIP(hipStreamWaitEvent((hipStream_t)stream_j, side->acc[j - 1], 0));
             return SAT_OK;
           };
-          if (Cn <= 32 && h->fuse_pairs && cmode == SAT_CONV_F16X3) {
+          if ((Cn <= 32 || (Cn == 64 && rk == 3 && planes_res && h->fuse_pair64)) && h->fuse_pairs && cmode == SAT_CONV_F16X3) {
             sat_conv1d_desc df = d2;
             df.dilation = dil;
             df.x_split = rs;

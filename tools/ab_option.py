@@ -1,5 +1,5 @@
-"""A/B of a sat_conv_set_option switch on the generator forward (batch 32 x 250 frames), interleaved rounds in one
-process: python tools/ab_option.py <option> <value_a> <value_b>"""
+"""A/B of a sat_conv_set_option switch (or, with the prefix `gen:`, a sat_hifigan_set_option switch) on the generator forward
+(batch 32 x 250 frames), interleaved rounds in one process: python tools/ab_option.py <option> <value_a> <value_b>"""
 import os
 import sys
 import torch
@@ -8,10 +8,20 @@ import satools_amd
 from satools_amd import _lib
 
 name, va, vb = sys.argv[1].encode(), int(sys.argv[2]), int(sys.argv[3])
+GEN = name.startswith(b"gen:")
+name = name[4:] if GEN else name
 model = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1")
 model.to("cuda")
 g = model.hifigan
 x = torch.randn(32, g.imput_dim, 250, device="cuda")
+
+
+def setopt(v):
+    if GEN:
+        g(x[:1])                             # (the handle exists after the first forward)
+        _lib.check(_lib.lib().sat_hifigan_set_option(g._handle, name, v), "set_option")
+    else:
+        _lib.check(_lib.lib().sat_conv_set_option(name, v), "set_option")
 
 
 def run(n):
@@ -26,11 +36,11 @@ def run(n):
 
 res, outs = {va: [], vb: []}, {}
 for v in (va, vb):
-    _lib.check(_lib.lib().sat_conv_set_option(name, v), "set_option")
+    setopt(v)
     run(3)
 for rnd in range(5):
     for v in (va, vb):
-        _lib.check(_lib.lib().sat_conv_set_option(name, v), "set_option")
+        setopt(v)
         t, outs[v] = run(8)
         res[v].append(t)
 for v in (va, vb):
