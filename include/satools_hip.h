@@ -140,8 +140,8 @@ typedef struct {
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
                    void* stream);
-/* One fused ResBlock1 step of the thin generator stages (C = 16 or 32; C = 64 with 3 taps and split planes end to end:
- * x_split in, res_split == x_split), split-f16 arithmetic:
+/* One fused ResBlock1 step of the thin generator stages (C = 16 or 32; C = 64 with split planes end to end: x_split in,
+ * res_split == x_split), split-f16 arithmetic:
  *   y = conv2(lrelu(conv1(lrelu(x)) + bias1)) + d->bias + x      (hifigan/nn.py:179-186)
  * conv1 = (ksize, d->dilation), conv2 = (ksize, 1), both 'same' padded, slope d->in_slope; the
  * intermediate never leaves LDS.  d->res must be x (or d->res_split == d->x_split); d->accum /

@@ -1732,7 +1732,7 @@ extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x,
   SAT_REQUIRE(d && w1_packed && w2_packed && bias1 && d->bias && (x || d->x_split) && (y || (d->no_y && d->y_split)),
               "resblock_pair: null pointer");
   SAT_REQUIRE(d->C_in == d->C_out && d->C_in % 16 == 0 &&
-                  (d->C_in <= 32 || (d->C_in == 64 && d->ksize == 3 && d->x_split && d->res_split)),
+                  (d->C_in <= 32 || (d->C_in == 64 && d->x_split && d->res_split)),
               "resblock_pair: C must be 16 or 32 (64 with 3 taps and split planes end to end)");
   SAT_REQUIRE(d->groups == 1 && d->up == 1 && d->stride == 1 && d->T_q == d->T_in, "resblock_pair: same-length conv pair only");
   SAT_REQUIRE(d->ksize == 3 || d->ksize == 7 || d->ksize == 11, "resblock_pair: kernel size %d not instantiated", d->ksize);
@@ -1785,8 +1785,8 @@ extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x,
     }
   }
   if (a.cin_g == 64) {
-    SAT_REQUIRE(pair64_supports(a), "resblock_pair(C = 64): 3 taps, split planes in, residual from planes, dilation <= 32");
-    return launch_pair64_k3(a, d->B, s);
+    SAT_REQUIRE(pair64_supports(a), "resblock_pair(C = 64): split planes in, residual from planes, (ksize - 1) * dilation <= 64");
+    return launch_pair64(a, d->B, s);
   }
   if (a.cin_g == 32 && a.x16 && a.res16) {
     switch (a.ksize) {

@@ -543,7 +543,7 @@ inline bool epilogue16_supports(const ConvArgs& a) {
 // 1x1 convolution on split planes through the LDS-DMA ring GEMM (gemm_ring.hip)
 int launch_f16x3_ring(const ConvArgs& a, int B, hipStream_t s);
 // fused ResBlock1 step for C = 64, 3 taps (pair64.hip)
-int launch_pair64_k3(const ConvArgs& a, int B, hipStream_t s);
+int launch_pair64(const ConvArgs& a, int B, hipStream_t s);
 bool pair64_supports(const ConvArgs& a);
 // three-blocks-per-CU form of the 3 / 7 / 11-tap conv tile on split planes (conv_lean.hip)
 int launch_f16x3_lean(const ConvArgs& a, int B, hipStream_t s);

@@ -132,7 +132,8 @@ struct sat_hifigan {
   };
   std::vector<Conv> convs;
   int fuse_pairs = 1;
-  int fuse_pair64 = 1;       // the 3-tap ResBlock steps of the C = 64 stage as one launch each (resblock_pair64_k3_kernel)
+  int fuse_pair64 = 3;       // bit mask: the 3- (1) / 7- (2) / 11-tap (4) ResBlock steps of the C = 64 stage as one launch each (pair64.hip);
+                             // 11 taps measured slower fused (its recomputed halo and short blocks cost more than the traffic saved)
   int split_acts = 1;
   int planes_residual = 1;
   int n_ups() const { return (int)up_rates.size(); }
@@ -435,7 +436,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             if (fan && pair == 2 && j > 0) SAT_HIP(hipStreamWaitEvent((hipStream_t)stream_j, side->acc[j - 1], 0));
             return SAT_OK;
           };
-          if ((Cn <= 32 || (Cn == 64 && rk == 3 && planes_res && h->fuse_pair64)) && h->fuse_pairs && cmode == SAT_CONV_F16X3) {
+          if ((Cn <= 32 || (Cn == 64 && planes_res && (h->fuse_pair64 & (rk == 3 ? 1 : rk == 7 ? 2 : 4)))) && h->fuse_pairs && cmode == SAT_CONV_F16X3) {
             sat_conv1d_desc df = d2;
             df.dilation = dil;
             df.x_split = rs;

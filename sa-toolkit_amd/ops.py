@@ -269,7 +269,7 @@ def unsplit(s):
 
 def resblock_pair(x, w1, b1, w2, b2, ksize, dilation, slope=0.1, out=None, accum=False, accum_div=0.0,
                   x_split=None, y_split=None, y_split_slope=1.0, planes_residual=False, no_y=False):
-    """fused ResBlock1 step (C = 16 / 32; C = 64 with 3 taps, x_split and planes_residual; split-f16):
+    """fused ResBlock1 step (C = 16 / 32; C = 64 with x_split and planes_residual; split-f16):
     out = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x"""
     x = _f32c(x)
     B, c, t = x.shape

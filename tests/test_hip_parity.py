@@ -870,14 +870,15 @@ def test_three_blocks_per_cu_form_of_the_conv_tile_gives_the_same_bits(C, T, dil
     assert (out[1][0].cpu().double() - ref).abs().max().item() < 3e-5
 
 
-@pytest.mark.parametrize("T,dil", [(700, 1), (1000, 3), (126, 5), (127, 1), (379, 5)], ids=lambda v: str(v))
-def test_fused_resblock_step_c64_equals_the_two_launch_path(T, dil):
-    """resblock_pair64_k3_kernel (C = 64, 3 taps, planes end to end: the generator's third stage) against the two conv
+@pytest.mark.parametrize("T,dil,k", [(700, 1, 3), (1000, 3, 3), (126, 5, 3), (127, 1, 3), (379, 5, 3), (700, 1, 7), (122, 5, 7), (123, 3, 7),
+                                     (1000, 5, 11), (118, 1, 11), (119, 3, 11)], ids=lambda v: str(v))
+def test_fused_resblock_step_c64_equals_the_two_launch_path(T, dil, k):
+    """resblock_pair64_kernel (C = 64, 3 / 7 / 11 taps, planes end to end: the generator's third stage) against the two conv
     launches it replaces — conv1 (dilation d) writing split(lrelu(t1)) planes, conv2 (dilation 1) adding the residual
     rebuilt from the input planes — bit for bit, planes-only and with the MRF accumulation into an f32 tensor; tile
-    edges (126 output positions per block), utterance edges and every dilation of the generator"""
+    edges (128 - (k - 1) output positions per block), utterance edges and every dilation of the generator"""
     ops, packing = _ops()
-    C, k, B = 64, 3, 2
+    C, B = 64, 2
     x = _rand(B, C, T, seed=1).to(DEV)
     pk = packing.pack_conv_weight_f16x3
     w1, w2 = pk(_rand(C, C, k, seed=2, scale=0.6 / np.sqrt(C * k)).to(DEV)), pk(_rand(C, C, k, seed=3, scale=0.6 / np.sqrt(C * k)).to(DEV))
@@ -887,12 +888,12 @@ def test_fused_resblock_step_c64_equals_the_two_launch_path(T, dil):
 
     def two_launches(accum):
         t1s, ys = ops.split_like(B, C, T, DEV), ops.split_like(B, C, T, DEV)
-        ops.conv1d(x, w1, C, k, bias=b1, dilation=dil, pad_left=dil, mode=1, x_split=xs, y_split=t1s, y_split_slope=0.1, no_y=True)
+        ops.conv1d(x, w1, C, k, bias=b1, dilation=dil, pad_left=dil * (k - 1) // 2, mode=1, x_split=xs, y_split=t1s, y_split_slope=0.1, no_y=True)
         if accum:
-            y = ops.conv1d(x, w2, C, k, bias=b2, pad_left=1, mode=1, x_split=t1s, res_split=xs, res_split_slope=0.1,
+            y = ops.conv1d(x, w2, C, k, bias=b2, pad_left=(k - 1) // 2, mode=1, x_split=t1s, res_split=xs, res_split_slope=0.1,
                            y_split=ys, y_split_slope=0.1, out=acc0.clone(), accum=True, accum_div=3.0)
             return y, ys
-        ops.conv1d(x, w2, C, k, bias=b2, pad_left=1, mode=1, x_split=t1s, res_split=xs, res_split_slope=0.1,
+        ops.conv1d(x, w2, C, k, bias=b2, pad_left=(k - 1) // 2, mode=1, x_split=t1s, res_split=xs, res_split_slope=0.1,
                    y_split=ys, y_split_slope=0.1, no_y=True)
         return None, ys
 
@@ -915,7 +916,7 @@ def test_fused_resblock_step_c64_equals_the_two_launch_path(T, dil):
             assert torch.equal(ya, yb)
     # and against torch in float64 (the planes residual carries 22 bits of x)
     ref = F.conv1d(F.leaky_relu(F.conv1d(F.leaky_relu(x.double().cpu(), 0.1), _rand(C, C, k, seed=2, scale=0.6 / np.sqrt(C * k)).double(),
-                                         b1.double().cpu(), dilation=dil, padding=dil), 0.1),
-                   _rand(C, C, k, seed=3, scale=0.6 / np.sqrt(C * k)).double(), b2.double().cpu(), padding=1) + x.double().cpu()
+                                         b1.double().cpu(), dilation=dil, padding=dil * (k - 1) // 2), 0.1),
+                   _rand(C, C, k, seed=3, scale=0.6 / np.sqrt(C * k)).double(), b2.double().cpu(), padding=(k - 1) // 2) + x.double().cpu()
     y, _ = fused(True)
     assert (y.cpu().double() - (acc0.double().cpu() + ref) / 3).abs().max().item() < 1e-5
