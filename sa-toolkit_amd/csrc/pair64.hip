@@ -53,31 +53,40 @@ __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs 
   const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)p.w_gs, 0x00020000);
   const int seg_bytes = p.co_pad * 16;
 
-  uint4 xst[XWI], wst[W_IT];
-  auto issue_x = [&](int chunk) __attribute__((always_inline)) {
+  // Two staging register sets: the loads of stage s + 2 are issued while stage s is multiplied, so that a stage's loads
+  // have two stage times to land (a stage is short here: 36-48 MFMAs per wave); the barriers wait for LDS only
+  // (`s_waitcnt lgkmcnt(0)` + `s_barrier`: __syncthreads() would drain the loads in flight), the compiler counts vmcnt
+  // down to the set a publish reads.
+  // Stage s of 2 * NCH * G: conv s / (NCH G), chunk (s / G) % NCH, tap group s % G.
+  constexpr int NS = 2 * NCH * G;
+  uint4 xst[2][XWI], wst[2][W_IT];
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto issue = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int st = decltype(sc)::value, set = st & 1, conv = st / (NCH * G), ch = (st / G) % NCH, g = st % G;
+    constexpr int tg0 = g * TG, nt = (KS - tg0 < TG) ? KS - tg0 : TG;
+    if constexpr (conv == 0 && g == 0) {
 #pragma unroll
-    for (int it = 0; it < XWI; ++it) {
-      const int xi = xi0 + lane + 64 * it;
-      const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((wave * p.T_in + xi) * 16) : 0x80000000u;
-      xst[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, chunk * 4 * p.T_in * 16, 0));
+      for (int it = 0; it < XWI; ++it) {
+        const int xi = xi0 + lane + 64 * it;
+        const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((wave * p.T_in + xi) * 16) : 0x80000000u;
+        xst[set][it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, ch * 4 * p.T_in * 16, 0));
+      }
     }
-  };
-  // wave w copies segment w (part * 2 + half) of every tap of the group
-  auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rs, int chunk, auto gc) __attribute__((always_inline)) {
-    constexpr int g = decltype(gc)::value, tg0 = g * TG, nt = (KS - tg0 < TG) ? KS - tg0 : TG;
+    // wave w copies segment w (part * 2 + half) of every tap of the group
 #pragma unroll
     for (int i = 0; i < nt; ++i)
-      wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + wave * seg_bytes,
-                                                                                ((chunk * KS + tg0 + i) * 4) * seg_bytes, 0));
+      wst[set][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(conv ? w2rs : w1rs, lane * 16 + wave * seg_bytes,
+                                                                                     ((ch * KS + tg0 + i) * 4) * seg_bytes, 0));
   };
-  auto publish_x = [&]() __attribute__((always_inline)) {
+  auto publish = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int st = decltype(sc)::value, set = st & 1, conv = st / (NCH * G), g = st % G;
+    constexpr int tg0 = g * TG, nt = (KS - tg0 < TG) ? KS - tg0 : TG;
+    if constexpr (conv == 0 && g == 0) {
 #pragma unroll
-    for (int it = 0; it < XWI; ++it) ldsx[wave * XWP + lane + 64 * it] = xst[it];
-  };
-  auto publish_w = [&](auto gc) __attribute__((always_inline)) {
-    constexpr int g = decltype(gc)::value, tg0 = g * TG, nt = (KS - tg0 < TG) ? KS - tg0 : TG;
+      for (int it = 0; it < XWI; ++it) ldsx[wave * XWP + lane + 64 * it] = xst[set][it];
+    }
 #pragma unroll
-    for (int i = 0; i < nt; ++i) ldsw[(i * 4 + wave) * 64 + lane] = wst[i];
+    for (int i = 0; i < nt; ++i) ldsw[(i * 4 + wave) * 64 + lane] = wst[set][i];
   };
   f32x16 acc[2][1];
   auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -105,38 +114,8 @@ __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs 
       }
     }
   };
-
-  using G0 = std::integral_constant<int, 0>;
-  // ---- conv1: four chunks of the input through LDS ----
-  zero_acc();
-  issue_x(0);
-  issue_w(w1rs, 0, G0{});
-  const uint4* xbase = ldsx + lh * XWP + wave * 32 + l31;
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    p64_static_for<G>([&](auto gc) __attribute__((always_inline)) {
-      constexpr int g = decltype(gc)::value;
-      __syncthreads();                      // every wave is done reading the previous stage's tiles
-      if constexpr (g == 0) publish_x();
-      publish_w(gc);
-      __syncthreads();
-      if constexpr (g + 1 < G) {
-        issue_w(w1rs, ch, std::integral_constant<int, g + 1>{});
-      } else {
-        if (ch + 1 < NCH) {
-          issue_x(ch + 1);
-          issue_w(w1rs, ch + 1, G0{});
-        } else {
-          issue_w(w2rs, 0, G0{});
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_group(xbase, XWP, p.dil, gc);
-    });
-  }
-  __syncthreads();                          // every wave is done reading the input chunk: t1 goes over it
-  // ---- t1 = lrelu(conv1 + b1) -> LDS as conv2's B operand (hi | lo planes of the four chunks), zero outside the utterance ----
-  {
+  // t1 = lrelu(conv1 + b1) -> LDS as conv2's B operand (hi | lo planes of the four chunks), zero outside the utterance
+  auto write_t1 = [&]() __attribute__((always_inline)) {
     const int col = wave * 32 + l31;
     const int pos = t0 - H2 + col;
     const bool inside = pos >= 0 && pos < p.T_in;
@@ -162,25 +141,27 @@ __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs 
         ((uint2*)(ldst + ((chunk * 4 + 2 + (rg & 1)) * W1 + col)))[lh] =
             make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
       }
-  }
-  // ---- conv2: t1 from LDS, four chunks of weights ----
+  };
+
   zero_acc();
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    p64_static_for<G>([&](auto gc) __attribute__((always_inline)) {
-      constexpr int g = decltype(gc)::value;
-      __syncthreads();                      // t1 complete (first pass) / the previous weight group is no longer read
-      publish_w(gc);
-      __syncthreads();
-      if constexpr (g + 1 < G) {
-        issue_w(w2rs, ch, std::integral_constant<int, g + 1>{});
-      } else {
-        if (ch + 1 < NCH) issue_w(w2rs, ch + 1, G0{});
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_group(ldst + (ch * 4 + lh) * W1 + wave * 32 + l31, W1, 1, gc);
-    });
-  }
+  issue(std::integral_constant<int, 0>{});
+  issue(std::integral_constant<int, 1>{});
+  const uint4* xbase = ldsx + lh * XWP + wave * 32 + l31;
+  p64_static_for<NS>([&](auto sc) __attribute__((always_inline)) {
+    constexpr int st = decltype(sc)::value, conv = st / (NCH * G), ch = (st / G) % NCH, g = st % G;
+    lds_barrier();                          // every wave is done reading the previous stage's tiles (first conv2 stage: t1 complete)
+    publish(sc);
+    lds_barrier();
+    if constexpr (st + 2 < NS) issue(std::integral_constant<int, st + 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (conv == 0) mfma_group(xbase, XWP, p.dil, std::integral_constant<int, g>{});
+    else mfma_group(ldst + (ch * 4 + lh) * W1 + wave * 32 + l31, W1, 1, std::integral_constant<int, g>{});
+    if constexpr (st == NCH * G - 1) {      // conv1 done
+      lds_barrier();                        // every wave is done reading the input chunk: t1 goes over it
+      write_t1();
+      zero_acc();
+    }
+  });
   // residual = the block input (from its planes), bias, MRF accumulate, f32 and / or planes out; the last KS - 1 columns dropped
   conv_epilogue<2, 1, false, false>(p, acc, b, 0, 0, t0 + wave * 32, l31, lh, 32, t0 + TO);
 }
