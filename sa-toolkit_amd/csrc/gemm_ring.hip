@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring_kernel(const ConvArgs 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a[j] ? wrs : xrs, (__attribute__((address_space(3))) void*)(uintptr_t)(dst + lunit[j]), 16,
                                                voff[j], ch * sstep[j], 0, 0);
 #else
-    (void)dst;
+    (void)dst; (void)xrs; (void)wrs;
 #endif
   };
   h8 fa[2][MT][2], fb[2][NT][2];          // fragments of the chunk being multiplied and of the next one
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
                                                  wrapped ? voff1[j] : voff[j], (is_a[j] ? ch : ch_b) * sstep[j], 0, 0);
     }
 #else
-    (void)st; (void)sb;
+    (void)st; (void)sb; (void)xrs; (void)wrs; (void)nwrap;
 #endif
   };
   // B fragments of the step being multiplied and of the next one; A fragments flow: row m's pair is dead after row
