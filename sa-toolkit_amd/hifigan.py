@@ -26,6 +26,10 @@ class CoreHifiGan(CoreHifiGanParams):
     #: single convert() in flight, a loss once two are (bench --jobs 2), so off by default
     branch_streams = int(os.environ.get("SATOOLS_AMD_GEN_BRANCH_STREAMS", "0"))
 
+    #: bit mask of the ResBlock steps of the C = 64 stage that run as ONE launch (csrc/pair64.hip): 1 = 3 taps, 2 = 7 taps,
+    #: 4 = 11 taps (measured slower fused)
+    fuse_pair64 = int(os.environ.get("SATOOLS_AMD_GEN_FUSE_PAIR64", "3"))
+
     #: per-stream workspaces kept (3.3 GB each at 32 x 5 s); beyond it the least recently used one is dropped
     max_workspaces = int(os.environ.get("SATOOLS_AMD_GEN_MAX_WORKSPACES", "16"))
 
@@ -43,7 +47,7 @@ class CoreHifiGan(CoreHifiGanParams):
         ps = self.__dict__.get("_flat_params")
         if ps is None:
             ps = self.__dict__["_flat_params"] = list(self.parameters())
-        return (self.precision, self.split_acts, self.branch_streams) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def invalidate(self):
         self._packed_key = None
@@ -103,6 +107,7 @@ class CoreHifiGan(CoreHifiGanParams):
             check(l.sat_hifigan_set_conv(self._handle, i, ptr(wp), ptr(b), mode), "sat_hifigan_set_conv")
         check(l.sat_hifigan_set_option(self._handle, b"split_acts", int(self.split_acts)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"branch_streams", int(self.branch_streams)), "sat_hifigan_set_option")
+        check(l.sat_hifigan_set_option(self._handle, b"fuse_pair64", int(self.fuse_pair64)), "sat_hifigan_set_option")
         self._packed = packed  # keeps the device buffers alive
         self._packed_key = key
         _lib.cache_rebuild_end(device)
