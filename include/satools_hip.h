@@ -48,6 +48,11 @@ int sat_device_info(char* name, int name_len, int* cu_count);
 /* diagnostic (tools/clock_probe.py): one wave records n pairs (shader cycle counter, 100 MHz wall counter) every
  * period_us into samples[2 n] while the caller runs other work on other streams: the clock the chip holds under it */
 int sat_clock_probe(int64_t* samples, int n, int period_us, void* stream);
+/* diagnostic (tools/stamp_mrf.py): with a device buffer set, block 0 of every sat_resblock_mrf_f16x3 launch records the
+ * shader cycle counter of its 8 waves at 4 points of each conv phase (start, operands read, matrix + epilogue work done,
+ * next weights committed, after the barrier) for its first 4 tiles: buf[tile][80 stamps][8 waves].  NULL switches it
+ * off.  Returns the number of int64 entries the buffer must hold.  Not thread-safe; never set on the product path. */
+int sat_mrf_debug_stamps(int64_t* buf);
 
 /* ------------------------------------------------------------------------------------------
  * Fused 1-D convolution as an implicit GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32;
@@ -149,6 +154,36 @@ int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packe
  * Weights: SAT_CONV_F16X3 packing. */
 int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
                             const float* bias1, const void* w2_packed, float* y, void* stream);
+/* A whole multi-receptive-field block of a thin generator stage in ONE launch (csrc/mrf.hip): n_branches ResBlock1
+ * branches (hifigan/nn.py:93-187; three steps x = x + conv2(lrelu(conv1(lrelu(x)))) each, conv1 dilated 1 / 3 / 5)
+ * on the same input, summed in branch order and divided by out_div (hifigan/archi.py:82-86: xs / num_kernels):
+ *   y = ((rb_0(x) + rb_1(x)) + rb_2(x)) / out_div          (out_div == 0: no division)
+ * The tile, the running x of a branch, the intermediates and the sum never leave the CU; arithmetic and rounding are
+ * those of sat_resblock_pair_f16x3 with split planes end to end (x_split in, residual from planes), so the result is
+ * bit-identical to that sequence of launches.  Supported (sat_resblock_mrf_supported): C = 16, kernel sizes (3, 7, 11)
+ * with n_branches = 3 or any one of them with n_branches = 1, dilations (1, 3, 5).  Weights: SAT_CONV_F16X3 packing. */
+typedef struct {
+  int32_t B, C, T;
+  int32_t n_branches;
+  int32_t ksize[3];
+  int32_t dilation[3][3];
+  const void* w[3][3][2];        /* [branch][step][conv1 | conv2] packed weights */
+  const float* bias[3][3][2];
+  float slope;                   /* leaky-relu slope of every conv input (and of x_split) */
+  const void* x_split;           /* input: SAT_SPLIT_F16 planes of lrelu(x, slope) */
+  float* y;                      /* f32 output [B][C][T], or NULL */
+  void* y_split;                 /* output as planes of lrelu(y, y_split_slope), or NULL */
+  float y_split_slope;
+  float out_div;
+  void* scratch;                 /* device scratch of sat_resblock_mrf_scratch_bytes(): the launch gathers the block's weights
+                                    and biases into it first (caller-owned, one per stream in flight) */
+  size_t scratch_bytes;
+  int32_t residual_from_planes;  /* 1: the residual of steps 2 and 3 is rebuilt from the 22-bit split of the step before, as the
+                                    launch-by-launch path does (bit-identical to it); 0: it stays in f32 registers */
+} sat_mrf_desc;
+int sat_resblock_mrf_supported(int C, int n_branches, const int* ksize, const int* dilations /* [n_branches][3] */);
+size_t sat_resblock_mrf_scratch_bytes(int n_branches, const int* ksize);
+int sat_resblock_mrf_f16x3(const sat_mrf_desc* d, void* stream);
 /* process-wide switches of the conv dispatch (A/B measurements): "k1_gemm" sends 1x1 convs on split planes through
  * 0 = the conv tile, 1 = the 128 x 128 GEMM kernel, 2 = the LDS-DMA ring GEMM (32x32x16 MFMA shape) where its
  * 256-column tiles fit, 3 (default) = the ring GEMM on the 16x16x32 shape (results of 3 agree with 0-2 to f32 rounding

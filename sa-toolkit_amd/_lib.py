@@ -43,6 +43,18 @@ class ConvDesc(C.Structure):
     ]
 
 
+class MrfDesc(C.Structure):
+    """mirror of sat_mrf_desc"""
+    _fields_ = [
+        ("B", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("n_branches", C.c_int32),
+        ("ksize", C.c_int32 * 3), ("dilation", (C.c_int32 * 3) * 3),
+        ("w", ((C.c_void_p * 2) * 3) * 3), ("bias", ((C.c_void_p * 2) * 3) * 3),
+        ("slope", C.c_float), ("x_split", C.c_void_p), ("y", C.c_void_p), ("y_split", C.c_void_p),
+        ("y_split_slope", C.c_float), ("out_div", C.c_float), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
+        ("residual_from_planes", C.c_int32),
+    ]
+
+
 _PROTOS = {
     "sat_abi_version": (C.c_int, []),
     "sat_last_error": (C.c_char_p, []),
@@ -61,6 +73,10 @@ _PROTOS = {
     "sat_hifigan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "sat_resblock_pair_f16x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "sat_mrf_debug_stamps": (C.c_int, [C.c_void_p]),
+    "sat_resblock_mrf_supported": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sat_resblock_mrf_scratch_bytes": (C.c_size_t, [C.c_int, C.POINTER(C.c_int)]),
+    "sat_resblock_mrf_f16x3": (C.c_int, [C.POINTER(MrfDesc), C.c_void_p]),
     "sat_act_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "sat_hifigan_convpost_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]),

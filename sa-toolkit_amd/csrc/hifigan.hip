@@ -134,6 +134,8 @@ struct sat_hifigan {
   int fuse_pairs = 1;
   int fuse_pair64 = 3;       // bit mask: the 3- (1) / 7- (2) / 11-tap (4) ResBlock steps of the C = 64 stage as one launch each (pair64.hip);
                              // 11 taps measured slower fused (its recomputed halo and short blocks cost more than the traffic saved)
+  int mrf_exact = 1;         // fused MRF block: residuals of steps 2 / 3 kept in f32 registers (0: rebuilt from the 22-bit planes like the launch-by-launch path, bit-identical to it)
+  int fuse_mrf = 1;          // a whole MRF block (all branches, all steps, the mean) as one launch where mrf.hip supports the stage (C = 16)
   int split_acts = 1;
   int planes_residual = 1;
   int n_ups() const { return (int)up_rates.size(); }
@@ -218,9 +220,11 @@ static bool hifigan_split_acts(const sat_hifigan* h) {
 
 constexpr int WS_SLOTS = 20;   // H (f32 + planes), MRF sum, 2 stage-input planes, 3 branches x (T1, RA, RB) x (f32 + planes)
 
+constexpr size_t WS_MRF_SCRATCH = 256 * 1024;   // behind the slots: the gathered weights of a fused MRF block (mrf.hip)
+
 extern "C" size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
-  return WS_SLOTS * align_up(hifigan_max_elems(h, B, T) * sizeof(float), 256);
+  return WS_SLOTS * align_up(hifigan_max_elems(h, B, T) * sizeof(float), 256) + WS_MRF_SCRATCH;
 }
 
 extern "C" void sat_hifigan_destroy(sat_hifigan* h) {
@@ -251,6 +255,8 @@ extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int valu
   SAT_REQUIRE(h && name, "hifigan_set_option: null pointer");
   if (std::string(name) == "fuse_pairs") { h->fuse_pairs = value; return SAT_OK; }
   if (std::string(name) == "fuse_pair64") { h->fuse_pair64 = value; return SAT_OK; }
+  if (std::string(name) == "fuse_mrf") { h->fuse_mrf = value; return SAT_OK; }
+  if (std::string(name) == "mrf_exact") { h->mrf_exact = value; return SAT_OK; }
   if (std::string(name) == "split_acts") { h->split_acts = value; return SAT_OK; }
   if (std::string(name) == "planes_residual") { h->planes_residual = value; return SAT_OK; }
   if (std::string(name) == "branch_streams") { h->branch_streams = value; return SAT_OK; }
@@ -377,6 +383,40 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
           s = sat_act_split_f32(Hf, Hs, B, Cn, Tn, 0.1f, cmode == SAT_CONV_F16F8 ? SAT_SPLIT_F8 : SAT_SPLIT_F16, stream);
           if (s != SAT_OK) return s;
         }
+      }
+      if (h->fuse_mrf && planes_res_all && h->fuse_pairs && nk <= 3 &&
+          sat_resblock_mrf_supported(Cn, nk, h->rb_kernels.data(), h->rb_dil.data()) &&
+          sat_resblock_mrf_scratch_bytes(nk, h->rb_kernels.data()) <= WS_MRF_SCRATCH) {
+        // the whole MRF block of this stage in one launch (mrf.hip): same bits as the loop below
+        sat_mrf_desc m{};
+        m.B = B; m.C = Cn; m.T = Tn; m.n_branches = nk;
+        for (int j = 0; j < nk; ++j) {
+          m.ksize[j] = h->rb_kernels[j];
+          for (int pair = 0; pair < 3; ++pair) {
+            m.dilation[j][pair] = h->rb_dil[j * 3 + pair];
+            for (int which = 0; which < 2; ++which) {
+              m.w[j][pair][which] = h->convs[h->id_rb(i, j, pair, which)].w;
+              m.bias[j][pair][which] = h->convs[h->id_rb(i, j, pair, which)].bias;
+            }
+          }
+        }
+        m.slope = 0.1f;
+        m.x_split = Hs;
+        m.y = ACCf;
+        m.y_split = last_stage ? nullptr : XSn;
+        m.y_split_slope = 0.1f;
+        m.out_div = (float)nk;
+        m.residual_from_planes = !h->mrf_exact;
+        m.scratch = ws + (size_t)WS_SLOTS * slot;
+        m.scratch_bytes = WS_MRF_SCRATCH;
+        int s = sat_resblock_mrf_f16x3(&m, stream);
+        if (s != SAT_OK) return s;
+        void* t = XS;
+        XS = XSn;
+        XSn = t;
+        C = Cn;
+        Tc = Tn;
+        continue;
       }
       if (side && i < h->branch_streams) {
         SAT_HIP(hipEventRecord(side->fork, (hipStream_t)stream));

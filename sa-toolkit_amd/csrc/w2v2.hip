@@ -571,7 +571,15 @@ extern "C" int sat_attention_f16x3(const void* q_split, const void* k_split, con
   const size_t lds_bytes = (size_t)2 * 64 * AT_VU * 16;  // split V image [hi|lo][64][33 units] >= K planes (16 x 256 x 16 B)
   const int nw = T > 128 ? 8 : 4;
   auto kern = nw == 8 ? attention_f16x3_kernel<8> : attention_f16x3_kernel<4>;
-  SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  {
+    // per device and per instantiation, once (the attribute call costs a driver round trip on each of the 24 layers)
+    static std::atomic<uint64_t> attr_done[2] = {{0}, {0}};
+    int dev;
+    if (attr_needed_on_current_device(attr_done[nw == 8], &dev)) {
+      SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      attr_done_on_device(attr_done[nw == 8], dev);
+    }
+  }
   dim3 grid(ceil_div(T, 32 * nw), heads, B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds_bytes, (hipStream_t)stream, (const uint4*)q_split,
                      (const uint4*)k_split, v, o, (uint4*)o_split, heads * head_dim, T, v_pitch, scale);

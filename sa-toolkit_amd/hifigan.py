@@ -30,8 +30,14 @@ class CoreHifiGan(CoreHifiGanParams):
     #: 4 = 11 taps (measured slower fused)
     fuse_pair64 = int(os.environ.get("SATOOLS_AMD_GEN_FUSE_PAIR64", "3"))
 
-    #: per-stream workspaces kept (3.3 GB each at 32 x 5 s); beyond it the least recently used one is dropped
-    max_workspaces = int(os.environ.get("SATOOLS_AMD_GEN_MAX_WORKSPACES", "16"))
+    #: run the whole MRF block of a stage (all branches and steps + the mean) as ONE launch where csrc/mrf.hip supports it
+    #: (C = 16); same bits as the launch-by-launch path
+    fuse_mrf = int(os.environ.get("SATOOLS_AMD_GEN_FUSE_MRF", "1"))
+
+    #: per-stream workspaces kept (3.3 GB each at 32 x 5 s: 26 GB at the default); beyond it the least recently used one is
+    #: dropped.  One per convert() job in flight on the GPU (the reference's jobs_per_compute_device, bench.py --jobs) is
+    #: what is needed; raise SATOOLS_AMD_GEN_MAX_WORKSPACES for more concurrent streams
+    max_workspaces = int(os.environ.get("SATOOLS_AMD_GEN_MAX_WORKSPACES", "8"))
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -47,7 +53,7 @@ class CoreHifiGan(CoreHifiGanParams):
         ps = self.__dict__.get("_flat_params")
         if ps is None:
             ps = self.__dict__["_flat_params"] = list(self.parameters())
-        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def invalidate(self):
         self._packed_key = None
@@ -108,6 +114,7 @@ class CoreHifiGan(CoreHifiGanParams):
         check(l.sat_hifigan_set_option(self._handle, b"split_acts", int(self.split_acts)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"branch_streams", int(self.branch_streams)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"fuse_pair64", int(self.fuse_pair64)), "sat_hifigan_set_option")
+        check(l.sat_hifigan_set_option(self._handle, b"fuse_mrf", int(self.fuse_mrf)), "sat_hifigan_set_option")
         self._packed = packed  # keeps the device buffers alive
         self._packed_key = key
         _lib.cache_rebuild_end(device)

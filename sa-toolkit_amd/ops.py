@@ -294,6 +294,34 @@ def resblock_pair(x, w1, b1, w2, b2, ksize, dilation, slope=0.1, out=None, accum
     return out
 
 
+def resblock_mrf(x_split, B, c, t, branches, slope=0.1, out=None, y_split=None, y_split_slope=1.0, out_div=0.0,
+                 residual_from_planes=False):
+    """a whole MRF block in one launch (csrc/mrf.hip): `branches` = [(ksize, [(w1, b1, w2, b2) x 3 steps]), ...] with packed
+    split-f16 weights; dilations (1, 3, 5); input split planes of lrelu(x, slope); returns the f32 output (or None)"""
+    from ._lib import MrfDesc
+    d = MrfDesc()
+    d.B, d.C, d.T, d.n_branches = B, c, t, len(branches)
+    keep = []
+    for j, (k, steps) in enumerate(branches):
+        d.ksize[j] = k
+        for i, (w1, b1, w2, b2) in enumerate(steps):
+            d.dilation[j][i] = 2 * i + 1
+            d.w[j][i][0], d.w[j][i][1] = ptr(w1), ptr(w2)
+            d.bias[j][i][0], d.bias[j][i][1] = ptr(b1), ptr(b2)
+            keep += [w1, b1, w2, b2]
+    d.slope = float(slope)
+    d.x_split = ptr(x_split)
+    if out is None and y_split is None:
+        out = torch.empty(B, c, t, dtype=torch.float32, device=x_split.device)
+    d.y, d.y_split, d.y_split_slope, d.out_div = ptr(out), ptr(y_split), float(y_split_slope), float(out_div)
+    d.residual_from_planes = int(residual_from_planes)
+    ks = _lib.int_array([k for k, _ in branches])
+    scratch = torch.empty(lib().sat_resblock_mrf_scratch_bytes(len(branches), ks), dtype=torch.uint8, device=x_split.device)
+    d.scratch, d.scratch_bytes = ptr(scratch), scratch.numel()
+    check(lib().sat_resblock_mrf_f16x3(C.byref(d), stream()), "sat_resblock_mrf_f16x3")
+    return out
+
+
 # ---- x-vector extractor (csrc/xvector.hip) -------------------------------------------------------
 def melspec_logmel(wav, window, fb, coef=0.97):
     """wav [B, n] -> log-mel [B, n_mel, 1 + n // 160]; fb [n_mel, 513] (rows = filters)"""

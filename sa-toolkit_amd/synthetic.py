@@ -125,7 +125,12 @@ def conditioning_path(asr_name):
     return os.path.join(here, "..", "tests", "golden", f"conditioning_{asr_name}.npz")
 
 
-_FILLED = {}     # (tag, seed, conditioning) -> filled state dict: drawing 327 M values takes ~15 s for the wav2vec2 tag
+# (tag, seed, conditioning) -> filled state dict: drawing 327 M values takes ~15 s for the wav2vec2 tag, and bench.py /
+# the tests build the same synthetic checkpoint several times per process.  ONE entry is kept (1.3 GB for the wav2vec2
+# tag); callers get the SAME tensors in a fresh dict and must treat them as read-only (load_state_dict copies them);
+# SATOOLS_AMD_SYNTH_CACHE=0 disables the cache.
+_FILLED = {}
+_FILLED_MAX = 1 if os.environ.get("SATOOLS_AMD_SYNTH_CACHE", "1") != "0" else 0
 
 
 def checkpoint(tag, seed=0, conditioning="auto"):
@@ -146,14 +151,16 @@ def checkpoint(tag, seed=0, conditioning="auto"):
         p = conditioning_path(asr_name)
         conditioning = p if os.path.exists(p) else None
     ck = (tag, int(seed), conditioning)
-    if ck not in _FILLED:
+    sd = _FILLED.get(ck)
+    if sd is None:
         sd = fill_state_dict(net.state_dict(), seed)
         if conditioning:
             apply_conditioning(sd, dict(np.load(conditioning)))
-        if len(_FILLED) >= 2:
-            _FILLED.pop(next(iter(_FILLED)))
-        _FILLED[ck] = sd
-    state["base_model_state_dict"] = dict(_FILLED[ck])     # same tensors (read-only by convention), a fresh dict
+        if _FILLED_MAX:
+            while len(_FILLED) >= _FILLED_MAX:
+                _FILLED.pop(next(iter(_FILLED)))
+            _FILLED[ck] = sd
+    state["base_model_state_dict"] = dict(sd)     # same tensors (read-only by convention), a fresh dict
     return state, net
 
 

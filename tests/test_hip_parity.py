@@ -920,3 +920,82 @@ def test_fused_resblock_step_c64_equals_the_two_launch_path(T, dil, k):
                    _rand(C, C, k, seed=3, scale=0.6 / np.sqrt(C * k)).double(), b2.double().cpu(), padding=(k - 1) // 2) + x.double().cpu()
     y, _ = fused(True)
     assert (y.cpu().double() - (acc0.double().cpu() + ref) / 3).abs().max().item() < 1e-5
+
+
+def _mrf_weights(C, ks, seed):
+    """seeded weights of a ResBlock1 branch: three steps of (w1, b1, w2, b2), f32 on the CPU"""
+    steps = []
+    for i in range(3):
+        s = seed + 10 * i
+        steps.append((_rand(C, C, ks, seed=s, scale=0.7 / np.sqrt(C * ks)), _rand(C, seed=s + 1, scale=0.1),
+                      _rand(C, C, ks, seed=s + 2, scale=0.7 / np.sqrt(C * ks)), _rand(C, seed=s + 3, scale=0.1)))
+    return steps
+
+
+def _mrf_launch_by_launch(ops, pk, x, xs, branches, out_div, y_split):
+    """today's path: per branch three sat_resblock_pair_f16x3 launches with planes end to end, the last one accumulating
+    into the f32 MRF sum (hifigan.hip's loop)"""
+    B, C, T = x.shape
+    acc = torch.empty(B, C, T, device=DEV)
+    nb = len(branches)
+    for j, (k, steps) in enumerate(branches):
+        cur = xs
+        for i, (w1, b1, w2, b2) in enumerate(steps):
+            a = (pk(w1.to(DEV)), b1.to(DEV), pk(w2.to(DEV)), b2.to(DEV))
+            if i < 2:
+                nxt = ops.split_like(B, C, T, DEV)
+                ops.resblock_pair(x, *a, k, 2 * i + 1, x_split=cur, y_split=nxt, y_split_slope=0.1, planes_residual=True, no_y=True, out=acc)
+                cur = nxt
+            else:
+                last = j == nb - 1
+                ops.resblock_pair(x, *a, k, 2 * i + 1, x_split=cur, y_split=y_split if last else None, y_split_slope=0.1,
+                                  planes_residual=True, out=acc, accum=j > 0, accum_div=out_div if last else 0.0)
+    return acc
+
+
+@pytest.mark.parametrize("T,B", [(700, 2), (512, 1), (513, 2), (1600, 3), (60, 2), (11, 1), (4099, 2)], ids=lambda v: str(v))
+def test_fused_mrf_block_c16_equals_the_nine_launch_path(T, B):
+    """mrf16_kernel (the whole MRF block of the C = 16 stage in one launch: 3 branches x 3 steps x 2 convs + the mean,
+    hifigan/archi.py:82-86) against the nine fused-step launches it replaces: bit for bit on the f32 mean and on its
+    split planes; tile edges (512 outputs per tile), utterances shorter than the 60-position halo, ragged tails"""
+    ops, packing = _ops()
+    C = 16
+    pk = packing.pack_conv_weight_f16x3
+    x = _rand(B, C, T, seed=1).to(DEV)
+    xs = ops.act_split(x, 0.1)
+    branches = [(3, _mrf_weights(C, 3, 100)), (7, _mrf_weights(C, 7, 200)), (11, _mrf_weights(C, 11, 300))]
+    ys_ref = ops.split_like(B, C, T, DEV)
+    ref = _mrf_launch_by_launch(ops, pk, x, xs, branches, 3.0, ys_ref)
+    packed = [(k, [(pk(w1.to(DEV)), b1.to(DEV), pk(w2.to(DEV)), b2.to(DEV)) for (w1, b1, w2, b2) in steps]) for k, steps in branches]
+    ys = ops.split_like(B, C, T, DEV)
+    y = ops.resblock_mrf(xs, B, C, T, packed, out=torch.empty(B, C, T, device=DEV), y_split=ys, y_split_slope=0.1, out_div=3.0,
+                         residual_from_planes=True)
+    assert torch.equal(y, ref)
+    assert torch.equal(ys, ys_ref)
+    # one branch alone (no mean): each kernel size against its three launches
+    for k, steps in branches:
+        r1 = _mrf_launch_by_launch(ops, pk, x, xs, [(k, steps)], 0.0, None)
+        p1 = [(k, [(pk(w1.to(DEV)), b1.to(DEV), pk(w2.to(DEV)), b2.to(DEV)) for (w1, b1, w2, b2) in steps])]
+        assert torch.equal(ops.resblock_mrf(xs, B, C, T, p1, residual_from_planes=True), r1), k
+    # float64 reference of the block
+    xd = ops.unsplit(xs).double().cpu()
+    xd = torch.where(xd > 0, xd, xd * 10.0)           # what the planes carry: 22 bits of x
+    tot = 0
+    for k, steps in branches:
+        v = xd
+        for i, (w1, b1, w2, b2) in enumerate(steps):
+            d = 2 * i + 1
+            t1 = F.conv1d(F.leaky_relu(v, 0.1), w1.double(), b1.double(), dilation=d, padding=d * (k - 1) // 2)
+            v = v + F.conv1d(F.leaky_relu(t1, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)
+        tot = tot + v
+    ref64 = tot / 3
+    e_planes = (y.cpu().double() - ref64).abs().max().item()
+    # default mode: the residual of steps 2 and 3 stays in f32 registers instead of being rebuilt from its 22-bit split —
+    # within f32 rounding of the bit-identical mode, and no further from float64 than it
+    ys2 = ops.split_like(B, C, T, DEV)
+    y2 = ops.resblock_mrf(xs, B, C, T, packed, out=torch.empty(B, C, T, device=DEV), y_split=ys2, y_split_slope=0.1, out_div=3.0)
+    e_exact = (y2.cpu().double() - ref64).abs().max().item()
+    assert e_planes < 2e-5 and e_exact < 2e-5, (e_planes, e_exact)
+    assert e_exact <= 1.5 * e_planes + 1e-7, (e_planes, e_exact)
+    assert (y2 - y).abs().max().item() < 4e-6
+    assert (ops.unsplit(ys2) - torch.where(y2 > 0, y2, y2 * 0.1)).abs().max().item() < 4e-6
