@@ -134,7 +134,8 @@ struct sat_hifigan {
   int fuse_pairs = 1;
   int fuse_pair64 = 3;       // bit mask: the 3- (1) / 7- (2) / 11-tap (4) ResBlock steps of the C = 64 stage as one launch each (pair64.hip);
                              // 11 taps measured slower fused (its recomputed halo and short blocks cost more than the traffic saved)
-  int mrf_exact = 1;         // fused MRF block: residuals of steps 2 / 3 kept in f32 registers (0: rebuilt from the 22-bit planes like the launch-by-launch path, bit-identical to it)
+  int mrf_exact = 0;         // fused MRF block: 0 = residuals of steps 2 / 3 rebuilt from the 22-bit planes like the launch-by-launch path (bit-identical
+                             // to it, and measured 5 % faster: fewer live registers); 1 = kept in f32 registers
   int fuse_mrf = 1;          // a whole MRF block (all branches, all steps, the mean) as one launch where mrf.hip supports the stage (C = 16)
   int split_acts = 1;
   int planes_residual = 1;

@@ -60,31 +60,47 @@ struct MrfFrags {               // A operand of one conv, resident in registers 
   h8 hi[NTP], lo[NTP];
 };
 
-// Weights of the NEXT conv travel global -> registers while the current conv runs and are written to their LDS slot
-// at the end of the phase (two 16-byte units per lane; holding both convs' fragment sets in registers instead — 96
-// VGPRs at 11 taps — made the allocator spill, and an LDS-DMA makes hipcc wait for it before the phase's first
-// ds_read).  They come from ONE buffer that holds every conv of the block as the image the slot takes
-// ([tap][hi|lo][half][16 rows] units = the packing without its padding rows, then 4 units of biases): a conv's
-// address is arithmetic on the scalar unit — with one pointer per conv in the kernel arguments every phase began
-// with scalar loads, and an s_load shares its counter with the LDS reads (s_waitcnt lgkmcnt(0): a full drain).
+// ---- asynchronous global -> LDS copies (LDS-DMA: buffer_load_dwordx4 ... lds, 64 lanes x 16 bytes = 1 KB contiguous in
+// LDS per instruction, no staging registers), issued through inline asm: with the builtin, hipcc waits for the copy
+// before the next ds_read it cannot prove disjoint (the whole phase), and it knows nothing of these, so the kernel counts
+// them itself: every wait for them below is an explicit s_waitcnt vmcnt.  M0 carries the LDS byte address (saved and
+// restored: hipcc owns M0).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 mrf_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void mrf_dma16(const uint4* lds_dst, const i32x4 rs, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);      // wave-uniform by construction
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(la), "v"(voff), "s"(rs), "s"(soff)
+               : "memory");
+#endif
+}
+
+// Weights of the NEXT conv travel to their LDS slot while the current conv runs.  They come from ONE buffer that holds
+// every conv of the block as the image the slot takes ([tap][hi|lo][half][16 rows] units = the packing without its
+// padding rows, then 4 units of biases): a conv's address is arithmetic on the scalar unit — with one pointer per conv in
+// the kernel arguments every phase began with scalar loads, and an s_load shares its counter with the LDS reads.
+// Wave w moves the 64-unit pieces w, w + 8 of the image; the piece that holds the biases zero-fills the 60 units
+// behind them (range check), which are the phantom tap's.
 template <int KS>
 __host__ __device__ constexpr int mrf_image_units() { return KS * 64 + 4; }
 template <int KS>
-__device__ __forceinline__ void mrf_issue_weights(uint4 (&wst)[2], const uint4* image, int tid) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)image, 0, (unsigned)(mrf_image_units<KS>() * 16), 0x00020000);
+__device__ __forceinline__ void mrf_stage_weights(uint4* slot, const uint4* image, int wave, int lane) {
+  const i32x4 rs = mrf_rsrc(image, (unsigned)(mrf_image_units<KS>() * 16));
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
-    if (MRF_THREADS * r < mrf_image_units<KS>())
-      wst[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((tid + MRF_THREADS * r) * 16), 0, 0));
-}
-template <int KS>
-__device__ __forceinline__ void mrf_commit_weights(uint4* slot, const uint4 (&wst)[2], int tid) {
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int u = tid + MRF_THREADS * r;
-    if (MRF_THREADS * r < mrf_image_units<KS>() && u < mrf_image_units<KS>()) slot[u] = wst[r];
+  for (int r = 0; r < (KS + 1 + 7) / 8; ++r) {
+    const int piece = wave + 8 * r;
+    if (piece <= KS) mrf_dma16(slot + piece * 64, rs, (unsigned)(lane * 16), (unsigned)(piece * 1024));
   }
 }
+// LDS-DMA instructions mrf_stage_weights issues on this wave
+template <int KS>
+__device__ __forceinline__ int mrf_stage_count(int wave) { return (KS - wave) / 8 + 1; }
 
 template <int KS, int NTPA>
 __device__ __forceinline__ void mrf_read_frags(MrfFrags<NTPA>& f, const uint4* slot, int j16, int g) {
@@ -233,48 +249,33 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
   if (tile >= tile_end) return;
 
   // input staging: 2 x 320 columns per plane (positions t0 - 64 .. t0 + 576), wave = (plane, column half), five
-  // 64-column pieces per wave.  The NEXT tile's image is fetched during the four phases that follow the last read of
-  // this tile's image, each piece written to LDS at the END of the phase AFTER the one that issued it (an HBM round trip
-  // is longer than a short phase): pieces {0, 1} and {3, 4} through one pair of staging registers, piece 2 through a third.
+  // 64-column LDS-DMA pieces per wave; columns outside the utterance arrive as zeros (range check).  The NEXT tile's
+  // image is requested as soon as this tile's is dead (second step of the last branch) and is only waited for at the
+  // end of the tile.
   const int xpl = wave & 3, xhf = wave >> 2;
-  uint4 xstA[2], xstB[1];
-  auto issue_x = [&](uint4* dst, int tl, int it0, int n) __attribute__((always_inline)) {
+  auto stage_x = [&](int tl) __attribute__((always_inline)) {
     const int ub = __builtin_amdgcn_readfirstlane(tl / p.tiles_t);
     const int pos0 = (tl - ub * p.tiles_t) * MRF_W - HP + xhf * 320;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.x16 + (long long)ub * 16 * p.T * 4), 0, (unsigned)(16 * p.T * 4), 0x00020000);
+    const i32x4 xrs = mrf_rsrc((const char*)p.x16 + (long long)ub * 16 * p.T * 4, (unsigned)(16 * p.T * 4));
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      if (r < n) {
-        const int pos = pos0 + lane + 64 * (it0 + r);
-        const unsigned voff = (pos >= 0 && pos < p.T) ? (unsigned)((xpl * p.T + pos) * 16) : OOB;
-        dst[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0));
-      }
+    for (int it = 0; it < 5; ++it) {
+      const int pos = pos0 + lane + 64 * it;
+      const unsigned voff = (pos >= 0 && pos < p.T) ? (unsigned)((xpl * p.T + pos) * 16) : OOB;
+      mrf_dma16(X0 + xpl * WP + xhf * 320 + 64 * it, xrs, voff, 0u);
     }
-  };
-  auto publish_x = [&](const uint4* src, int it0, int n) __attribute__((always_inline)) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-      if (r < n) X0[xpl * WP + xhf * 320 + lane + 64 * (it0 + r)] = src[r];
   };
 
   MrfFrags<NTPA> fr;            // A operand of the running conv
   float xr[5][4];               // the running x of this lane's columns (subtile wave + 8 i, channels 4 g ..)
   f32x4 held[NB == 1 ? 1 : 2][4];   // outputs of the branches processed first (subtiles of the last phase: slot & 3)
 
-  issue_x(xstA, tile, 0, 2);
-  issue_x(xstB, tile, 2, 1);
-  publish_x(xstA, 0, 2);
-  publish_x(xstB, 2, 1);
-  issue_x(xstA, tile, 3, 2);
-  publish_x(xstA, 3, 2);
-  uint4 wst[2];                 // the next conv's weights on their way to LDS
+  stage_x(tile);
   // first unit of branch j's six images (convs in (step, conv) order)
   constexpr int OFF0 = 0, OFF1 = NB == 1 ? 0 : 6 * mrf_image_units<K0>(), OFF2 = NB == 1 ? 0 : OFF1 + 6 * mrf_image_units<K1>();
   constexpr int KF = NB == 1 ? K0 : K2;               // the branch processed first
   constexpr int OFFF = NB == 1 ? OFF0 : OFF2;
-  mrf_issue_weights<KF>(wst, p.blob + OFFF, tid);
-  mrf_commit_weights<KF>(WA, wst, tid);
+  mrf_stage_weights<KF>(WA, p.blob + OFFF, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   int dbg_tile = 0, dbg_idx = 0;
   for (;;) {
@@ -358,9 +359,9 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
           float bias1[4];
           mrf_read_frags<KS>(fr, WA, j16, g);
           mrf_read_bias<KS>(bias1, WA, g);
-          mrf_issue_weights<KS>(wst, p.blob + woff + (2 * i + 1) * mrf_image_units<KS>(), tid);
-          const bool xfetch = last && i >= 1 && more;         // the input image is dead from the second step of the last branch on
-          if (xfetch) issue_x(xstA, next, i == 1 ? 0 : 3, 2);
+          mrf_stage_weights<KS>(WB, p.blob + woff + (2 * i + 1) * mrf_image_units<KS>(), wave, lane);
+          const bool xfetch = last && i == 1 && more;         // the input image is dead from the second step of the last branch on
+          if (xfetch) stage_x(next);
           MRF_STAMP();
           uint2* const t1w = (uint2*)(T1 + gt * WP + 16 * wave + jl) + gh;
           auto stage = [&](const int st, Epi& e, const f32x4 acc, const int sl) __attribute__((always_inline)) {
@@ -385,8 +386,9 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
           };
           run_phase(xin + gh * WP + 16 * wave + jl - h * dil, dil, wave + 32 <= s_hi, stage);
           MRF_STAMP();
-          if (xfetch && i == 2) publish_x(xstB, 2, 1);
-          mrf_commit_weights<KS>(WB, wst, tid);
+          // the weights of conv2 have landed (the five pieces of the next tile's image, requested after them, may still fly)
+          if (xfetch) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           MRF_STAMP();
           mrf_barrier();
           MRF_STAMP();
@@ -400,12 +402,10 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
           mrf_read_frags<KS>(fr, WB, j16, g);
           mrf_read_bias<KS>(bias2, WB, g);
           if (i < 2) {
-            mrf_issue_weights<KS>(wst, p.blob + woff + (2 * i + 2) * mrf_image_units<KS>(), tid);
+            mrf_stage_weights<KS>(WA, p.blob + woff + (2 * i + 2) * mrf_image_units<KS>(), wave, lane);
           } else {
-            mrf_issue_weights<KSN>(wst, p.blob + woff_next, tid);
+            mrf_stage_weights<KSN>(WA, p.blob + woff_next, wave, lane);
           }
-          const bool xfetch = last && i >= 1 && more;
-          if (xfetch && i == 1) issue_x(xstB, next, 2, 1);
           if (i == 0) {      // the residual of the first step: the stage input, from its planes
             const uint2* xw = (const uint2*)(X0 + gt * WP + 16 * wave + jl) + gh;
 #pragma unroll
@@ -489,9 +489,7 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
           };
           run_phase(T1 + gh * WP + 16 * wave + jl - h, 1, wave + 32 <= s_hi, stage);
           MRF_STAMP();
-          if (xfetch) publish_x(xstA, i == 1 ? 0 : 3, 2);
-          if (i < 2) mrf_commit_weights<KS>(WA, wst, tid);
-          else mrf_commit_weights<KSN>(WA, wst, tid);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next conv1's weights (and, at the end of the tile, its stores and the next image)
           MRF_STAMP();
           mrf_barrier();
           MRF_STAMP();
