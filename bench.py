@@ -52,6 +52,8 @@ UNIT = "x real-time (audio s / wall s)"
 GEN_FLOP_PER_UTT = 80.86e9          # generator: 40.43 GMAC
 GEN_BYTES_PER_UTT = 731.4e6         # per-layer streaming model of the generator
 W2V2_FLOP_PER_UTT = 185.5e9 + 0.92e9   # wav2vec2-large 92.73 GMAC + TDNNF tail 0.46 GMAC
+W2V2_ACT_BYTES_PER_UTT = 620e6 + 5e6   # per-layer streaming model of the extractor's activations
+W2V2_WEIGHT_BYTES = 1.26e9             # its weights, streamed once per batch
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0       # dense f16/bf16 MFMA (MI355X_MICROARCH.md); split-f16 issues 3 MFMA products per product
 PEAK_HBM_TBS = 8.0
@@ -82,7 +84,8 @@ def host_cpu():
     return model, int(cores)
 
 
-def cpu_baseline(tag, f0_transformation, spk, n_utt, runs_1, runs_n, n_utt_1=None, budget_note=""):
+def cpu_baseline(tag, f0_transformation, spk, n_utt, runs_1, runs_n, n_utt_1=None, budget_note="", procs=0, n_utt_proc=0,
+                 worker_mode=False):
     """the CPU oracle (a port of the reference's PyTorch path: serial YAAPT loop over the batch, fbank / wav2vec2,
     TDNNF-VQ, generator) timed on the host cores over a bounded sample of the same workload: one convert() batch of
     `n_utt` utterances, median of `runs_*` runs, at 1 thread and at the physical core count"""
@@ -119,6 +122,8 @@ def cpu_baseline(tag, f0_transformation, spk, n_utt, runs_1, runs_n, n_utt_1=Non
             t2 = time.perf_counter()
         return t2 - t0, t1 - t0
 
+    if worker_mode:
+        return once
     model_name, cores = host_cpu()
     keep = torch.get_num_threads()
     out = {"unit": UNIT, "kind": "port", "cpu_model": model_name}
@@ -133,14 +138,65 @@ def cpu_baseline(tag, f0_transformation, spk, n_utt, runs_1, runs_n, n_utt_1=Non
     finally:
         torch.set_num_threads(keep)
     out.update(res)
-    # `value` / `cores` = the faster of the two settings (what the host can do), both kept above
-    best = max(("threads1", "threadsN"), key=lambda k: res[k]["value"])
+    if procs > 0:
+        # what the host can do the way the reference scales on CPUs: P single-thread PROCESSES side by side (its
+        # jobs_per_compute_device model, bin/anonymize:85-93), each converting its own batch
+        pr = cpu_processes(tag, f0_transformation, min(procs, max(1, cores)), n_utt_proc or n_utt)
+        if pr:
+            out["processes"] = res["processes"] = pr
+    # `value` / `cores` = the fastest of the settings (what the host can do), all kept above
+    best = max(res, key=lambda k: res[k]["value"])
     out["value"], out["cores"] = res[best]["value"], res[best]["threads"]
     out["sample"] = (f"one convert() batch, torch CPU f32: {res['threads1']['utterances']} x 5 s at 1 thread (the reference's "
                      f"setting, yaapt.py:27; median of {runs_1}) = {res['threads1']['value']} x RT in {res['threads1']['seconds']} s; "
                      f"{res['threadsN']['utterances']} x 5 s at {cores} threads (physical cores; median of {runs_n}) = "
-                     f"{res['threadsN']['value']} x RT in {res['threadsN']['seconds']} s" + budget_note)
+                     f"{res['threadsN']['value']} x RT in {res['threadsN']['seconds']} s"
+                     + (f"; {res['processes']['threads']} single-thread processes x {res['processes']['utterances_per_process']} x 5 s side by side = "
+                        f"{res['processes']['value']} x RT in {res['processes']['seconds']} s" if "processes" in res else "") + budget_note)
     return out
+
+
+def cpu_processes(tag, f0_transformation, procs, n_utt):
+    """P child processes, one torch thread each, load the oracle, report READY, start together on GO and each convert one
+    batch of n_utt utterances: throughput = P x n_utt x 5 s / the slowest process"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", tag, f0_transformation or "-", str(n_utt)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    ps = []
+    try:
+        for i in range(procs):
+            ps.append(subprocess.Popen(cmd + [str(i)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                       text=True, env=env))
+        for p in ps:
+            if p.stdout.readline().strip() != "READY":
+                raise RuntimeError("cpu worker failed to load")
+        for p in ps:
+            p.stdin.write("GO\n")
+            p.stdin.flush()
+        secs = [float(p.stdout.readline()) for p in ps]
+        for p in ps:
+            p.wait(timeout=60)
+    except Exception as e:                                   # the CPU leg is a reported baseline: never fail the bench on it
+        for p in ps:
+            p.kill()
+        print(f"bench.py: process-parallel CPU leg skipped ({e})", file=sys.stderr)
+        return None
+    dt = max(secs)
+    return {"value": round(procs * n_utt * UTT_SECONDS / dt, 3), "threads": procs, "processes": procs, "utterances_per_process": n_utt,
+            "utterances": procs * n_utt, "runs": 1, "seconds": round(dt, 2), "slowest_fastest_process_s": [round(max(secs), 2), round(min(secs), 2)]}
+
+
+def cpu_worker(tag, f0_tr, n_utt, index):
+    import torch
+    torch.set_num_threads(1)
+    import satools_amd  # noqa: F401
+    from satools_amd import synthetic
+    state, _ = synthetic.checkpoint(tag)
+    spk = sorted(set(state["base_model_params"]["utt2spk"].values()))
+    once = cpu_baseline(tag, "" if f0_tr == "-" else f0_tr, spk, n_utt, 1, 1, worker_mode=True)
+    print("READY", flush=True)
+    sys.stdin.readline()
+    dt, _ = once([index * n_utt + i for i in range(n_utt)])
+    print(dt, flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -186,10 +242,12 @@ def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each):
     return time.perf_counter() - t0, setup_steps
 
 
-def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each):
+def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, gather="f32"):
     """N > 1 mode (and SAT_BENCH_FORCE_PG=1 with one rank): world x steps x 32 utterances sharded through
     satools_amd.dist.convert_sharded, one all-gather of the shards at the end, all inside the timed region.
-    Returns (seconds [max over ranks], all-gather ms [max over ranks], ranks seen, setup_steps)."""
+    `gather` = "pcm16": the shards are converted to the int16 PCM the reference writes before the collective (half the
+    bytes).  Returns (seconds [max over ranks], all-gather ms [max over ranks], ranks seen, setup_steps, gathered job ==
+    this rank's shard at its place)."""
     import torch
     import torch.distributed as dist
     from satools_amd import dist as sdist
@@ -224,22 +282,30 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each):
     for i in range(setup_steps + warmup):
         convert_fn(lo + (i % steps) * BATCH, lo + (i % steps) * BATCH + BATCH)
     join_streams()
-    sdist.all_gather_rows(local, n_items)                 # first collective: RCCL builds its communicator / rings here
+    transform = sdist.pcm16_rows if gather == "pcm16" else None
+    sdist.all_gather_rows(transform(local) if transform else local, n_items)   # first collective: RCCL builds its communicator / rings here
     ranks_seen = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(ranks_seen, torch.tensor([rank], dtype=torch.int64, device=dev))
     ranks_seen = [int(t.item()) for t in ranks_seen]
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = sdist.convert_sharded(convert_fn, n_items, BATCH, gather=True, local_out=local, before_gather=join_streams)
+    out = sdist.convert_sharded(convert_fn, n_items, BATCH, gather=True, local_out=local, before_gather=join_streams, transform=transform)
     ev[1].record(cur)
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
     assert out.shape == (n_items, 1, N_SAMPLES + 1)
-    t = torch.tensor([dt, ev[0].elapsed_time(ev[1])], dtype=torch.float64, device=dev)
+    same = bool(torch.equal(out[lo:hi], transform(local) if transform else local))
+    t = torch.tensor([dt, ev[0].elapsed_time(ev[1]), 0.0 if same else 1.0], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t[0].item()), float(t[1].item()), ranks_seen, setup_steps
+    return float(t[0].item()), float(t[1].item()), ranks_seen, setup_steps, t[2].item() == 0.0
+
+
+def last_dispatch():
+    """the kernel (family<template arguments>) the library launched last on this thread: read back, not assumed"""
+    from satools_amd import _lib
+    return _lib.lib().sat_last_dispatch_name().decode()
 
 
 def time_events(fn, reps, warm=2):
@@ -283,14 +349,14 @@ def roofline_generator(model, dev, reps):
                                  y_split=ys, y_split_slope=0.1, res_split=rs, res_split_slope=0.1, no_y=True, out=xk)
         us = time_events(run, 20, warm=3) * 1e3
         flop = 2.0 * BATCH * C * C * k * T
-        dom = {"name": "conv1d_f16x3_planes_lean_kernel<11, 6> (split-f16 conv tile, three blocks per CU), 11 taps, C=256, T=1250, dilation 5, batch 32 (18 launches per forward)",
+        dom = {"name": last_dispatch() + " — the generator's split-f16 conv tile at 11 taps, C=256, T=1250, dilation 5, batch 32 (18 launches per forward)",
                "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
                "frac": round(flop / us / 1e6 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)}
     achieved = GEN_FLOP_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
     peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
     hbm = GEN_BYTES_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
     traffic, note = None, None
-    for name in ("r02_generator_traffic.json", "r01o_generator_traffic.json"):
+    for name in ("r03_generator_traffic.json", "r02_generator_traffic.json", "r01o_generator_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))["per_forward"]
@@ -329,13 +395,26 @@ def roofline_w2v2(model, dev, reps):
         xs, ys = ops.act_split(x, 1.0), ops.split_like(BATCH, cout, T, dev)
         run = lambda: ops.conv1d(x, w, cout, 1, bias=b, gelu=True, mode=1, x_split=xs, y_split=ys, y_split_slope=1.0, no_y=True)
         us = time_events(run, 20, warm=3) * 1e3
+        dom_name = last_dispatch()
     flop = 2.0 * BATCH * T * cin * cout
     peak = PEAK_F16_MFMA_TFLOPS / 3.0
     achieved = W2V2_FLOP_PER_UTT * BATCH / (ext_ms * 1e-3) / 1e12
+    model_bytes = W2V2_ACT_BYTES_PER_UTT * BATCH + W2V2_WEIGHT_BYTES
+    hbm = model_bytes / (ext_ms * 1e-3) / 1e12
+    traffic, note = None, None
+    tpath = os.path.join(ROOT, "profiles", "r03_w2v2_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))["per_forward"]
+        traffic = (tj["fetch_GB_doubled"] + tj["write_GB"]) * 1e9
+        note = (f"HBM bytes per get_bn() of a batch of 32, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                f"(profiles/r03_w2v2_traffic.json): fetch {tj['fetch_GB_doubled']} GB (FETCH_SIZE x 2, the gfx950 wide-load "
+                f"correction) + write {tj['write_GB']} GB; per-layer streaming model {model_bytes / 1e9:.2f} GB")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note,
+            "hbm_model": {"achieved_TBps": round(hbm, 3), "peak_TBps": PEAK_HBM_TBS, "frac": round(hbm / PEAK_HBM_TBS, 4),
+                          "bytes_per_launch_group": model_bytes},
             "kernel": f"wav2vec2-large + TDNNF tail bottleneck extractor (get_bn): all launches, {ext_ms:.3f} ms per batch of {BATCH}",
-            "dominant_kernel": {"name": "gemm_f16x3_ring16_kernel (1x1 GEMM on split planes, LDS-DMA ring, v_mfma_f32_16x16x32_f16), FFN 1024 -> 4096 + GELU, 249 frames, batch 32",
+            "dominant_kernel": {"name": dom_name + " — the 1x1 GEMM on split planes of the encoder's Linear layers: FFN 1024 -> 4096 + GELU, 249 frames, batch 32",
                                 "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
                                 "frac": round(flop / us / 1e6 / peak, 4)},
             "arithmetic": "f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 MFMA peak / 3",
@@ -348,11 +427,14 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
     seed_each = "awgn" in f0_tr
     extra = {}
     if use_pg:
-        dt, ag_ms, ranks, setup = run_sharded(model, dev, rank, world, steps, warmup, a.jobs, seed_each)
+        dt, ag_ms, ranks, setup, same = run_sharded(model, dev, rank, world, steps, warmup, a.jobs, seed_each, a.gather)
+        gb = 2 if a.gather == "pcm16" else 4
         extra = {"all_gather_ms": round(ag_ms, 3), "ranks_seen_by_rccl": ranks,
-                 "utterances": world * steps * BATCH,
-                 "all_gather": f"one all_gather_into_tensor of [{steps * BATCH}, 1, {N_SAMPLES + 1}] f32 per rank "
-                               f"({steps * BATCH * (N_SAMPLES + 1) * 4 / 1e6:.0f} MB) at the end, inside the timed region"}
+                 "utterances": world * steps * BATCH, "gather_dtype": "int16" if a.gather == "pcm16" else "float32",
+                 "gathered_equals_shard": same,
+                 "all_gather": f"one all_gather_into_tensor of [{steps * BATCH}, 1, {N_SAMPLES + 1}] "
+                               f"{'int16 PCM' if a.gather == 'pcm16' else 'f32'} per rank "
+                               f"({steps * BATCH * (N_SAMPLES + 1) * gb / 1e6:.0f} MB) at the end, inside the timed region"}
     else:
         dt, setup = run_steps(model, dev, rank, steps, warmup, a.jobs, seed_each)
     if rank != 0:
@@ -370,6 +452,8 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
                            "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
                            "f0": "YAAPT computed on-path on the GPU inside convert()", "jobs_per_gpu": a.jobs,
                            "setup_steps": setup,
+                           "reference_default_tag": f"{TAG_W2V2} (hubconf.py:69): its lines are configs[2] / configs[3] / configs[4] of this same run; "
+                                                    f"the headline is BASELINE.json's configs[1], the tag the metric is quoted on",
                            "parallelism": f"dp{world}" + (" sharded (contiguous shards, batches of 32 in index order)" if use_pg else "")},
                           **extra),
            "roofline": roof}
@@ -437,10 +521,15 @@ def main():
     ap.add_argument("--jobs", type=int, default=4,
                     help="convert() calls in flight per GPU, each on its own HIP stream (the reference's "
                          "jobs_per_compute_device, satools/satools/bin/anonymize:85-93)")
+    ap.add_argument("--gather", choices=("f32", "pcm16"), default="f32",
+                    help="sharded mode: gather the waveforms as f32 (default) or as the int16 PCM the reference writes (half the bytes)")
+    ap.add_argument("--cpu-worker", nargs=4, metavar=("TAG", "F0TR", "N", "INDEX"), default=None, help=argparse.SUPPRESS)
     ap.add_argument("--tag", default=None, help="measure only this tag (one line)")
     ap.add_argument("--f0-transformation", default="", help="with --tag: e.g. quant_16_awgn_2")
     a = ap.parse_args()
     a.jobs = max(1, a.jobs)
+    if a.cpu_worker:
+        return cpu_worker(a.cpu_worker[0], a.cpu_worker[1], int(a.cpu_worker[2]), int(a.cpu_worker[3]))
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # typed as `python bench.py --gpus N`: start the ranks as a CHILD process (this parent has not touched the GPU
@@ -490,11 +579,11 @@ def main():
     else:
         k2 = min(a.steps, 12)
         plan = ([] if a.headline_only else [
-            ("configs[2]", TAG_W2V2, "", k2, a.warmup, dict(n_utt=8, runs_1=1, runs_n=3, n_utt_1=4)),
+            ("configs[2]", TAG_W2V2, "", k2, a.warmup, dict(n_utt=8, runs_1=1, runs_n=3, n_utt_1=4, procs=8, n_utt_proc=2)),
             ("configs[3]", TAG_W2V2, "quant_16_awgn_2", k2, a.warmup,
              dict(n_utt=8, runs_1=1, runs_n=1, n_utt_1=2,
                   budget_note="; configs[3] differs from configs[2] by the quantisation + noise of 250 x B values only, so its CPU leg is a shorter sample"))]) + \
-            [("configs[1]", TAG, "", a.steps, a.warmup, dict(n_utt=8, runs_1=3, runs_n=3))]
+            [("configs[1]", TAG, "", a.steps, a.warmup, dict(n_utt=8, runs_1=3, runs_n=3, procs=32, n_utt_proc=4))]
     for name, tag, f0_tr, steps, warmup, cpu_args in plan:
         out = one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu and cpu_args is not None, cpu_args or {})
         torch.cuda.empty_cache()
@@ -519,6 +608,8 @@ def main():
                     cb = o["cpu_baseline"]
                     d["cpu_baseline"] = {"value": cb["value"], "cores": cb["cores"], "threads1": cb["threads1"]["value"],
                                          "threadsN": cb["threadsN"]["value"], "threadsN_cores": cb["threadsN"]["threads"], "kind": cb["kind"]}
+                    if "processes" in cb:
+                        d["cpu_baseline"]["processes"] = {"value": cb["processes"]["value"], "processes": cb["processes"]["processes"]}
                 return d
             head["configs"] = {o["config"]["workload"].split(":")[0]: brief(o) for o in lines[:-1]}
             for o in lines[:-1]:

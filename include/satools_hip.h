@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 2
+#define SAT_ABI_VERSION 3
 
 typedef enum {
   SAT_OK = 0,
@@ -43,6 +43,10 @@ typedef enum {
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
+/* kernel family (with its template arguments) of the last launch the calling thread made through this library, e.g.
+ * "conv1d_f16x3_planes_lean_kernel<KS = 11, TG = 6>"; "" before the first launch.  Diagnostics: which kernel the
+ * dispatch picked for a shape. */
+const char* sat_last_dispatch_name(void);
 /* name of device 0 and its CU count; SAT_ERR_NO_DEVICE without a GPU. `name` is a host buffer. */
 int sat_device_info(char* name, int name_len, int* cu_count);
 /* diagnostic (tools/clock_probe.py): one wave records n pairs (shader cycle counter, 100 MHz wall counter) every
@@ -141,6 +145,10 @@ typedef struct {
                               y[t] = W[:, :Cw] x[:, t] + W[:, Cw:] x[:C_in - Cw, t + 1].  A stride-2 3-tap conv over
                               [even | odd] phase-split input is this with Cw = 2 C, C_in = 3 C (no zero taps, one GEMM).
                               Multiples of 32; C_out % 128 == 0; positions t + 1 >= T_in read as zero */
+  float w_descale;         /* SAT_CONV_F16X3 / F16F8: the packed weights are w * 2^e (packing.py picks e per layer so that the
+                              largest |w| sits near 2^10: lo = f16(w - hi) is then a NORMAL f16 for every weight within
+                              2^-13 of the largest, i.e. hi + lo carries 22 significand bits whatever the layer's scale) and
+                              the accumulator is multiplied by w_descale = 2^-e before the bias — exact.  0 means 1 */
 } sat_conv1d_desc;
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
@@ -154,6 +162,9 @@ int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packe
  * Weights: SAT_CONV_F16X3 packing. */
 int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
                             const float* bias1, const void* w2_packed, float* y, void* stream);
+/* the same with the first conv's weights packed as w1 * 2^e1: w1_descale = 2^-e1 (d->w_descale is the second conv's) */
+int sat_resblock_pair_scaled_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
+                                   const float* bias1, float w1_descale, const void* w2_packed, float* y, void* stream);
 /* A whole multi-receptive-field block of a thin generator stage in ONE launch (csrc/mrf.hip): n_branches ResBlock1
  * branches (hifigan/nn.py:93-187; three steps x = x + conv2(lrelu(conv1(lrelu(x)))) each, conv1 dilated 1 / 3 / 5)
  * on the same input, summed in branch order and divided by out_div (hifigan/archi.py:82-86: xs / num_kernels):
@@ -169,6 +180,7 @@ typedef struct {
   int32_t dilation[3][3];
   const void* w[3][3][2];        /* [branch][step][conv1 | conv2] packed weights */
   const float* bias[3][3][2];
+  float w_descale[3][3][2];      /* 2^-e of each conv's packed weights (sat_conv1d_desc.w_descale); 0 means 1 */
   float slope;                   /* leaky-relu slope of every conv input (and of x_split) */
   const void* x_split;           /* input: SAT_SPLIT_F16 planes of lrelu(x, slope) */
   float* y;                      /* f32 output [B][C][T], or NULL */
@@ -214,6 +226,8 @@ int sat_hifigan_create(sat_hifigan** out, int in_channels, int initial_channels,
                        const int* rb_kernels, const int* rb_dilations /* [n_rb_kernels][3] */);
 int sat_hifigan_num_convs(const sat_hifigan* h);
 int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const void* w_packed, const float* bias, int mode);
+/* power-of-two descale of a conv's packed weights (sat_conv1d_desc.w_descale); 1 after sat_hifigan_set_conv */
+int sat_hifigan_set_conv_descale(sat_hifigan* h, int conv_id, float w_descale);
 size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T);
 /* x [B][in_channels][T] -> y [B][1][T*prod(up_rates)+1]  (tanh output, archi.py:87-90) */
 int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, float* y, void* workspace,

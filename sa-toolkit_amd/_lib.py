@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("res_split", C.c_void_p), ("res_split_slope", C.c_float), ("y_split_format", C.c_int32),
         ("relu_first", C.c_int32),
         ("x_wrap_channels", C.c_int32),
+        ("w_descale", C.c_float),
     ]
 
 
@@ -48,7 +49,7 @@ class MrfDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("n_branches", C.c_int32),
         ("ksize", C.c_int32 * 3), ("dilation", (C.c_int32 * 3) * 3),
-        ("w", ((C.c_void_p * 2) * 3) * 3), ("bias", ((C.c_void_p * 2) * 3) * 3),
+        ("w", ((C.c_void_p * 2) * 3) * 3), ("bias", ((C.c_void_p * 2) * 3) * 3), ("w_descale", ((C.c_float * 2) * 3) * 3),
         ("slope", C.c_float), ("x_split", C.c_void_p), ("y", C.c_void_p), ("y_split", C.c_void_p),
         ("y_split_slope", C.c_float), ("out_div", C.c_float), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
         ("residual_from_planes", C.c_int32),
@@ -58,6 +59,7 @@ class MrfDesc(C.Structure):
 _PROTOS = {
     "sat_abi_version": (C.c_int, []),
     "sat_last_error": (C.c_char_p, []),
+    "sat_last_dispatch_name": (C.c_char_p, []),
     "sat_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "sat_conv1d_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sat_conv1d_packed_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -77,6 +79,9 @@ _PROTOS = {
     "sat_resblock_mrf_supported": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sat_resblock_mrf_scratch_bytes": (C.c_size_t, [C.c_int, C.POINTER(C.c_int)]),
     "sat_resblock_mrf_f16x3": (C.c_int, [C.POINTER(MrfDesc), C.c_void_p]),
+    "sat_resblock_pair_scaled_f16x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]),
+    "sat_hifigan_set_conv_descale": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
     "sat_act_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "sat_hifigan_convpost_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]),
@@ -147,7 +152,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.sat_abi_version() != 2:
+        if l.sat_abi_version() != 3:
             raise SatError("libsatools_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -6,6 +6,19 @@
 namespace sat {
 static thread_local char g_err[512] = "";
 
+static thread_local char g_dispatch[384] = "";
+
+void note_dispatch(const char* kernel, const char* launcher) {
+  // "... launch_lean(...) [KS = 11, TG = 6]" -> "kernel<KS = 11, TG = 6>"
+  const char* lb = launcher ? strrchr(launcher, '[') : nullptr;
+  if (lb && strchr(lb, ']')) {
+    const int n = (int)(strchr(lb, ']') - lb - 1);
+    snprintf(g_dispatch, sizeof(g_dispatch), "%s<%.*s>", kernel, n, lb + 1);
+  } else {
+    snprintf(g_dispatch, sizeof(g_dispatch), "%s", kernel);
+  }
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -17,6 +30,8 @@ void set_error(const char* fmt, ...) {
 extern "C" int sat_abi_version(void) { return SAT_ABI_VERSION; }
 
 extern "C" const char* sat_last_error(void) { return sat::g_err; }
+
+extern "C" const char* sat_last_dispatch_name(void) { return sat::g_dispatch; }
 
 extern "C" int sat_device_info(char* name, int name_len, int* cu_count) {
   int n = 0;

@@ -27,7 +27,15 @@ inline int check_hip(hipError_t e, const char* what) {
     if (_s != SAT_OK) return _s;                        \
   } while (0)
 
-#define SAT_LAUNCH_CHECK(name) SAT_HIP(hipGetLastError())
+// every launcher passes the name of the kernel family it has just launched: kept (with the launcher's own signature, which
+// spells its template arguments) as this thread's last dispatch, for callers that report WHICH kernel served a shape
+// (bench.py's roofline.dominant_kernel.name; sat_last_dispatch_name)
+void note_dispatch(const char* kernel, const char* launcher);
+#define SAT_LAUNCH_CHECK(name)                          \
+  do {                                                  \
+    ::sat::note_dispatch(name, __PRETTY_FUNCTION__);    \
+    SAT_HIP(hipGetLastError());                         \
+  } while (0)
 
 #define SAT_REQUIRE(cond, ...)          \
   do {                                  \

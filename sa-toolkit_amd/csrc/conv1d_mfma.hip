@@ -392,7 +392,7 @@ __device__ __forceinline__ void polyphase_planes_epilogue(const ConvArgs& p, f32
         const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int grow = co_w + row;
         const float bias = (p.bias && grow < p.rows_g) ? p.bias[grow / up] : 0.f;
-        tile[row * PITCH + wave * (32 * NT) + n * 32 + l31] = acc[m][n][r] + bias;
+        tile[row * PITCH + wave * (32 * NT) + n * 32 + l31] = __builtin_fmaf(acc[m][n][r], p.w_descale, bias);
       }
   __syncthreads();
   const int T_out = p.T_q * up;
@@ -999,7 +999,7 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_f16x3_kernel(const ConvA
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int row = 8 * rg + 4 * lh + k;
-        float t = acc[n][4 * rg + k] + (row < p.rows_g ? p.bias1[row] : 0.f);
+        float t = __builtin_fmaf(acc[n][4 * rg + k], p.w_descale1, row < p.rows_g ? p.bias1[row] : 0.f);
         t = t > 0.f ? t : t * p.in_slope;
         v[k] = inside ? t : 0.f;
       }
@@ -1183,7 +1183,7 @@ __global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(
     float v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float t = acc[s][k] + bias1[k];
+      float t = __builtin_fmaf(acc[s][k], p.w_descale1, bias1[k]);
       t = t > 0.f ? t : t * p.in_slope;
       v[k] = inside ? t : 0.f;      // t1 outside the utterance is conv2's zero padding
     }
@@ -1242,7 +1242,7 @@ __global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(
     const unsigned yoff = ok ? (unsigned)((4 * g) * y_rb + q * 4) : OOB;
     float v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = acc[s][k] + bias2[k] + r[k];
+    for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(acc[s][k], p.w_descale, bias2[k]) + r[k];
     if (p.accum) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -1428,7 +1428,7 @@ __global__ void __launch_bounds__(256, 3) resblock_pair32_kernel(const ConvArgs 
       float v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float t = acc[0][n][4 * rg + k] + p.bias1[8 * rg + 4 * lh + k];
+        float t = __builtin_fmaf(acc[0][n][4 * rg + k], p.w_descale1, p.bias1[8 * rg + 4 * lh + k]);
         t = t > 0.f ? t : t * p.in_slope;
         v[k] = inside ? t : 0.f;
       }
@@ -1636,6 +1636,9 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
   a.res_scale = d->res_scale;
   a.res_toff = d->res_toff;
   a.res_tstride = d->res_tstride > 0 ? d->res_tstride : 1;
+  a.w_descale = d->w_descale != 0.f ? d->w_descale : 1.f;
+  a.w_descale1 = 1.f;
+  SAT_REQUIRE(d->mode != SAT_CONV_F32 || a.w_descale == 1.f, "conv1d: w_descale is a split-f16 option");
   {
     const long long ylim = (long long)a.rows_g * a.y_cs * 4;
     const long long rlim = d->res ? ((long long)a.rows_g * a.r_cs + (long long)a.T_q * a.res_tstride + a.res_toff) * 4 : 0;
@@ -1729,6 +1732,11 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
 
 extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
                                        const float* bias1, const void* w2_packed, float* y, void* stream) {
+  return sat_resblock_pair_scaled_f16x3(d, x, w1_packed, bias1, 1.f, w2_packed, y, stream);
+}
+
+extern "C" int sat_resblock_pair_scaled_f16x3(const sat_conv1d_desc* d, const float* x, const void* w1_packed,
+                                              const float* bias1, float w1_descale, const void* w2_packed, float* y, void* stream) {
   SAT_REQUIRE(d && w1_packed && w2_packed && bias1 && d->bias && (x || d->x_split) && (y || (d->no_y && d->y_split)),
               "resblock_pair: null pointer");
   SAT_REQUIRE(d->C_in == d->C_out && d->C_in % 16 == 0 &&
@@ -1760,6 +1768,8 @@ extern "C" int sat_resblock_pair_f16x3(const sat_conv1d_desc* d, const float* x,
   a.in_lrelu = 1; a.in_slope = d->in_slope;
   a.accum = d->accum; a.accum_div = d->accum_div;
   a.res_scale = 1.f; a.res_toff = 0; a.res_tstride = 1;
+  a.w_descale = d->w_descale != 0.f ? d->w_descale : 1.f;        // second conv (the epilogue's)
+  a.w_descale1 = w1_descale != 0.f ? w1_descale : 1.f;
   SAT_REQUIRE((long long)a.cin_g * a.x_cs * 4 < (1LL << 31) && (long long)a.rows_g * a.y_cs * 4 < (1LL << 31),
               "resblock_pair: slab too large for 31-bit offsets");
   a.fast_epi = 1;

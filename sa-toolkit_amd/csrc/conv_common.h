@@ -60,6 +60,10 @@ struct ConvArgs {
   int y16_f8;            // output planes carry (hi f16 | e4m3(hi) | e4m3(lo * 2^10)) instead of (hi f16 | lo f16)
   int k1_wrap;           // ring16 GEMM: K chunks >= k1_wrap read plane chunk (c - k1_wrap) one position later; 0 = none
   int pp_tiles_t, pp_total, pp_per_xcd, pp_nslots;   // persistent pair kernel: tiles per utterance / in all / per XCD, blocks per XCD
+  float w_descale;       // split-f16: the packed weights carry a power-of-two factor (packing.py: their largest magnitude moved
+                         // into the middle of the f16 range, so that lo = f16(w - hi) is a normal number for every weight
+                         // that matters); the accumulator is multiplied by its inverse before the bias — exact
+  float w_descale1;      // fused pair: the same for the first conv
 #ifdef SAT_STAMPS
   long long* dbg;        // diagnostic build (tools/stamp_conv.hip): per-block, per-chunk phase time stamps
 #endif
@@ -253,7 +257,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         // form cost ~20k cycles of scalar branching per block); the order of operations is the desc's
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[m][n][r] + bi[r];
+        for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(acc[m][n][r], p.w_descale, bi[r]);   // (the product is exact: one rounding, that of the sum)
         if (has_res && !p.res_after) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] += p.res_scale * rv[r];
@@ -366,7 +370,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         const int q = q_w + n * q_step + l31;
         if (q >= p.T_q || q >= q_end) continue;
         const int t = q * up + ph;
-        float v = acc[m][n][r] + bias;
+        float v = __builtin_fmaf(acc[m][n][r], p.w_descale, bias);
         if (rrow && !p.res_after) v += p.res_scale * rrow[(long long)t * p.res_tstride + p.res_toff];
         if (p.relu && p.relu_first) v = v > 0.f ? v : 0.f;
         if (p.ch_scale) v = v * sc + sh;
@@ -476,7 +480,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[
           yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yoff + r * y_rb, 0, 0));
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[m][n][r] + bi[r];
+      for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[m][n][r], p.w_descale, bi[r]);
       if (has_res && !p.res_after) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += p.res_scale * rv[r];

@@ -129,6 +129,7 @@ struct sat_hifigan {
     const void* w = nullptr;
     const float* bias = nullptr;
     int mode = SAT_CONV_F32;
+    float descale = 1.f;      // power-of-two descale of the packed weights (sat_conv1d_desc.w_descale)
   };
   std::vector<Conv> convs;
   int fuse_pairs = 1;
@@ -192,6 +193,15 @@ extern "C" int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const void* w_p
   h->convs[conv_id].w = w_packed;
   h->convs[conv_id].bias = bias;
   h->convs[conv_id].mode = mode;
+  h->convs[conv_id].descale = 1.f;
+  return SAT_OK;
+}
+
+extern "C" int sat_hifigan_set_conv_descale(sat_hifigan* h, int conv_id, float w_descale) {
+  SAT_REQUIRE(h && conv_id >= 0 && conv_id < (int)h->convs.size() && w_descale > 0.f, "hifigan_set_conv_descale: bad arguments");
+  SAT_REQUIRE(conv_id != h->id_post() && (h->convs[conv_id].mode != SAT_CONV_F32 || w_descale == 1.f),
+              "hifigan_set_conv_descale: only split-f16 convs carry a descale");
+  h->convs[conv_id].descale = w_descale;
   return SAT_OK;
 }
 
@@ -344,6 +354,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
       d.ksize = 7;
       d.pad_left = 3;
       d.bias = h->convs[0].bias;
+      d.w_descale = h->convs[0].descale;
       d.mode = SAT_CONV_F16X3;
       d.y_split = XS;
       d.y_split_slope = 0.1f;
@@ -365,6 +376,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         d.ksize = hi - lo + 1;
         d.pad_left = -lo;
         d.bias = h->convs[h->id_up(i)].bias;
+        d.w_descale = h->convs[h->id_up(i)].descale;
         d.mode = cmode;
         d.x_split = XS;
         // rates 2 and 4: the transposed conv writes the split planes itself (LDS-transposed epilogue); other
@@ -398,6 +410,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             for (int which = 0; which < 2; ++which) {
               m.w[j][pair][which] = h->convs[h->id_rb(i, j, pair, which)].w;
               m.bias[j][pair][which] = h->convs[h->id_rb(i, j, pair, which)].bias;
+              m.w_descale[j][pair][which] = h->convs[h->id_rb(i, j, pair, which)].descale;
             }
           }
         }
@@ -444,6 +457,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
           d2.in_lrelu = 1;
           d2.in_slope = 0.1f;
           d2.bias = cv2.bias;
+          d2.w_descale = cv2.descale;
           d2.mode = cmode;
           // the residual is the pair's input: from its split planes (hi + lo, leaky-relu undone) when the
           // format carries both halves, so no f32 copy of the activations is written inside a resblock
@@ -483,7 +497,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             df.x_split = rs;
             s = wait_prev_sum();
             if (s != SAT_OK) return s;
-            s = sat_resblock_pair_f16x3(&df, planes_res ? nullptr : rf, cv1.w, cv1.bias, cv2.w, dstf, stream_j);
+            s = sat_resblock_pair_scaled_f16x3(&df, planes_res ? nullptr : rf, cv1.w, cv1.bias, cv1.descale, cv2.w, dstf, stream_j);
             if (s != SAT_OK) return s;
           } else {
             sat_conv1d_desc d1 = base_desc(Cn, Cn, Tn, Tn, 1);
@@ -491,6 +505,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             d1.dilation = dil;
             d1.pad_left = (rk * dil - dil) / 2;
             d1.bias = cv1.bias;
+            d1.w_descale = cv1.descale;
             d1.mode = cmode;
             d1.x_split = rs;
             d1.y_split = T1s;
@@ -524,6 +539,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
     d.ksize = 7;
     d.pad_left = 3;
     d.bias = h->convs[0].bias;
+    d.w_descale = h->convs[0].descale;
     d.mode = h->convs[0].mode;
     int s = sat_conv1d_f32(&d, x, h->convs[0].w, X, stream);
     if (s != SAT_OK) return s;
@@ -544,6 +560,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
       d.in_lrelu = 1;
       d.in_slope = 0.1f;
       d.bias = h->convs[h->id_up(i)].bias;
+      d.w_descale = h->convs[h->id_up(i)].descale;
       d.mode = h->convs[h->id_up(i)].mode;
       int s = sat_conv1d_f32(&d, X, h->convs[h->id_up(i)].w, H, stream);
       if (s != SAT_OK) return s;
@@ -565,6 +582,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         d2.in_lrelu = 1;
         d2.in_slope = 0.1f;
         d2.bias = cv2.bias;
+        d2.w_descale = cv2.descale;
         d2.mode = cv2.mode;
         d2.res = r;
         d2.res_scale = 1.f;
@@ -582,7 +600,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
           // thin stages sit on the HBM roofline: one fused kernel, the intermediate stays in LDS
           sat_conv1d_desc df = d2;
           df.dilation = dil;
-          s = sat_resblock_pair_f16x3(&df, r, cv1.w, cv1.bias, cv2.w, dst, stream);
+          s = sat_resblock_pair_scaled_f16x3(&df, r, cv1.w, cv1.bias, cv1.descale, cv2.w, dst, stream);
           if (s != SAT_OK) return s;
         } else {
           sat_conv1d_desc d1 = base_desc(Cn, Cn, Tn, Tn, 1);
@@ -592,6 +610,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
           d1.in_lrelu = 1;
           d1.in_slope = 0.1f;
           d1.bias = cv1.bias;
+          d1.w_descale = cv1.descale;
           d1.mode = cv1.mode;
           s = sat_conv1d_f32(&d1, r, cv1.w, T1, stream);
           if (s != SAT_OK) return s;

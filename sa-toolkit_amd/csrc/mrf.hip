@@ -88,7 +88,7 @@ __device__ __forceinline__ void mrf_dma16(const uint4* lds_dst, const i32x4 rs, 
 // Wave w moves the 64-unit pieces w, w + 8 of the image; the piece that holds the biases zero-fills the 60 units
 // behind them (range check), which are the phantom tap's.
 template <int KS>
-__host__ __device__ constexpr int mrf_image_units() { return KS * 64 + 4; }
+__host__ __device__ constexpr int mrf_image_units() { return KS * 64 + 5; }     // taps, 16 biases, (descale, 0, 0, 0)
 template <int KS>
 __device__ __forceinline__ void mrf_stage_weights(uint4* slot, const uint4* image, int wave, int lane) {
   const i32x4 rs = mrf_rsrc(image, (unsigned)(mrf_image_units<KS>() * 16));
@@ -133,20 +133,27 @@ __device__ __forceinline__ void mrf_read_bias(float (&bv)[4], const uint4* slot,
   bv[0] = __builtin_bit_cast(float, v.x); bv[1] = __builtin_bit_cast(float, v.y);
   bv[2] = __builtin_bit_cast(float, v.z); bv[3] = __builtin_bit_cast(float, v.w);
 }
+template <int KS>
+__device__ __forceinline__ float mrf_read_descale(const uint4* slot) {
+  return __builtin_bit_cast(float, ((const unsigned*)(slot + KS * 64 + 4))[0]);
+}
 
 // packed weights + biases of every conv of the block -> the images mrf16_kernel stages (one block per conv)
 struct MrfPackArgs {
   const void* w[18];
   const float* bias[18];
   int ks[18], off[18];       // taps and first unit of conv n's image
+  float descale[18];
   int seg_bytes;             // co_pad * 16: bytes between the (tap, hi|lo, half) segments of the packing
 };
 __global__ void __launch_bounds__(256) mrf_pack_kernel(const MrfPackArgs a, uint4* __restrict__ blob) {
   const int n = blockIdx.x;
   const int nu = a.ks[n] * 64;
   const uint4* w = (const uint4*)a.w[n];
-  for (int u = threadIdx.x; u < nu + 4; u += 256)
-    blob[a.off[n] + u] = u < nu ? w[((u >> 4) * a.seg_bytes >> 4) + (u & 15)] : ((const uint4*)a.bias[n])[u - nu];
+  for (int u = threadIdx.x; u < nu + 5; u += 256)
+    blob[a.off[n] + u] = u < nu ? w[((u >> 4) * a.seg_bytes >> 4) + (u & 15)]
+                       : u < nu + 4 ? ((const uint4*)a.bias[n])[u - nu]
+                                    : make_uint4(__builtin_bit_cast(unsigned, a.descale[n]), 0u, 0u, 0u);
 }
 
 // B operand of one subtile (16 columns) for all tap pairs of a conv: read ahead of its MFMAs
@@ -359,6 +366,7 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
           float bias1[4];
           mrf_read_frags<KS>(fr, WA, j16, g);
           mrf_read_bias<KS>(bias1, WA, g);
+          const float dsc1 = mrf_read_descale<KS>(WA);
           mrf_stage_weights<KS>(WB, p.blob + woff + (2 * i + 1) * mrf_image_units<KS>(), wave, lane);
           const bool xfetch = last && i == 1 && more;         // the input image is dead from the second step of the last branch on
           if (xfetch) stage_x(next);
@@ -367,7 +375,7 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
           auto stage = [&](const int st, Epi& e, const f32x4 acc, const int sl) __attribute__((always_inline)) {
             if (st == 0) {
 #pragma unroll
-              for (int k = 0; k < 4; ++k) e.v[k] = acc[k] + bias1[k];
+              for (int k = 0; k < 4; ++k) e.v[k] = __builtin_fmaf(acc[k], dsc1, bias1[k]);
             } else if (st == 1) {
 #pragma unroll
               for (int k = 0; k < 4; ++k) e.v[k] = mrf_lrelu(e.v[k], p.slope);
@@ -401,6 +409,7 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
           float bias2[4];
           mrf_read_frags<KS>(fr, WB, j16, g);
           mrf_read_bias<KS>(bias2, WB, g);
+          const float dsc2 = mrf_read_descale<KS>(WB);
           if (i < 2) {
             mrf_stage_weights<KS>(WA, p.blob + woff + (2 * i + 2) * mrf_image_units<KS>(), wave, lane);
           } else {
@@ -421,7 +430,7 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
             if (i < 2) {
               if (st == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) e.v[k] = acc[k] + bias2[k] + xr[sl][k];
+                for (int k = 0; k < 4; ++k) e.v[k] = __builtin_fmaf(acc[k], dsc2, bias2[k]) + xr[sl][k];
               } else if (st == 1) {
                 if (edge) {                                    // x' outside the utterance is the next conv1's zero padding
                   const int pos = t0 - HP + 16 * (wave + 8 * sl) + jl;
@@ -447,7 +456,7 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
               const int si = sl & 3;
               if (st == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) e.v[k] = acc[k] + bias2[k] + xr[sl][k];
+                for (int k = 0; k < 4; ++k) e.v[k] = __builtin_fmaf(acc[k], dsc2, bias2[k]) + xr[sl][k];
               } else if (st == 1) {
                 if (!last) {
 #pragma unroll
@@ -568,7 +577,7 @@ extern "C" int sat_resblock_mrf_supported(int C, int n_branches, const int* ksiz
 
 static size_t mrf_scratch_units(int n_branches, const int* ksize) {
   size_t u = 0;
-  for (int j = 0; j < n_branches; ++j) u += (size_t)6 * (ksize[j] * 64 + 4);
+  for (int j = 0; j < n_branches; ++j) u += (size_t)6 * (ksize[j] * 64 + 5);
   return u;
 }
 
@@ -598,7 +607,8 @@ extern "C" int sat_resblock_mrf_f16x3(const sat_mrf_desc* d, void* stream) {
         pa.bias[n] = d->bias[j][i][c];
         pa.ks[n] = d->ksize[j];
         pa.off[n] = off;
-        off += d->ksize[j] * 64 + 4;
+        pa.descale[n] = d->w_descale[j][i][c] != 0.f ? d->w_descale[j][i][c] : 1.f;
+        off += d->ksize[j] * 64 + 5;
       }
   hipLaunchKernelGGL(mrf_pack_kernel, dim3(n), dim3(256), 0, s, pa, (uint4*)d->scratch);
   SAT_LAUNCH_CHECK("mrf_pack_kernel");

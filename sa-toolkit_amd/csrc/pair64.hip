@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs 
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float t = acc[m][0][4 * rg + k] + p.bias1[32 * m + 8 * rg + 4 * lh + k];
+          float t = __builtin_fmaf(acc[m][0][4 * rg + k], p.w_descale1, p.bias1[32 * m + 8 * rg + 4 * lh + k]);
           t = t > 0.f ? t : t * p.in_slope;
           v[k] = inside ? t : 0.f;
         }

@@ -594,6 +594,13 @@ __device__ float std_unbiased_par(const float* v, int n) {
 // a functor.  aux[i][j] = PCOST[j] + trans[i][j][t]; K[i] = LAST argmin_j; CCOST[i] = PCOST[K[i]] +
 // trans[K[i]][i][t] + local[i][t]; p_small = LAST argmin_i CCOST.  Back-trace P[t] = PRED[P[t+1]][t+1].
 // Lane (i*C + j) evaluates transition (i, j); lane l < C carries PCOST[l].
+// torch.argmin treats NaN as the smallest value and returns the FIRST one; the reference takes it on the flipped row
+// ("last minimum"), so a NaN cost beats every number and the LAST NaN of a row wins.  NaN costs are real: an utterance
+// whose median-filtered best track is all zero (noise: `rand` inputs) has mean_pitch = mean(empty) = NaN in
+// dynamic() (yaapt.py:326), and every voiced-to-voiced transition cost is NaN.
+__device__ __forceinline__ bool path1_takes(float cand, float best) {
+  return (cand != cand) || (!(best != best) && cand <= best);
+}
 template <int C, class TransFn>
 __device__ void path1_wave(const float* local, int ls, int T, TransFn trans, unsigned char* pred,
                            unsigned char* path_out) {
@@ -610,7 +617,7 @@ __device__ void path1_wave(const float* local, int ls, int T, TransFn trans, uns
 #pragma unroll
     for (int jj = 1; jj < C; ++jj) {
       const float vv = __shfl(v, i * C + jj, 64);
-      if (vv <= bv) { bv = vv; K = jj; }   // last minimum wins
+      if (path1_takes(vv, bv)) { bv = vv; K = jj; }   // last minimum wins
     }
     const float pcK = __shfl(pc, K, 64);
     const float cc = (pcK + trans(K, i, t)) + local[i * ls + t];
@@ -625,7 +632,7 @@ __device__ void path1_wave(const float* local, int ls, int T, TransFn trans, uns
 #pragma unroll
     for (int ii = 1; ii < C; ++ii) {
       const float cv = __shfl(pc, ii, 64);
-      if (cv <= jv) { jv = cv; p = ii; }
+      if (path1_takes(cv, jv)) { jv = cv; p = ii; }
     }
     if (T <= 1) p = 0;
   }

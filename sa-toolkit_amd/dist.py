@@ -23,10 +23,20 @@ def batches(lo, hi, batch_size):
     return [(s, min(s + batch_size, hi)) for s in range(lo, hi, batch_size)]
 
 
+def pcm16_rows(local):
+    """f32 waveforms -> the int16 PCM the reference writes (bin/pipeline.py:160, torchaudio.save(..., bits_per_sample=16):
+    round(x * 32768) clipped): half the bytes on the xGMI links (82 MB per rank instead of 164 at 512 utterances)"""
+    return (local * 32768.0).round_().clamp_(-32768.0, 32767.0).to(torch.int16)
+
+
 def all_gather_rows(local, n_items, group=None):
     """gather per-rank row blocks [n_local, ...] (contiguous shards of shard_bounds) into
     [n_items, ...] on every rank.  Equal shards use one all_gather_into_tensor; ragged shards are
     padded to the largest shard."""
+    if local is not None and local.dtype == torch.int16:
+        # ProcessGroupNCCL has no int16: the PCM rows travel as bytes
+        out = all_gather_rows(local.contiguous().view(torch.uint8), n_items, group)
+        return out.view(torch.int16)
     world = dist.get_world_size(group)
     sizes = [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
     mx = max(sizes)
@@ -49,14 +59,14 @@ def all_gather_rows(local, n_items, group=None):
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], 0)
 
 
-def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, local_out=None, before_gather=None):
+def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, local_out=None, before_gather=None, transform=None):
     """run `convert_fn(lo, hi) -> [hi-lo, ...]` over this rank's shard in fixed batches and
     (optionally) all-gather the results in global index order.
 
     `local_out` [shard rows, ...]: a preallocated buffer `convert_fn` fills itself (row `i - lo` for item `i`, e.g.
     from several HIP streams); its return values are then ignored and nothing is concatenated.  `before_gather()`
     runs after the last batch has been issued and before the collective (e.g. make the current stream wait for the
-    job streams).  Every rank must hold at least one item: with n_items < world some shard is empty, its rank has no
+    job streams); `transform(local)` then maps the shard to what is gathered (e.g. `pcm16_rows`).  Every rank must hold at least one item: with n_items < world some shard is empty, its rank has no
     rows to give the trailing shape of, and the collective would hang on the others — refused on ALL ranks before
     anything is launched (the reference's `split_dict` never produces more shards than entries either)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -72,6 +82,8 @@ def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, lo
         local = torch.cat(outs, 0)
     if before_gather is not None:
         before_gather()
+    if transform is not None:
+        local = transform(local)
     if not gather:
         return local
     return all_gather_rows(local, n_items, group)

@@ -111,6 +111,8 @@ class CoreHifiGan(CoreHifiGanParams):
                 wp = pack(w)
             packed.append((wp, b))
             check(l.sat_hifigan_set_conv(self._handle, i, ptr(wp), ptr(b), mode), "sat_hifigan_set_conv")
+            if mode == _lib.CONV_F16X3:      # the packed weights' power-of-two layer scale (packing.pack_conv_weight_f16x3)
+                check(l.sat_hifigan_set_conv_descale(self._handle, i, float(getattr(wp, "w_descale", 1.0))), "sat_hifigan_set_conv_descale")
         check(l.sat_hifigan_set_option(self._handle, b"split_acts", int(self.split_acts)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"branch_streams", int(self.branch_streams)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"fuse_pair64", int(self.fuse_pair64)), "sat_hifigan_set_option")

@@ -59,6 +59,7 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
     d.B, d.C_in, d.T_in, d.C_out, d.T_q = B, (c_in if c_in_w is None else int(c_in_w)), t_in, c_out, t_q
     d.ksize, d.dilation, d.stride, d.pad_left, d.groups, d.up = ksize, dilation, stride, pad_left, groups, up
     d.mode = int(mode)
+    d.w_descale = float(getattr(w_packed, "w_descale", 1.0))      # power-of-two layer scale of split-f16 packed weights (packing.py)
     d.in_lrelu = 0 if in_lrelu is None else 1
     d.in_slope = 0.0 if in_lrelu is None else float(in_lrelu)
     d.relu, d.gelu, d.res_after_act = int(relu), int(gelu), int(post_res is not None)
@@ -289,8 +290,10 @@ def resblock_pair(x, w1, b1, w2, b2, ksize, dilation, slope=0.1, out=None, accum
     if planes_residual:
         d.res_split, d.res_split_slope = ptr(x_split), float(slope)
     d.no_y = int(no_y)
-    check(lib().sat_resblock_pair_f16x3(C.byref(d), None if planes_residual else ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(out), stream()),
-          "sat_resblock_pair_f16x3")
+    d.w_descale = float(getattr(w2, "w_descale", 1.0))
+    check(lib().sat_resblock_pair_scaled_f16x3(C.byref(d), None if planes_residual else ptr(x), ptr(w1), ptr(b1),
+                                               float(getattr(w1, "w_descale", 1.0)), ptr(w2), ptr(out), stream()),
+          "sat_resblock_pair_scaled_f16x3")
     return out
 
 
@@ -308,6 +311,7 @@ def resblock_mrf(x_split, B, c, t, branches, slope=0.1, out=None, y_split=None, 
             d.dilation[j][i] = 2 * i + 1
             d.w[j][i][0], d.w[j][i][1] = ptr(w1), ptr(w2)
             d.bias[j][i][0], d.bias[j][i][1] = ptr(b1), ptr(b2)
+            d.w_descale[j][i][0], d.w_descale[j][i][1] = float(getattr(w1, "w_descale", 1.0)), float(getattr(w2, "w_descale", 1.0))
             keep += [w1, b1, w2, b2]
     d.slope = float(slope)
     d.x_split = ptr(x_split)

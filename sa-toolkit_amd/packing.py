@@ -53,17 +53,50 @@ def convtranspose_as_phase_conv(w: torch.Tensor, stride: int, padding: int):
     return wc, kp, pad_left
 
 
-def pack_conv_weight_f16x3(w: torch.Tensor, groups: int = 1, up: int = 1) -> torch.Tensor:
+class SplitRangeError(ValueError):
+    """weights that the split-f16 representation cannot carry (non-finite values)"""
+
+
+#: the largest |w| of a layer is moved into [2^(F16X3_TARGET_EXP - 1), 2^F16X3_TARGET_EXP) before the split: hi = f16(w') then
+#: stays far from the f16 limit (65504 = 2^16), and lo = f16(w' - hi) ~ 2^-11 w' is a NORMAL f16 (>= 2^-14) for every
+#: weight down to 2^-13 of the largest — without the scale a weight below 0.125 has a subnormal lo and the split only
+#: carries it to an ABSOLUTE 2^-25 (a layer of 1e-4-sized weights: 3e-4 relative)
+F16X3_TARGET_EXP = 10
+
+
+def f16x3_scale_exponent(w: torch.Tensor) -> int:
+    """power-of-two exponent e of the layer scale: the packed weights are w * 2^e, the kernels multiply the accumulator
+    by 2^-e (exact).  0 for an all-zero tensor; raises SplitRangeError for non-finite weights."""
+    if not bool(torch.isfinite(w).all()):
+        raise SplitRangeError("pack_conv_weight_f16x3: non-finite weights")
+    m = float(w.detach().abs().max())
+    if m == 0.0:
+        return 0
+    import math
+    e = F16X3_TARGET_EXP - (math.frexp(m)[1])        # m = f * 2^k, f in [0.5, 1): m * 2^e in [2^(TARGET-1), 2^TARGET)
+    return max(-100, min(100, e))                     # (2^-e and w * 2^e must stay normal f32)
+
+
+def pack_conv_weight_f16x3(w: torch.Tensor, groups: int = 1, up: int = 1, scale: bool = True) -> torch.Tensor:
     """split-f16 packing for SAT_CONV_F16X3: w [rows, C_in/groups, K] f32 ->
-    [g][cin_pad/16][K][2 (hi|lo)][2 (channel half)][co_pad][8] f16, hi = f16(w), lo = f16(w - hi)
-    (w - hi is exact in f32, so hi + lo carries 22 significand bits of w).  One (chunk, tap, part, half)
-    segment holds 8 channels of every row: the kernel copies 32*MT-row pieces of it straight into LDS."""
+    [g][cin_pad/16][K][2 (hi|lo)][2 (channel half)][co_pad][8] f16, hi = f16(w'), lo = f16(w' - hi), w' = w * 2^e
+    (w' - hi is exact in f32, so hi + lo carries 22 significand bits of w).  One (chunk, tap, part, half)
+    segment holds 8 channels of every row: the kernels copy 32*MT-row pieces of it straight into LDS.
+    The per-layer power-of-two scale (f16x3_scale_exponent; `scale=False`: e = 0) travels with the tensor as the
+    attribute `.w_descale` = 2^-e, which ops.conv1d / ops.resblock_pair / the generator hand to the kernels
+    (sat_conv1d_desc.w_descale): results are those of the unscaled weights to the last bit wherever the unscaled split
+    was exact to 22 bits, and stay 22-bit accurate for layers of any magnitude."""
+    e = f16x3_scale_exponent(w) if scale else 0
     p = pack_conv_weight(w, groups=groups, up=up)                    # [g][cin_pad][K][co_pad] f32
+    if e:
+        p = p * float(2.0 ** e)
     g, cin_pad, k, co_pad = p.shape
     p = p.reshape(g, cin_pad // 16, 2, 8, k, co_pad).permute(0, 1, 4, 2, 5, 3).contiguous()   # [g][nch][K][half][co][8]
     hi = p.to(torch.float16)
     lo = (p - hi.to(torch.float32)).to(torch.float16)
-    return torch.stack([hi, lo], dim=3).contiguous()                 # [g][nch][K][part][half][co][8]
+    out = torch.stack([hi, lo], dim=3).contiguous()                  # [g][nch][K][part][half][co][8]
+    out.w_descale = float(2.0 ** -e)
+    return out
 
 
 F8_W_HI_EXP, F8_W_LO_EXP, F8_X_LO_EXP = 6, 16, 10      # power-of-two scales of the e4m3 operands (csrc/conv1d_mfma.hip)

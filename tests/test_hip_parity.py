@@ -999,3 +999,87 @@ def test_fused_mrf_block_c16_equals_the_nine_launch_path(T, B):
     assert e_exact <= 1.5 * e_planes + 1e-7, (e_planes, e_exact)
     assert (y2 - y).abs().max().item() < 4e-6
     assert (ops.unsplit(ys2) - torch.where(y2 > 0, y2, y2 * 0.1)).abs().max().item() < 4e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# split-f16 over the range of a real checkpoint: the per-layer power-of-two weight scale (packing.py) keeps the
+# 22-bit split whatever the magnitude of a layer's weights; activations carry 22 bits down to |x| = 0.125 and an
+# ABSOLUTE 2^-24 below (f16 subnormals), and must stay below 65504
+# ---------------------------------------------------------------------------------------------
+REL_2M18 = 2.0 ** -18
+
+
+@pytest.mark.parametrize("wscale", [1e-5, 1e-3, 3e-2, 1.0, 10.0, 1e3], ids=lambda v: f"w{v:g}")
+def test_split_f16_weight_scale_sweep(wscale):
+    """a 7-tap conv on split planes (the generator's tile) and a 1024 -> 1024 1x1 conv (the ring GEMM of the wav2vec2
+    encoder) against float64, weights of every magnitude: relative error <= 2^-18 of the output scale.  Without the
+    layer scale a layer of 1e-5-sized weights only carries ~8 bits (asserted too: the scale is what fixes it)."""
+    ops, packing = _ops()
+    for (cin, cout, k, T) in [(64, 64, 7, 700), (1024, 1024, 1, 256)]:
+        x = _rand(2, cin, T, seed=1).to(DEV)
+        w = _rand(cout, cin, k, seed=2, scale=wscale / np.sqrt(cin * k))
+        b = _rand(cout, seed=3, scale=wscale)
+        ref = F.conv1d(x.double().cpu(), w.double(), b.double(), padding=(k - 1) // 2)
+        xs = ops.act_split(x, 1.0)
+        wp = packing.pack_conv_weight_f16x3(w.to(DEV))
+        y = ops.conv1d(x, wp, cout, k, bias=b.to(DEV), pad_left=(k - 1) // 2, mode=1, x_split=xs)
+        rel = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert rel <= REL_2M18, (cin, k, wscale, rel)
+        if wscale <= 1e-3:
+            wp0 = packing.pack_conv_weight_f16x3(w.to(DEV), scale=False)
+            assert wp0.w_descale == 1.0
+            y0 = ops.conv1d(x, wp0, cout, k, bias=b.to(DEV), pad_left=(k - 1) // 2, mode=1, x_split=xs)
+            rel0 = (y0.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+            assert rel0 > 4 * rel, (wscale, rel0, rel)
+
+
+@pytest.mark.parametrize("xscale", [1e-4, 1e-2, 0.1, 1.0, 1e2, 1e4], ids=lambda v: f"x{v:g}")
+def test_split_f16_activation_scale_sweep(xscale):
+    """the same two layers with activations of every magnitude.  From 0.1 to 1e4 (|x| < 65504) the result is within
+    2^-18 of the output scale; below, the split of x is an ABSOLUTE 2^-24 per element (lo is an f16 subnormal), so the
+    error bound is 2^-24 * sum |w| — both asserted, the second is the documented limit of the representation."""
+    ops, packing = _ops()
+    for (cin, cout, k, T) in [(64, 64, 7, 700), (1024, 1024, 1, 256)]:
+        x = (_rand(2, cin, T, seed=1).clamp(-5, 5) * xscale).to(DEV)
+        w = _rand(cout, cin, k, seed=2, scale=1.0 / np.sqrt(cin * k))
+        ref = F.conv1d(x.double().cpu(), w.double(), None, padding=(k - 1) // 2)
+        wp = packing.pack_conv_weight_f16x3(w.to(DEV))
+        for xs in (ops.act_split(x, 1.0), None):           # planes input, and f32 input split in the kernel (3 / 7 / 11 taps)
+            if xs is None and k == 1:
+                continue
+            y = ops.conv1d(x, wp, cout, k, pad_left=(k - 1) // 2, mode=1, x_split=xs)
+            err = (y.cpu().double() - ref).abs().max().item()
+            bound = REL_2M18 * ref.abs().max().item() + 2.0 ** -24 * w.abs().sum(dim=(1, 2)).max().item()
+            assert err <= bound, (cin, k, xscale, err, bound)
+            if xscale >= 0.1:
+                assert err <= REL_2M18 * ref.abs().max().item(), (cin, k, xscale, err)
+
+
+def test_generator_survives_rescaled_layer_pairs():
+    """leaky_relu is positively homogeneous: scaling conv1 (weight and bias) of every ResBlock1 step by 2^8 and its conv2
+    weight by 2^-8 leaves the generator's function unchanged while the inner activations t1 grow 256-fold and the conv2
+    weights shrink 256-fold (and the other way round).  The reference's f32 path does not care; here the layer scale of
+    the packed weights absorbs it: the waveform still matches the CPU oracle at < 1e-5 RMS (bar of the path: 1e-4)."""
+    import satools_amd
+    from satools_amd import synthetic
+    from oracle import hifigan as ogen
+    tag = "hifigan_bn_tdnnf_600h_vq_48_v1"
+    state, _ = synthetic.checkpoint(tag)
+    sd0 = state["base_model_state_dict"]
+    x = _rand(2, 504, 40, seed=7)
+    for shift in (8, -8):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        for k in list(sd):
+            if k.startswith("hifigan.resblocks.") and k.endswith("weight_g"):
+                which = "convs1" if ".convs1." in k else "convs2"
+                sd[k] = sd[k] * (2.0 ** shift if which == "convs1" else 2.0 ** -shift)
+            if k.startswith("hifigan.resblocks.") and ".convs1." in k and k.endswith(".bias"):
+                sd[k] = sd[k] * 2.0 ** shift
+        model = satools_amd.load_model("synthetic:" + tag)
+        model.load_state_dict(sd)
+        model.to(DEV)
+        y = model.hifigan(x.to(DEV))
+        gsd = {k[len("hifigan."):]: v for k, v in sd.items() if k.startswith("hifigan.")}
+        ref = ogen.generator(gsd, x)
+        err = rms(y.cpu().numpy() - ref.numpy())
+        assert err < 1e-5, (shift, err)

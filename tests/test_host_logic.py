@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.lib()
     header = open(os.path.join(ROOT, "include", "satools_hip.h")).read()
-    assert lib.sat_abi_version() == int(re.search(r"#define SAT_ABI_VERSION (\d+)", header).group(1)) == 2
+    assert lib.sat_abi_version() == int(re.search(r"#define SAT_ABI_VERSION (\d+)", header).group(1)) == 3
     declared = set(re.findall(r"\b(sat_[a-z0-9_]+)\s*\(", header))
     declared -= {"sat_status"}
     assert declared, "no declarations parsed"
@@ -162,6 +162,11 @@ def fill(a, b):
     buf[a - lo:b - lo] = torch.arange(a, b, dtype=torch.float32).view(-1, 1, 1)
 out2 = sdist.convert_sharded(fill, N, batch_size=4, local_out=buf, before_gather=lambda: hooked.append(1))
 assert hooked == [1] and torch.equal(out2, out)
+# the PCM16 gather (the int16 the reference writes, half the bytes): ragged shards, rows travel as bytes
+out3 = sdist.convert_sharded(lambda a, b: (torch.arange(a, b, dtype=torch.float32).view(-1, 1, 1) / 32768.0) * torch.ones(1, 1, 5),
+                             N, batch_size=4, transform=sdist.pcm16_rows)
+assert out3.dtype == torch.int16 and out3.shape == (N, 1, 5) and torch.equal(out3[:, 0, 0], torch.arange(N, dtype=torch.int16)), out3[:, 0, 0]
+assert torch.equal(sdist.pcm16_rows(torch.tensor([1.5, -1.5, 0.5 / 32768, 1.5 / 32768, -2.0])), torch.tensor([32767, -32768, 0, 2, -32768], dtype=torch.int16))
 # fewer items than ranks: refused on every rank before any collective (no hang)
 try:
     sdist.convert_sharded(conv, 1, batch_size=4)
