@@ -37,6 +37,7 @@ def build(args):
         def __init__(self, utt2spk):
             super().__init__()
             self.bn_extractor_model = args.asrbn_model
+            self._build_args = dict(args.__dict__)          # what `build(args)` was called with (frozen export)
             self.bn_extractor = infer_helper.load_model(self.bn_extractor_model, from_file=__file__, load_weight=False)
             self.bn_extractor.eval()
             self.f0_yaapt_opts = {

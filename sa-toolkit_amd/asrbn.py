@@ -118,6 +118,8 @@ class _TdnnfBase(nn.Module):
         return c
 
     def _prepare(self, device):
+        if self.__dict__.get("_frozen"):           # caches installed by frozen.load_frozen
+            return
         key = (self.precision,) + self._param_key()
         if self._cache_key == key:
             return

@@ -73,21 +73,13 @@ class CoreHifiGan(CoreHifiGanParams):
         return mods + [self.conv_post]
 
     def _prepare(self, device):
+        if self.__dict__.get("_frozen"):           # packed weights installed by frozen.load_frozen: no parameters to fold
+            return
         key = self._param_key()
         if self._packed_key == key and self._handle is not None:
             return
-        l = lib()
         _lib.cache_rebuild_begin(device, self._packed is not None)
-        if self._handle is None:
-            h = C.c_void_p()
-            dil = [d for ds in self.resblock_dilation_sizes for d in ds]
-            check(l.sat_hifigan_create(C.byref(h), self.imput_dim, self.upsample_initial_channel,
-                                       len(self.upsample_rates), _lib.int_array(self.upsample_rates),
-                                       _lib.int_array(self.upsample_kernel_sizes), len(self.resblock_kernel_sizes),
-                                       _lib.int_array(self.resblock_kernel_sizes), _lib.int_array(dil)),
-                  "sat_hifigan_create")
-            self._handle = h
-        packed = []
+        packed, modes = [], []
         mods = self._conv_modules()
         n_ups = len(self.ups)
         for i, m in enumerate(mods):
@@ -110,6 +102,25 @@ class CoreHifiGan(CoreHifiGanParams):
             else:
                 wp = pack(w)
             packed.append((wp, b))
+            modes.append(mode)
+        self._install_packed(packed, modes)
+        self._packed_key = key
+        _lib.cache_rebuild_end(device)
+
+    def _install_packed(self, packed, modes):
+        """hand the kernel-ready weights [(packed weight, bias)] of every conv to the C handle (also the entry point of
+        frozen.load_frozen, which brings them from a file instead of folding and packing parameters)"""
+        l = lib()
+        if self._handle is None:
+            h = C.c_void_p()
+            dil = [d for ds in self.resblock_dilation_sizes for d in ds]
+            check(l.sat_hifigan_create(C.byref(h), self.imput_dim, self.upsample_initial_channel,
+                                       len(self.upsample_rates), _lib.int_array(self.upsample_rates),
+                                       _lib.int_array(self.upsample_kernel_sizes), len(self.resblock_kernel_sizes),
+                                       _lib.int_array(self.resblock_kernel_sizes), _lib.int_array(dil)),
+                  "sat_hifigan_create")
+            self._handle = h
+        for i, ((wp, b), mode) in enumerate(zip(packed, modes)):
             check(l.sat_hifigan_set_conv(self._handle, i, ptr(wp), ptr(b), mode), "sat_hifigan_set_conv")
             if mode == _lib.CONV_F16X3:      # the packed weights' power-of-two layer scale (packing.pack_conv_weight_f16x3)
                 check(l.sat_hifigan_set_conv_descale(self._handle, i, float(getattr(wp, "w_descale", 1.0))), "sat_hifigan_set_conv_descale")
@@ -118,8 +129,7 @@ class CoreHifiGan(CoreHifiGanParams):
         check(l.sat_hifigan_set_option(self._handle, b"fuse_pair64", int(self.fuse_pair64)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"fuse_mrf", int(self.fuse_mrf)), "sat_hifigan_set_option")
         self._packed = packed  # keeps the device buffers alive
-        self._packed_key = key
-        _lib.cache_rebuild_end(device)
+        self._packed_modes = list(modes)
 
     def _workspace(self, B, T, device):
         # one workspace per launch stream: concurrent convert() calls on different streams (the

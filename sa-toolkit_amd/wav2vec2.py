@@ -163,6 +163,8 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
     fe_wrapped_gemm = int(os.environ.get("SATOOLS_AMD_W2V2_FE_WRAPPED_GEMM", "1"))
 
     def _prepare_w2v2(self, device):
+        if self.__dict__.get("_frozen"):           # caches installed by frozen.load_frozen
+            return self._w2
         key = (self.w2v2_precision,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.preprocessor.parameters())
         if self._w2_key == key:
             return self._w2

@@ -275,3 +275,31 @@ def test_sharded_job_runs_on_rccl_in_a_child_process():
         assert cfg["gathered_equals_shard"] is True, cfg
         assert cfg["gather_dtype"] == ("int16" if extra else "float32")
         assert line["n_gpus"] == 1 and line["value"] > 0
+
+
+@pytest.mark.parametrize("tag", [FBANK_TAG, W2V2_TAG])
+def test_frozen_export_round_trip(tmp_path, tag):
+    """satools_amd.export_frozen / load_frozen (the analogue of the reference's final.jit, hifigan/model.py:162-171): a
+    file of kernel-ready weights loads into the same Net interface without parameters and converts to the same bits"""
+    import satools_amd
+    from satools_amd import synthetic
+    model = satools_amd.load_model("synthetic:" + tag)
+    model.to(DEV)
+    model.eval()
+    wav = synthetic.harm_batch([0, 1], 16000).to(DEV)
+    tg = synthetic.targets(model.spk, [4, 5])
+    ref = model.convert(wav, target=tg)
+    path = str(tmp_path / "final.frozen")
+    satools_amd.export_frozen(model, path)
+    del model
+    torch.cuda.empty_cache()
+    fz = satools_amd.load_frozen(path, DEV)
+    assert sum(p.numel() for p in fz.parameters()) == 0          # inference-only: no f32 parameters on the device
+    assert fz.spk == sorted(set(fz.utt2spk.values()))
+    y = fz.convert(wav, target=tg)
+    assert torch.equal(y, ref)
+    assert torch.equal(fz.get_bn(wav), fz.get_bn(wav)) and fz.get_f0(wav).shape == (2, 50)
+    assert fz.eval() is None                                       # the reference's quirk survives
+    with pytest.raises(Exception):
+        satools_amd.export_frozen(fz, path + "2")                   # a frozen model has nothing left to export from
+    assert os.path.getsize(path) < (1.5e9 if "wav2vec2" in tag else 2.0e8)

@@ -23,7 +23,10 @@ def load(path, counter):
 
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    gen = lambda n: ("conv1d_f16x3" in n or "resblock_pair" in n or "convpost" in n or "act_split" in n)
+    w2v2 = len(sys.argv) > 3 and sys.argv[3] == "w2v2"
+    if w2v2:
+        return main_w2v2(fetch, write, int(sys.argv[4]) if len(sys.argv) > 4 else 5)
+    gen = lambda n: ("conv1d_f16x3" in n or "resblock_pair" in n or "convpost" in n or "act_split" in n or "mrf" in n)
     # generator forwards in that run: 3 convert() steps + 1 warm + 3 timed forwards of the roofline probe
     n_post = max(1, sum(v[0] for k, v in fetch.items() if "convpost_kernel" in k))
     out = {"generator_forwards_in_run": n_post, "kernels": {}}
@@ -40,6 +43,24 @@ def main():
                           "traffic_GB_raw": round((tot_f + tot_w) / n_post / 1e9, 3),
                           "traffic_GB_fetch_doubled": round((2 * tot_f + tot_w) / n_post / 1e9, 3),
                           "algorithmic_GB_per_layer_model": 23.405}
+    print(json.dumps(out, indent=1))
+
+
+def main_w2v2(fetch, write, n_fwd):
+    """every launch of `tools/w2v2_only.py` (get_bn of a batch of 32 = the wav2vec2 extractor + TDNNF tail + VQ), per forward"""
+    out = {"forwards_in_run": n_fwd, "kernels": {}}
+    tot_f = tot_w = 0.0
+    for name in sorted(set(fetch) | set(write)):
+        if name.startswith("at::") or "rocclr" in name:
+            continue                                   # load-time packing / fills of the process, not the path
+        f, w = fetch.get(name, [0, 0.0]), write.get(name, [0, 0.0])
+        out["kernels"][name] = {"launches": f[0], "fetch_GB": round(f[1] * 1024 / 1e9, 3), "write_GB": round(w[1] * 1024 / 1e9, 3)}
+        tot_f += f[1] * 1024
+        tot_w += w[1] * 1024
+    out["per_forward"] = {"fetch_GB_raw": round(tot_f / n_fwd / 1e9, 3), "fetch_GB_doubled": round(2 * tot_f / n_fwd / 1e9, 3),
+                          "write_GB": round(tot_w / n_fwd / 1e9, 3),
+                          "traffic_GB_fetch_doubled": round((2 * tot_f + tot_w) / n_fwd / 1e9, 3),
+                          "algorithmic_GB_per_layer_model": round((625e6 * 32 + 1.26e9) / 1e9, 3)}
     print(json.dumps(out, indent=1))
 
 
