@@ -130,6 +130,74 @@ def build(args):
             st.check()
             return y
 
+        def check_precision(self, wav=None, tol=2e-5, fallback=True):
+            """Load-time guard for the split-f16 arithmetic (f32 operands carried as hi + lo f16): run a
+            calibration utterance through the generator and the bottleneck extractor twice — as configured, and on the
+            exact-f32 MFMA kernels — and compare.  A checkpoint whose activations leave the f16 range (|x| >= 65504
+            saturates hi) or sit far below it (the split is only exact to an absolute 2^-24) shows up as a difference the
+            reference's plain-f32 path would not have; with `fallback` the offending part then STAYS on the exact-f32
+            kernels (16 x slower matrix work, same results as the reference) instead of degrading silently.
+            Returns {"generator": relative RMS difference, "bn_extractor": relative RMS difference of the bottleneck
+            projections (before the VQ decision), "bn_index_agreement": fraction of VQ indices equal, "fallback": [...]}.
+            `wav` [B, n] on any device (default: one synthetic 1 s voiced utterance).  Not for frozen models."""
+            import warnings
+            from . import synthetic
+            if self.hifigan.__dict__.get("_frozen"):
+                raise _lib.SatError("check_precision needs the f32 parameters: run it before export_frozen")
+            dev = self._device()
+            wav = synthetic.harm_batch([0], 16000) if wav is None else wav
+            wav = self._to_device(wav.detach().to(torch.float32))
+            out, fell = {}, []
+            gen, ext = self.hifigan, self.bn_extractor
+
+            def relrms(a, b):
+                a, b = a.double(), b.double()
+                d = torch.sqrt(torch.mean((a - b) ** 2))
+                return float("inf") if not bool(torch.isfinite(d)) else float(d / torch.sqrt(torch.mean(b ** 2)).clamp_min(1e-30))
+
+            with torch.no_grad():
+                # ---- bottleneck extractor: compare the projections the VQ decides on, and the decisions
+                cfg = {k: getattr(ext, k) for k in ("precision", "w2v2_precision") if hasattr(ext, k)}
+                if any(v != "f32" for v in cfg.values()):
+                    _, (z, idx, _) = ext.extract_bn(wav.clone(), want_aux=True)
+                    for k in cfg:
+                        setattr(ext, k, "f32")
+                    _, (z32, idx32, _) = ext.extract_bn(wav.clone(), want_aux=True)
+                    out["bn_extractor"] = relrms(z, z32)
+                    out["bn_index_agreement"] = float((idx == idx32).float().mean())
+                    if out["bn_extractor"] <= 5 * tol and out["bn_index_agreement"] >= 0.98:
+                        for k, v in cfg.items():
+                            setattr(ext, k, v)
+                    elif fallback:
+                        fell.append("bn_extractor")
+                    else:
+                        for k, v in cfg.items():
+                            setattr(ext, k, v)
+                # ---- generator, teacher-forced on the exact-f32 extractor's features
+                if gen.precision != "f32":
+                    f0 = self.get_f0(wav).unsqueeze(0)
+                    bn = self.get_bn(wav)
+                    f0n = f0.clone()
+                    ops.f0_norm_transform_(f0n)
+                    spk = F.one_hot(torch.zeros(wav.shape[0], dtype=torch.long), num_classes=len(self.spk))
+                    x = ops.assemble_input(bn, f0n.reshape(wav.shape[0], -1), spk.to(dev, torch.float32).contiguous(), spk.shape[1])
+                    keep = gen.precision
+                    y = gen(x)[0]
+                    gen.precision = "f32"
+                    y32 = gen(x)[0]
+                    out["generator"] = relrms(y, y32)
+                    if out["generator"] <= 50 * tol:          # waveform RMS ~0.1: 1e-3 relative = the path's 1e-4 bar
+                        gen.precision = keep
+                    elif fallback:
+                        fell.append("generator")
+                    else:
+                        gen.precision = keep
+            out["fallback"] = fell
+            if fell:
+                warnings.warn(f"satools_amd: {', '.join(fell)} left the range the split-f16 kernels represent on the calibration "
+                              f"utterance ({out}); running on the exact-f32 kernels instead (slower, reference-exact)")
+            return out
+
         def get_spk_id(self, wavinfo, target=None):
             if not target:
                 target = [self.utt2spk[wavinfo.name]]

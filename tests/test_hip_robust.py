@@ -303,3 +303,40 @@ def test_frozen_export_round_trip(tmp_path, tag):
     with pytest.raises(Exception):
         satools_amd.export_frozen(fz, path + "2")                   # a frozen model has nothing left to export from
     assert os.path.getsize(path) < (1.5e9 if "wav2vec2" in tag else 2.0e8)
+
+
+def test_check_precision_guards_against_out_of_range_checkpoints():
+    """Net.check_precision(): the load-time guard of the split-f16 arithmetic.  A sane checkpoint passes and keeps its
+    kernels; one whose inner activations exceed the f16 range (conv1 of every ResBlock step scaled by 2^18 against its
+    conv2 — the same function in exact arithmetic, t1 ~ 2e5 > 65504) is detected and falls back to the exact-f32
+    kernels, after which convert() matches the CPU oracle again instead of saturating silently"""
+    import warnings
+    import satools_amd
+    from oracle import convert as oconv
+    from satools_amd import synthetic
+    model = satools_amd.load_model("synthetic:" + FBANK_TAG)
+    model.to(DEV)
+    model.eval()
+    rep = model.check_precision()
+    print("check_precision on the synthetic checkpoint:", rep)
+    assert rep["fallback"] == [] and rep["generator"] < 2e-5 and rep["bn_index_agreement"] == 1.0 and rep["bn_extractor"] < 1e-4
+    assert model.hifigan.precision == "f16x3" and model.bn_extractor.precision == "f16x3"
+    state, _ = synthetic.checkpoint(FBANK_TAG)
+    sd = {k: v.clone() for k, v in state["base_model_state_dict"].items()}
+    for k in list(sd):
+        if k.startswith("hifigan.resblocks.") and k.endswith("weight_g"):
+            sd[k] = sd[k] * (2.0 ** 18 if ".convs1." in k else 2.0 ** -18)
+        if k.startswith("hifigan.resblocks.") and ".convs1." in k and k.endswith(".bias"):
+            sd[k] = sd[k] * 2.0 ** 18
+    model.load_state_dict(sd)
+    wav = synthetic.harm_batch([2], 16000)
+    f0 = _oracle_f0(wav)
+    ref = oconv.convert_fbank(sd, model.spk, wav, model.spk[1], f0)
+    bad = rms(model.convert(wav.to(DEV), target=model.spk[1]).cpu().numpy() - ref.numpy())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        rep = model.check_precision()
+    print("check_precision on the out-of-range checkpoint:", rep, "error before the guard", bad)
+    assert "generator" in rep["fallback"] and model.hifigan.precision == "f32" and w
+    good = rms(model.convert(wav.to(DEV), target=model.spk[1]).cpu().numpy() - ref.numpy())
+    assert bad > 1e-4 and good < 1e-5, (bad, good)
