@@ -130,7 +130,7 @@ class _TdnnfBase(nn.Module):
         self._cache_key = key
         _lib.cache_rebuild_end(device)
 
-    def _tdnnf_layer(self, lay, c, x, xs=None, return_bottleneck=False, want_aux=False):
+    def _tdnnf_layer(self, lay, c, x, xs=None, return_bottleneck=False, want_aux=False, row_frames=None):
         """x [B, feat, T] -> [B, out, T'] (or the bottleneck [B, bott, T']).  In split-f16 mode the layers
         hand their activations on as split planes as well (`xs`, csrc/conv1d_mfma.hip): linearB then
         stages its 1024 x 3 input with 16-byte copies and linearA reads the bottleneck from planes; the
@@ -141,6 +141,11 @@ class _TdnnfBase(nn.Module):
             # chain/nn.py:267-304: windows of the flattened input every 1.5 frames + the add_padd bypass
             assert ctx == 1 and not return_bottleneck and c.codebook is None
             win, byp = ops.tdnnf_unfold15(x)
+            if row_frames is not None:
+                # ragged rows: the reference's bypass of this layer takes int(T / 1.5) frames and zero-fills the rest of
+                # the windows (chain/nn.py:294-304) — T being the row's OWN frame count, not the padded batch's
+                for i, n in enumerate(row_frames):
+                    byp[i, :, int(n / 1.5):] = 0
             z = ops.conv1d(win, c.wB, lay.bottleneck_dim, 1, bias=c.bB, pad_left=0, pad_right=0, mode=c.modeB)
             kw = dict(res=byp, res_scale=lay.bypass_scale) if lay.use_bypass else {}
             ys = ops.split_like(B, lay.out_dim, z.shape[2], x.device) if (c.modeA == 1 and lay.out_dim % 16 == 0) else None
@@ -221,6 +226,64 @@ class _TdnnfBase(nn.Module):
             outs.append(ops.conv1d(h, w, odim, 1, bias=b, mode=c.modeA, x_split=hs))
         ops.log_softmax_channels_(outs[1])
         return outs[0].permute(0, 2, 1), outs[1].permute(0, 2, 1)
+
+
+    # ---- batched ASR forward of utterances of different lengths --------------------------------------------------
+    @staticmethod
+    def _layers_out_len(layers, T):
+        """frames after a run of TDNNF layers ('valid' windows of context_len frames every subsampling_factor frames;
+        1.5: windows of the flattened input every int(1.5 D) values, chain/nn.py:267-304)"""
+        for lay in layers:
+            if lay.subsampling_factor == 1.5:
+                T = ((T - 1) * lay.feat_dim) // int(1.5 * lay.feat_dim) + 1
+            else:
+                T = (T - lay.context_len) // int(lay.subsampling_factor) + 1
+        return T
+
+    def forward_ragged(self, wavs):
+        """`forward()` for a LIST of utterances of different lengths in two batched passes (the reference decodes one
+        utterance per call, chain/decoder.py:24-39; a batch of equal-length rows is all its `forward` takes):
+        wavs = [n_i] or [1, n_i] waveforms in [-1, 1] on the HIP device -> [(chain_out [T'_i, output_dim],
+        log_softmax(xent_out) [T'_i, output_dim])], each what `forward(wav_i[None])` returns.
+        Every layer is a 'valid' window over frames, so frame t of utterance i only ever reads utterance i's own
+        (individually replicate-padded) frames; rows are zero-filled behind their own length and cut at T'_i.  The two
+        `pad_input` steps (before the stack, before `tdnnfs_after`) are applied per utterance.  Inputs are not modified."""
+        if not hasattr(self, "_fbank_tables"):
+            # wav2vec2 front end: its positional conv and attention look at every frame of a row — one utterance per call
+            out = []
+            for w in wavs:
+                c, x = self.forward(w.reshape(1, -1).clone())
+                out.append((c[0], x[0]))
+            return out
+        dev = wavs[0].device
+        feats = [self.features(w.reshape(1, -1).to(torch.float32).contiguous(), scale=32768.0) for w in wavs]
+        B = len(feats)
+        L0 = [f.shape[2] for f in feats]
+        x = torch.zeros(B, feats[0].shape[1], max(L0), dtype=torch.float32, device=dev)
+        for i, f in enumerate(feats):
+            x[i, :, :L0[i]] = f[0]
+        full = self._prepare_full(dev)
+        layers = self._stack_layers()
+        xs = None
+        for lay, c in zip(layers, self._cache):
+            x, xs = self._tdnnf_layer(lay, c, x, xs)
+        T1 = [self._layers_out_len(layers, n) for n in L0]
+        pa = self.padding_after
+        x2 = torch.zeros(B, x.shape[1], max(T1) + 2 * pa, dtype=torch.float32, device=dev)
+        for i in range(B):
+            x2[i, :, :T1[i] + 2 * pa] = ops.pad_replicate(x[i:i + 1, :, :T1[i]].contiguous(), pa, pa, interleave_right=True)[0]
+        x, xs = x2, None
+        cur = [n + 2 * pa for n in T1]
+        for lay, c in full["after"]:
+            x, xs = self._tdnnf_layer(lay, c, x, xs, row_frames=cur)
+            cur = [self._layers_out_len([lay], n) for n in cur]
+        T2 = cur
+        outs = []
+        for (lay, c), (w, b, odim) in zip(full["prefinal"], full["out"]):
+            h, hs = self._tdnnf_layer(lay, c, x, xs)
+            outs.append(ops.conv1d(h, w, odim, 1, bias=b, mode=c.modeA, x_split=hs))
+        ops.log_softmax_channels_(outs[1])
+        return [(outs[0][i, :, :T2[i]].t(), outs[1][i, :, :T2[i]].t()) for i in range(B)]
 
 
 class _AsrHead(nn.Module):

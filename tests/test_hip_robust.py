@@ -340,3 +340,30 @@ def test_check_precision_guards_against_out_of_range_checkpoints():
     assert "generator" in rep["fallback"] and model.hifigan.precision == "f32" and w
     good = rms(model.convert(wav.to(DEV), target=model.spk[1]).cpu().numpy() - ref.numpy())
     assert bad > 1e-4 and good < 1e-5, (bad, good)
+
+
+def test_asr_forward_of_a_ragged_utterance_list():
+    """TdnnfVqNet.forward_ragged: utterances of 1 s, 2.5 s, 1.7 s and 0.6 s in two batched passes = `forward()` of each
+    utterance alone (what the reference's decoder driver feeds, chain/decoder.py:24-39), and the oracle's forward"""
+    import satools_amd
+    from oracle import tdnnf as otd
+    from satools_amd import synthetic
+    tag = "bn_tdnnf_600h_vq_48_v1"
+    net = satools_amd.load_model("synthetic:" + tag)
+    net.to(DEV)
+    net.eval()
+    lens = [16000, 40000, 27200, 9600]
+    wavs = [synthetic.harm_batch([20 + i], n)[0].to(DEV) for i, n in enumerate(lens)]
+    keep = [w.clone() for w in wavs]
+    got = net.forward_ragged(wavs)
+    assert all(torch.equal(a, b) for a, b in zip(wavs, keep))            # inputs untouched
+    for i, w in enumerate(wavs):
+        c1, x1 = net.forward(w.reshape(1, -1).clone())
+        assert got[i][0].shape == c1[0].shape and got[i][1].shape == x1[0].shape, (i, got[i][0].shape, c1.shape)
+        # the batch may be served by another tile shape of the same kernels than a single utterance: f32 re-association only
+        assert (got[i][0] - c1[0]).abs().max().item() < 2e-5 * max(1.0, c1.abs().max().item()), i
+        assert (got[i][1] - x1[0]).abs().max().item() < 2e-5 * max(1.0, x1.abs().max().item()), i
+    state, _ = synthetic.checkpoint(tag)
+    ref_c, ref_x = otd.forward_fbank(state["base_model_state_dict"], wavs[1].cpu().reshape(1, -1))
+    assert rms(got[1][0].cpu().numpy() - ref_c[0].numpy()) < 1e-4 * max(1.0, rms(ref_c[0].numpy()))
+    assert rms(got[1][1].cpu().numpy() - ref_x[0].numpy()) < 1e-4 * max(1.0, rms(ref_x[0].numpy()))
