@@ -57,6 +57,8 @@ int sat_clock_probe(int64_t* samples, int n, int period_us, void* stream);
  * next weights committed, after the barrier) for its first 4 tiles: buf[tile][80 stamps][8 waves].  NULL switches it
  * off.  Returns the number of int64 entries the buffer must hold.  Not thread-safe; never set on the product path. */
 int sat_mrf_debug_stamps(int64_t* buf);
+/* the same for sat_attention_f16x3 (tools/bench_attention.py stamps): block (0, 0, 0), 7 points of the first key block x 8 waves */
+int sat_attention_debug_stamps(int64_t* buf);
 
 /* ------------------------------------------------------------------------------------------
  * Fused 1-D convolution as an implicit GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32;

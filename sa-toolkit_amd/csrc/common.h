@@ -93,6 +93,27 @@ __device__ __forceinline__ float erf_fast(float x) {
   return ax < 0.6f ? s : big;
 }
 __device__ __forceinline__ float gelu_fast(float v) { return v * 0.5f * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
+
+// ---- asynchronous global -> LDS copies (LDS-DMA: buffer_load_dwordx4 ... lds, 64 lanes x 16 bytes = 1 KB contiguous in
+// LDS per instruction, no staging registers), issued through inline asm: with the builtin, hipcc waits for the copy
+// before the next ds_read it cannot prove disjoint (the whole phase), and it knows nothing of these, so the kernel counts
+// them itself: every wait for them below is an explicit s_waitcnt vmcnt.  M0 carries the LDS byte address (saved and
+// restored: hipcc owns M0).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 dma_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void lds_dma16(const uint4* lds_dst, const i32x4 rs, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);      // wave-uniform by construction
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(la), "v"(voff), "s"(rs), "s"(soff)
+               : "memory");
+#endif
+}
 #endif
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

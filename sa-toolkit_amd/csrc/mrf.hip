@@ -60,27 +60,6 @@ struct MrfFrags {               // A operand of one conv, resident in registers 
   h8 hi[NTP], lo[NTP];
 };
 
-// ---- asynchronous global -> LDS copies (LDS-DMA: buffer_load_dwordx4 ... lds, 64 lanes x 16 bytes = 1 KB contiguous in
-// LDS per instruction, no staging registers), issued through inline asm: with the builtin, hipcc waits for the copy
-// before the next ds_read it cannot prove disjoint (the whole phase), and it knows nothing of these, so the kernel counts
-// them itself: every wait for them below is an explicit s_waitcnt vmcnt.  M0 carries the LDS byte address (saved and
-// restored: hipcc owns M0).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 mrf_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-__device__ __forceinline__ void mrf_dma16(const uint4* lds_dst, const i32x4 rs, unsigned voff, unsigned soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);      // wave-uniform by construction
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "s"(la), "v"(voff), "s"(rs), "s"(soff)
-               : "memory");
-#endif
-}
-
 // Weights of the NEXT conv travel to their LDS slot while the current conv runs.  They come from ONE buffer that holds
 // every conv of the block as the image the slot takes ([tap][hi|lo][half][16 rows] units = the packing without its
 // padding rows, then 4 units of biases): a conv's address is arithmetic on the scalar unit — with one pointer per conv in
@@ -91,11 +70,11 @@ template <int KS>
 __host__ __device__ constexpr int mrf_image_units() { return KS * 64 + 5; }     // taps, 16 biases, (descale, 0, 0, 0)
 template <int KS>
 __device__ __forceinline__ void mrf_stage_weights(uint4* slot, const uint4* image, int wave, int lane) {
-  const i32x4 rs = mrf_rsrc(image, (unsigned)(mrf_image_units<KS>() * 16));
+  const i32x4 rs = dma_rsrc(image, (unsigned)(mrf_image_units<KS>() * 16));
 #pragma unroll
   for (int r = 0; r < (KS + 1 + 7) / 8; ++r) {
     const int piece = wave + 8 * r;
-    if (piece <= KS) mrf_dma16(slot + piece * 64, rs, (unsigned)(lane * 16), (unsigned)(piece * 1024));
+    if (piece <= KS) lds_dma16(slot + piece * 64, rs, (unsigned)(lane * 16), (unsigned)(piece * 1024));
   }
 }
 // LDS-DMA instructions mrf_stage_weights issues on this wave
@@ -263,12 +242,12 @@ __global__ void __launch_bounds__(MRF_THREADS, 1) mrf16_kernel(const MrfArgs p) 
   auto stage_x = [&](int tl) __attribute__((always_inline)) {
     const int ub = __builtin_amdgcn_readfirstlane(tl / p.tiles_t);
     const int pos0 = (tl - ub * p.tiles_t) * MRF_W - HP + xhf * 320;
-    const i32x4 xrs = mrf_rsrc((const char*)p.x16 + (long long)ub * 16 * p.T * 4, (unsigned)(16 * p.T * 4));
+    const i32x4 xrs = dma_rsrc((const char*)p.x16 + (long long)ub * 16 * p.T * 4, (unsigned)(16 * p.T * 4));
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
       const int pos = pos0 + lane + 64 * it;
       const unsigned voff = (pos >= 0 && pos < p.T) ? (unsigned)((xpl * p.T + pos) * 16) : OOB;
-      mrf_dma16(X0 + xpl * WP + xhf * 320 + 64 * it, xrs, voff, 0u);
+      lds_dma16(X0 + xpl * WP + xhf * 320 + 64 * it, xrs, voff, 0u);
     }
   };
 

@@ -259,53 +259,99 @@ __device__ __forceinline__ void split8(const float (&a)[8], h8& hi, h8& lo) {
   }
 }
 
-// NW waves per block = 32 NW queries: 8 (one block per head at 249 frames: K and V are fetched and staged ONCE per head — with
-// four-wave blocks the two query blocks of a head each did it, and the kernel moves ~130 MB per launch at 2-3 TB/s) or 4
+// NW waves per block = 32 NW queries: 8 (one block per head at 249 frames: K and V are fetched and staged ONCE per head) or 4
 // (utterances of up to 128 frames).
+//
+// Round 3: the kernel was a chain of exposed loads — by its own cycle stamps (tools/bench_attention.py stamps) a head took
+// 46.5 k cycles of which 15.4 k waited for K and Q and 9.3 k for V to arrive through registers, one 8-wave block per CU (256
+// VGPRs).  Now a block walks HPB heads (and, for utterances longer than 256 frames, their key blocks) as STAGES over two LDS
+// regions A / B that swap roles, every operand arriving by LDS-DMA (inline asm, counted waits) one stage ahead:
+//   stage s:  K_s in R = A or B;  V_s (f32 rows) in the other region R';  split V image over K_s in R
+//     Q fragments <- global | wait K_s | barrier | DMA V_s -> R'          (R' is free: the image of stage s - 1 is done)
+//     S = K^T Q, softmax                                                   (V_s lands underneath)
+//     wait V_s | barrier | V_s f32 (R') -> hi | lo f16 fragment image (R) | barrier | DMA K_{s+1} -> R'
+//     O += V P                                                             (K_{s+1} lands underneath)
+//     barrier (the image is no longer read)
+// Only the first K of a block is waited for in the open.
+// diagnostics (sat_attention_debug_stamps): block (0, 0, 0) records its waves' cycle counters at 7 points of its first stage
+#define AT_STAMP(i)                                                                                          \
+  do {                                                                                                       \
+    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      unsigned long long t_;                                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      if (lane == 0) dbg[(i) * 8 + wave] = (long long)t_;                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
+  } while (0)
+
 template <int NW>
-__global__ void __launch_bounds__(64 * NW, 2) attention_f16x3_kernel(const uint4* __restrict__ qs, const uint4* __restrict__ ks,
+__global__ void __launch_bounds__(64 * NW, 1) attention_f16x3_kernel(const uint4* __restrict__ qs, const uint4* __restrict__ ks,
                                                                 const float* __restrict__ v, float* __restrict__ o,
-                                                                uint4* __restrict__ os, int C, int T, int v_pitch, float scale) {
+                                                                uint4* __restrict__ os, int C, int T, int v_pitch, float scale,
+                                                                int hpb, long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) uint4 at_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  constexpr int REG_UNITS = 2 * 64 * AT_VU;      // one region: the split V image (66 KB) >= K planes (16 x 256 units) = V f32 rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z;
   constexpr int NTHR = 64 * NW;
   const int q = blockIdx.x * (32 * NW) + wave * 32 + l31;     // this lane's query column
   const bool qok = q < T;
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   const size_t ub = (size_t)b * (C / 4) * T;                 // units per utterance: C * T * 4 bytes
+  const float scale2 = scale * 1.44269504088896340736f;      // softmax through the hardware exp2
+  const int nkb = (T + 255) >> 8;                            // key blocks of 256 per head
+  const int nst = hpb * nkb;                                 // stages of this block
+  const int h0 = blockIdx.y * hpb;
+  const i32x4 krs = dma_rsrc((const char*)ks + ub * 16, (unsigned)((size_t)C * T * 4));
+
+  // LDS-DMA of a stage's K planes: 16 plane rows x 256 keys = 64 pieces of 64 units, 64 / NW per wave; keys >= T arrive as zeros
+  auto dma_k = [&](uint4* reg, int hh, int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 64 / NW; ++r) {
+      const int piece = wave + NW * r, row = piece >> 2, col = (piece & 3) * 64 + lane;
+      const unsigned voff = k0 + col < T ? (unsigned)((((4 * hh + (row >> 2)) * 4 + (row & 3)) * T + k0 + col) * 16) : 0x80000000u;
+      lds_dma16(reg + row * 256 + (piece & 3) * 64, krs, voff, 0u);
+    }
+  };
+  // ... and of its V rows (f32 [64 head dims][256 keys]): a piece = one head dim; columns >= v_pitch arrive as zeros, columns in
+  // [T, v_pitch) carry whatever the caller's buffer holds and are masked when the image is built
+  auto dma_v = [&](uint4* reg, int hh, int k0) __attribute__((always_inline)) {
+    const i32x4 vrs = dma_rsrc(v + ((size_t)b * C + (size_t)hh * 64) * v_pitch, (unsigned)(64 * v_pitch * 4));
+#pragma unroll
+    for (int r = 0; r < 64 / NW; ++r) {
+      const int d = wave + NW * r, jg = k0 + lane * 4;
+      lds_dma16(reg + d * 64, vrs, jg < v_pitch ? (unsigned)((d * v_pitch + jg) * 4) : 0x80000000u, 0u);
+    }
+  };
 
   f32x16 oa[2];
-#pragma unroll
-  for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oa[m2][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;          // running maximum and sum of this lane's query column
-  // softmax through the hardware exp2 (one quarter-rate instruction) instead of expf's ~15-instruction expansion: 256
-  // exponentials per lane and key block were the longest VALU stretch of the kernel
-  const float scale2 = scale * 1.44269504088896340736f;
-  const float* vb = v + ((size_t)b * C + (size_t)h * 64) * v_pitch;
-  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (unsigned)(64 * v_pitch * 4), 0x00020000);
-
-  // keys in blocks of 256 (one block for T <= 256); longer utterances keep a running softmax over the blocks
-  for (int k0 = 0; k0 < T; k0 += 256) {
-    // ---- K planes of the head, keys k0 .. k0 + 255 -> LDS [chunk*4 + plane][256] (keys >= T zero) ----
-    __syncthreads();                        // the previous block's V is no longer read
+  AT_STAMP(0);
+  dma_k(at_lds, h0, 0);
+  for (int s = 0; s < nst; ++s) {
+    const int hh = h0 + s / nkb, k0 = (s % nkb) * 256;
+    uint4* R = at_lds + (s & 1) * REG_UNITS;
+    uint4* Rp = at_lds + ((s & 1) ^ 1) * REG_UNITS;
+    if (k0 == 0) {
 #pragma unroll
-    for (int r = 0; r < 4096 / NTHR; ++r) {
-      const int i = r * NTHR + tid, row = i >> 8, col = i & 255;     // unit (plane row, key)
-      at_lds[i] = k0 + col < T ? ks[ub + (size_t)((4 * h + (row >> 2)) * 4 + (row & 3)) * T + k0 + col] : zero4;
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[m2][r] = 0.f;
+      m_run = -INFINITY;
+      l_run = 0.f;
     }
-    // Q fragments of the wave's 32 queries (re-read per key block from L2: holding them across the V product
-    // would spill registers)
+    // Q fragments of the wave's 32 queries (re-read per stage from L2: holding them across the V product would spill)
     h8 qh[4], ql[4];
 #pragma unroll
     for (int cl = 0; cl < 4; ++cl) {
-      const size_t u = ub + (size_t)((4 * h + cl) * 4 + lh) * T + q;
+      const size_t u = ub + (size_t)((4 * hh + cl) * 4 + lh) * T + q;
       qh[cl] = __builtin_bit_cast(h8, qok ? qs[u] : zero4);
       ql[cl] = __builtin_bit_cast(h8, qok ? qs[u + 2 * (size_t)T] : zero4);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // K_s has landed everywhere (and Q; hipcc does not count the DMAs)
+    dma_v(Rp, hh, k0);
+    if (s == 0) AT_STAMP(1);
 
     // ---- S^T = K^T Q: 8 key tiles x (4 chunks of 16 channels) ----
     f32x16 st[8];
@@ -319,8 +365,8 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_f16x3_kernel(const uint4
       h8 ka[2][2];
       auto ldk = [&](int buf, int i) __attribute__((always_inline)) {
         const int cl = i >> 3, m = i & 7;
-        ka[buf][0] = __builtin_bit_cast(h8, at_lds[(cl * 4 + 0 + lh) * 256 + 32 * m + l31]);
-        ka[buf][1] = __builtin_bit_cast(h8, at_lds[(cl * 4 + 2 + lh) * 256 + 32 * m + l31]);
+        ka[buf][0] = __builtin_bit_cast(h8, R[(cl * 4 + 0 + lh) * 256 + 32 * m + l31]);
+        ka[buf][1] = __builtin_bit_cast(h8, R[(cl * 4 + 2 + lh) * 256 + 32 * m + l31]);
       };
       ldk(0, 0);
 #pragma unroll
@@ -334,6 +380,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_f16x3_kernel(const uint4
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (s == 0) AT_STAMP(2);
     // ---- softmax over keys: register r of tile m is key k0 + 32m + 8(r>>2) + 4lh + (r&3) ----
     float mx = m_run;
 #pragma unroll
@@ -363,30 +410,20 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_f16x3_kernel(const uint4
     for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oa[m2][r] *= alpha;
+    if (s == 0) AT_STAMP(3);
 
-    // ---- V of the head (f32 [64][v_pitch]), keys k0 .. -> LDS, split to hi | lo f16 ONCE and laid out as the A
-    // fragments of the second product: unit [part][d][16 k-steps x 2 lane halves] (row pitch AT_VU units: 4 banks apart,
-    // conflict-free 16-byte reads down a column of d) holding the keys 16 ks + 4 lh + {0..3} and 16 ks + 8 + 4 lh + {0..3}
-    // — the k-slot order of the P registers.  (Before: f32 rows in LDS and every wave of both query blocks split the
-    // same V on the fly, ~770 VALU instructions per wave and key block next to 96 MFMAs.)  Keys >= T zero.
-    __syncthreads();                        // every wave is done with K
-    // batches of eight 16-byte loads per lane, each batch in flight at once (a buffer descriptor's range check
-    // instead of a branch around every load: the branchy form ran sixteen global round trips one after the other)
+    // ---- V_s: f32 rows in R' -> split to hi | lo f16 ONCE, laid out as the A fragments of the second product over K_s in R:
+    // unit [part][d][16 k-steps x 2 lane halves] (row pitch AT_VU units: 4 banks apart, conflict-free 16-byte reads down a
+    // column of d) holding the keys 16 ks + 4 lh + {0..3} and 16 ks + 8 + 4 lh + {0..3} — the k-slot order of the P
+    // registers.  Keys >= T zero.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // V_s has landed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everywhere, and every wave is done with K_s
+    if (s == 0) AT_STAMP(4);
 #pragma unroll
-    for (int hb = 0; hb < 512 / NTHR; ++hb) {
-    float4 wv[8];
-#pragma unroll
-    for (int i8 = 0; i8 < 8; ++i8) {
-      const int u = tid + NTHR * (8 * hb + i8);
-      const int d = u >> 6, jg = k0 + (u & 63) * 4;
-      const unsigned off = jg < v_pitch ? (unsigned)((d * v_pitch + jg) * 4) : 0x80000000u;
-      wv[i8] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(vrs, off, 0, 0));
-    }
-#pragma unroll
-    for (int i8 = 0; i8 < 8; ++i8) {
-      const int u = tid + NTHR * (8 * hb + i8);  // float4 index: row d = u / 64, keys k0 + 4 (u % 64) ..
+    for (int i8 = 0; i8 < 4096 / NTHR; ++i8) {
+      const int u = tid + NTHR * i8;             // float4 index: row d = u / 64, keys k0 + 4 (u % 64) ..
       const int d = u >> 6, j4 = (u & 63) * 4, jg = k0 + j4;
-      float4 w = wv[i8];
+      float4 w = __builtin_bit_cast(float4, Rp[u]);
       if (jg + 0 >= T) w.x = 0.f;
       if (jg + 1 >= T) w.y = 0.f;
       if (jg + 2 >= T) w.z = 0.f;
@@ -396,70 +433,74 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_f16x3_kernel(const uint4
       const auto l01 = __builtin_amdgcn_cvt_pkrtz(w.x - (float)h01[0], w.y - (float)h01[1]);
       const auto l23 = __builtin_amdgcn_cvt_pkrtz(w.z - (float)h23[0], w.w - (float)h23[1]);
       // keys j4 .. j4 + 3 of the block: k-step j4 / 16, lane half (j4 / 4) & 1, first or second 8 bytes of the unit
-      uint2* dst = (uint2*)(at_lds + d * AT_VU + (j4 >> 4) * 2 + ((j4 >> 2) & 1)) + ((j4 >> 3) & 1);
+      uint2* dst = (uint2*)(R + d * AT_VU + (j4 >> 4) * 2 + ((j4 >> 2) & 1)) + ((j4 >> 3) & 1);
       dst[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
       dst[2 * 64 * AT_VU] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
     }
-    }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the image is complete, the f32 rows are no longer read
+    if (s + 1 < nst) dma_k(Rp, h0 + (s + 1) / nkb, ((s + 1) % nkb) * 256);
+    if (s == 0) AT_STAMP(5);
 
     // ---- O += V P: 2 row tiles (64 head dims) x 16 k-steps of 16 keys ----
     {
       h8 va[2][2][2];                       // [buffer][row tile][hi | lo]: the next k-step's V fragments are read ahead
-      auto ldv = [&](int buf, int ks) __attribute__((always_inline)) {
+      auto ldv = [&](int buf, int kst) __attribute__((always_inline)) {
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2) {
-          const uint4* vu = at_lds + (32 * m2 + l31) * AT_VU + ks * 2 + lh;
+          const uint4* vu = R + (32 * m2 + l31) * AT_VU + kst * 2 + lh;
           va[buf][m2][0] = __builtin_bit_cast(h8, vu[0]);
           va[buf][m2][1] = __builtin_bit_cast(h8, vu[64 * AT_VU]);
         }
       };
       ldv(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {     // k-step ks = keys 16 ks .. 16 ks + 15 = registers 8 (ks & 1) .. of tile ks / 2
-        const int m = ks >> 1, hh = ks & 1;
-        if (ks + 1 < 16) ldv((ks + 1) & 1, ks + 1);
+      for (int kst = 0; kst < 16; ++kst) {  // k-step = keys 16 kst .. 16 kst + 15 = registers 8 (kst & 1) .. of tile kst / 2
+        const int m = kst >> 1, hh2 = kst & 1;
+        if (kst + 1 < 16) ldv((kst + 1) & 1, kst + 1);
         float pv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pv[e] = st[m][8 * hh + e];
+        for (int e = 0; e < 8; ++e) pv[e] = st[m][8 * hh2 + e];
         h8 b_hi, b_lo;
         split8(pv, b_hi, b_lo);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2) {
-          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[ks & 1][m2][1], b_hi, oa[m2], 0, 0, 0);
-          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[ks & 1][m2][0], b_lo, oa[m2], 0, 0, 0);
-          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[ks & 1][m2][0], b_hi, oa[m2], 0, 0, 0);
+          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[kst & 1][m2][1], b_hi, oa[m2], 0, 0, 0);
+          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[kst & 1][m2][0], b_lo, oa[m2], 0, 0, 0);
+          oa[m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[kst & 1][m2][0], b_hi, oa[m2], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-  }
-  const float inv = 1.0f / l_run;
-  if (!qok) return;
-  // ---- store: register r of tile m2 is head dim 32 m2 + 8 (r>>2) + 4 lh + (r&3) ----
+    if (s == 0) AT_STAMP(6);
+    if (k0 + 256 >= T && qok) {
+      // ---- the head is complete: store; register r of tile m2 is head dim 32 m2 + 8 (r>>2) + 4 lh + (r&3) ----
+      const float inv = 1.0f / l_run;
 #pragma unroll
-  for (int m2 = 0; m2 < 2; ++m2) {
+      for (int m2 = 0; m2 < 2; ++m2) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float w[4];
+        for (int g = 0; g < 4; ++g) {
+          float w[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) w[k] = oa[m2][4 * g + k] * inv;
-      const int c = h * 64 + 32 * m2 + 8 * g;               // first channel of the 8-channel unit (this lane: + 4 lh)
-      if (o) {
+          for (int k = 0; k < 4; ++k) w[k] = oa[m2][4 * g + k] * inv;
+          const int c = hh * 64 + 32 * m2 + 8 * g;               // first channel of the 8-channel unit (this lane: + 4 lh)
+          if (o) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[((size_t)b * C + c + 4 * lh + k) * T + q] = w[k];
-      }
-      if (os) {
-        const auto h01 = __builtin_amdgcn_cvt_pkrtz(w[0], w[1]);
-        const auto h23 = __builtin_amdgcn_cvt_pkrtz(w[2], w[3]);
-        const auto l01 = __builtin_amdgcn_cvt_pkrtz(w[0] - (float)h01[0], w[1] - (float)h01[1]);
-        const auto l23 = __builtin_amdgcn_cvt_pkrtz(w[2] - (float)h23[0], w[3] - (float)h23[1]);
-        const size_t un = ub + (size_t)((c >> 4) * 4 + ((c >> 3) & 1)) * T + q;
-        ((uint2*)(os + un))[lh] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-        ((uint2*)(os + un + 2 * (size_t)T))[lh] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+            for (int k = 0; k < 4; ++k) o[((size_t)b * C + c + 4 * lh + k) * T + q] = w[k];
+          }
+          if (os) {
+            const auto h01 = __builtin_amdgcn_cvt_pkrtz(w[0], w[1]);
+            const auto h23 = __builtin_amdgcn_cvt_pkrtz(w[2], w[3]);
+            const auto l01 = __builtin_amdgcn_cvt_pkrtz(w[0] - (float)h01[0], w[1] - (float)h01[1]);
+            const auto l23 = __builtin_amdgcn_cvt_pkrtz(w[2] - (float)h23[0], w[3] - (float)h23[1]);
+            const size_t un = ub + (size_t)((c >> 4) * 4 + ((c >> 3) & 1)) * T + q;
+            ((uint2*)(os + un))[lh] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+            ((uint2*)(os + un + 2 * (size_t)T))[lh] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+          }
+        }
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the image of this stage is no longer read: V_{s+1} may land on it
   }
 }
 
@@ -562,13 +603,19 @@ extern "C" int sat_transpose_heads_f32(const float* v, float* vt, int G, int D, 
   return SAT_OK;
 }
 
+static long long* g_attention_dbg = nullptr;
+extern "C" int sat_attention_debug_stamps(int64_t* buf) {
+  g_attention_dbg = (long long*)buf;
+  return 7 * 8;
+}
+
 extern "C" int sat_attention_f16x3(const void* q_split, const void* k_split, const float* v, float* o, void* o_split, int B,
                                    int heads, int head_dim, int T, int v_pitch, float scale, void* stream) {
   SAT_REQUIRE(q_split && k_split && v && (o || o_split), "attention: null pointer");
   SAT_REQUIRE(B > 0 && heads > 0 && T > 0, "attention: empty shape");
   SAT_REQUIRE(head_dim == 64, "attention: head dimension 64 only (got %d)", head_dim);
   SAT_REQUIRE(v_pitch >= T && v_pitch % 4 == 0, "attention: v needs a row pitch >= T that is a multiple of 4 floats (got %d)", v_pitch);
-  const size_t lds_bytes = (size_t)2 * 64 * AT_VU * 16;  // split V image [hi|lo][64][33 units] >= K planes (16 x 256 x 16 B)
+  const size_t lds_bytes = (size_t)2 * 2 * 64 * AT_VU * 16;  // two regions of a split V image [hi|lo][64][33 units] >= K planes = V f32 rows (64 KB)
   const int nw = T > 128 ? 8 : 4;
   auto kern = nw == 8 ? attention_f16x3_kernel<8> : attention_f16x3_kernel<4>;
   {
@@ -580,9 +627,10 @@ extern "C" int sat_attention_f16x3(const void* q_split, const void* k_split, con
       attr_done_on_device(attr_done[nw == 8], dev);
     }
   }
-  dim3 grid(ceil_div(T, 32 * nw), heads, B);
+  const int hpb = heads % 2 == 0 ? 2 : 1;      // heads a block walks: the second one's K arrives under the first one's V product
+  dim3 grid(ceil_div(T, 32 * nw), heads / hpb, B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds_bytes, (hipStream_t)stream, (const uint4*)q_split,
-                     (const uint4*)k_split, v, o, (uint4*)o_split, heads * head_dim, T, v_pitch, scale);
+                     (const uint4*)k_split, v, o, (uint4*)o_split, heads * head_dim, T, v_pitch, scale, hpb, g_attention_dbg);
   SAT_LAUNCH_CHECK("attention_f16x3_kernel");
   return SAT_OK;
 }

@@ -26,3 +26,18 @@ for T in (249, 499):
     us = e0.elapsed_time(e1) / 20 * 1e3
     fl = 4.0 * B * H * T * T * D
     print(f"T={T}: {us:7.1f} us per launch, {fl / us / 1e6:6.1f} TFLOP/s useful")
+
+    if "stamps" in sys.argv:
+        from satools_amd import _lib
+        buf = torch.zeros(56, dtype=torch.int64, device="cuda")
+        _lib.lib().sat_attention_debug_stamps(buf.data_ptr())
+        f()
+        torch.cuda.synchronize()
+        _lib.lib().sat_attention_debug_stamps(None)
+        st = buf.cpu().numpy().reshape(7, 8)
+        names = ["wait K_0 + Q, barrier", "S = K^T Q", "softmax", "wait V, barrier", "V f32 -> split image", "O += V P"]
+        print("   phase cycles of block (0,0,0), first stage (min / max over waves):")
+        for i, nme in enumerate(names):
+            d = st[i + 1] - st[i]
+            print(f"     {nme:28s} {int(d.min()):7d} {int(d.max()):7d}")
+        print(f"     whole {int((st[6] - st[0]).max())} cycles")
