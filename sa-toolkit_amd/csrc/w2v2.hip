@@ -382,24 +382,30 @@ __global__ void __launch_bounds__(64 * NW, 1) attention_f16x3_kernel(const uint4
     }
     if (s == 0) AT_STAMP(2);
     // ---- softmax over keys: register r of tile m is key k0 + 32m + 8(r>>2) + 4lh + (r&3) ----
-    float mx = m_run;
+    // exp(scale s - max) = exp2(fma(s, scale log2 e, -max')) with the maximum taken on the raw scores (scale > 0): one max,
+    // one fma, one v_exp_f32 and one add per score; only a tile that reaches past T masks its keys
+    float mr = -INFINITY;
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
+    for (int m = 0; m < 8; ++m) {
+      if (k0 + 32 * m + 32 > T) {           // (wave-uniform)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jk = k0 + 32 * m + 8 * (r >> 2) + 4 * lh + (r & 3);
-        const float t = jk < T ? st[m][r] * scale2 : -INFINITY;     // scores in units of log2: exp(x) = exp2(x log2 e)
-        st[m][r] = t;
-        mx = fmaxf(mx, t);
+        for (int r = 0; r < 16; ++r) {
+          const int jk = k0 + 32 * m + 8 * (r >> 2) + 4 * lh + (r & 3);
+          st[m][r] = jk < T ? st[m][r] : -INFINITY;
+        }
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mr = fmaxf(mr, st[m][r]);
+    }
+    mr = fmaxf(mr, __shfl_xor(mr, 32));
+    const float mx = fmaxf(m_run, mr * scale2);               // running maximum in units of log2
     const float alpha = __builtin_amdgcn_exp2f(m_run - mx);   // 0 on the first block (m_run = -inf); v_exp_f32, 1 ulp
     float sum = 0.f;
 #pragma unroll
     for (int m = 0; m < 8; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(st[m][r] - mx);     // masked keys: exp2(-inf) = 0
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[m][r], scale2, -mx));     // masked keys: exp2(-inf) = 0
         st[m][r] = e;
         sum += e;
       }
