@@ -198,6 +198,14 @@ typedef struct {
 int sat_resblock_mrf_supported(int C, int n_branches, const int* ksize, const int* dilations /* [n_branches][3] */);
 size_t sat_resblock_mrf_scratch_bytes(int n_branches, const int* ksize);
 int sat_resblock_mrf_f16x3(const sat_mrf_desc* d, void* stream);
+/* The thin upsamplers of the generator, ConvTranspose1d(C_in -> C_in / 2, k = 4, stride 2, padding 1) with C_in = 32 or 64
+ * (hifigan/archi.py:47-59, 80-81), as one streaming launch on split planes (csrc/ups2.hip): x_split [B][C_in][T] planes in,
+ * y_split [B][C_in/2][2T] planes of lrelu(y, y_split_slope) out; w_packed = the SAT_CONV_F16X3 packing of the polyphase
+ * conv (packing.convtranspose_as_phase_conv + pack_conv_weight_f16x3(up = 2)), w_descale its layer scale.  Same split-f16
+ * arithmetic as sat_conv1d_f32 with up = 2, another accumulation order (agrees to f32 rounding). */
+int sat_upsample2_supported(int C_in, int ksize, int stride, int padding);
+int sat_upsample2_f16x3(const void* x_split, const void* w_packed, const float* bias, float w_descale, void* y_split,
+                        float y_split_slope, int B, int C_in, int T, void* stream);
 /* process-wide switches of the conv dispatch (A/B measurements): "k1_gemm" sends 1x1 convs on split planes through
  * 0 = the conv tile, 1 = the 128 x 128 GEMM kernel, 2 = the LDS-DMA ring GEMM (32x32x16 MFMA shape) where its
  * 256-column tiles fit, 3 (default) = the ring GEMM on the 16x16x32 shape (results of 3 agree with 0-2 to f32 rounding
@@ -235,7 +243,9 @@ size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T);
 int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, float* y, void* workspace,
                             size_t workspace_bytes, int B, int T, void* stream);
 void sat_hifigan_destroy(sat_hifigan* h);
-/* options: "fuse_pairs" (default 1): run the conv pairs of stages with C <= 32 as one fused kernel */
+/* options: "fuse_pairs" (default 1): run the conv pairs of stages with C <= 32 as one fused kernel; "fuse_pair64" (bit mask,
+ * default 3), "fuse_mrf" (default 1: whole MRF block of the C = 16 stage in one launch), "mrf_exact" (default 0),
+ * "ups2" (default 1: the two thin upsamplers on sat_upsample2_f16x3), "split_acts", "planes_residual", "branch_streams" */
 int sat_hifigan_set_option(sat_hifigan* h, const char* name, int value);
 
 /* final stage alone: leaky_relu(0.01) -> ReflectionPad1d((1,0)) -> Conv1d(C,1,7,pad 3) -> tanh

@@ -83,6 +83,9 @@ _PROTOS = {
     "sat_resblock_pair_scaled_f16x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                                  C.c_void_p, C.c_void_p]),
     "sat_hifigan_set_conv_descale": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "sat_upsample2_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sat_upsample2_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p]),
     "sat_act_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "sat_hifigan_convpost_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]),

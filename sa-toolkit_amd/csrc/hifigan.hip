@@ -137,6 +137,7 @@ struct sat_hifigan {
                              // 11 taps measured slower fused (its recomputed halo and short blocks cost more than the traffic saved)
   int mrf_exact = 0;         // fused MRF block: 0 = residuals of steps 2 / 3 rebuilt from the 22-bit planes like the launch-by-launch path (bit-identical
                              // to it, and measured 5 % faster: fewer live registers); 1 = kept in f32 registers
+  int ups2 = 1;              // the thin upsamplers (C_in = 64, 32; k 4, stride 2) on the streaming kernel of ups2.hip
   int fuse_mrf = 1;          // a whole MRF block (all branches, all steps, the mean) as one launch where mrf.hip supports the stage (C = 16)
   int split_acts = 1;
   int planes_residual = 1;
@@ -268,6 +269,7 @@ extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int valu
   if (std::string(name) == "fuse_pair64") { h->fuse_pair64 = value; return SAT_OK; }
   if (std::string(name) == "fuse_mrf") { h->fuse_mrf = value; return SAT_OK; }
   if (std::string(name) == "mrf_exact") { h->mrf_exact = value; return SAT_OK; }
+  if (std::string(name) == "ups2") { h->ups2 = value; return SAT_OK; }
   if (std::string(name) == "split_acts") { h->split_acts = value; return SAT_OK; }
   if (std::string(name) == "planes_residual") { h->planes_residual = value; return SAT_OK; }
   if (std::string(name) == "branch_streams") { h->branch_streams = value; return SAT_OK; }
@@ -384,7 +386,10 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         const int co_b = Cn * u > 32 ? 64 : 32;
         const bool direct = cmode == SAT_CONV_F16X3 && h->planes_residual && co_b % (8 * u) == 0;
         int s;
-        if (direct) {
+        if (h->ups2 && cmode == SAT_CONV_F16X3 && h->planes_residual && sat_upsample2_supported(C, k, u, (k - u) / 2)) {
+          s = sat_upsample2_f16x3(XS, h->convs[h->id_up(i)].w, h->convs[h->id_up(i)].bias, h->convs[h->id_up(i)].descale, Hs, 0.1f, B, C, Tc, stream);
+          if (s != SAT_OK) return s;
+        } else if (direct) {
           d.y_split = Hs;
           d.y_split_slope = 0.1f;
           d.no_y = 1;

@@ -34,6 +34,9 @@ class CoreHifiGan(CoreHifiGanParams):
     #: (C = 16); same bits as the launch-by-launch path
     fuse_mrf = int(os.environ.get("SATOOLS_AMD_GEN_FUSE_MRF", "1"))
 
+    #: the two thin upsamplers (64 -> 32 and 32 -> 16 channels) on the streaming kernel of csrc/ups2.hip
+    ups2 = int(os.environ.get("SATOOLS_AMD_GEN_UPS2", "1"))
+
     #: per-stream workspaces kept (3.3 GB each at 32 x 5 s: 26 GB at the default); beyond it the least recently used one is
     #: dropped.  One per convert() job in flight on the GPU (the reference's jobs_per_compute_device, bench.py --jobs) is
     #: what is needed; raise SATOOLS_AMD_GEN_MAX_WORKSPACES for more concurrent streams
@@ -53,7 +56,7 @@ class CoreHifiGan(CoreHifiGanParams):
         ps = self.__dict__.get("_flat_params")
         if ps is None:
             ps = self.__dict__["_flat_params"] = list(self.parameters())
-        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf, self.ups2) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def invalidate(self):
         self._packed_key = None
@@ -128,6 +131,7 @@ class CoreHifiGan(CoreHifiGanParams):
         check(l.sat_hifigan_set_option(self._handle, b"branch_streams", int(self.branch_streams)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"fuse_pair64", int(self.fuse_pair64)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"fuse_mrf", int(self.fuse_mrf)), "sat_hifigan_set_option")
+        check(l.sat_hifigan_set_option(self._handle, b"ups2", int(self.ups2)), "sat_hifigan_set_option")
         self._packed = packed  # keeps the device buffers alive
         self._packed_modes = list(modes)
 

@@ -326,6 +326,16 @@ def resblock_mrf(x_split, B, c, t, branches, slope=0.1, out=None, y_split=None, 
     return out
 
 
+def upsample2(x_split, w_packed, bias, B, c_in, t, y_split_slope=0.1, y_split=None):
+    """ConvTranspose1d(c_in -> c_in / 2, k 4, stride 2, padding 1) on split planes (csrc/ups2.hip): returns the planes of
+    lrelu(y, y_split_slope), [B][c_in / 2][2 t]"""
+    if y_split is None:
+        y_split = split_like(B, c_in // 2, 2 * t, x_split.device)
+    check(lib().sat_upsample2_f16x3(ptr(x_split), ptr(w_packed), ptr(bias), float(getattr(w_packed, "w_descale", 1.0)), ptr(y_split),
+                                    float(y_split_slope), B, c_in, t, stream()), "sat_upsample2_f16x3")
+    return y_split
+
+
 # ---- x-vector extractor (csrc/xvector.hip) -------------------------------------------------------
 def melspec_logmel(wav, window, fb, coef=0.97):
     """wav [B, n] -> log-mel [B, n_mel, 1 + n // 160]; fb [n_mel, 513] (rows = filters)"""

@@ -1083,3 +1083,27 @@ def test_generator_survives_rescaled_layer_pairs():
         ref = ogen.generator(gsd, x)
         err = rms(y.cpu().numpy() - ref.numpy())
         assert err < 1e-5, (shift, err)
+
+
+@pytest.mark.parametrize("cin,T,B", [(32, 700, 2), (32, 496, 1), (32, 497, 2), (32, 3000, 2), (64, 240, 1), (64, 241, 2), (64, 1000, 3), (32, 5, 1)],
+                         ids=lambda v: str(v))
+def test_streaming_upsampler_matches_the_polyphase_conv_and_torch(cin, T, B):
+    """ups2_kernel (ConvTranspose1d(C -> C / 2, k 4, stride 2, padding 1) on split planes, the generator's last two
+    upsamplers) against the polyphase conv tile it replaces (same split-f16 products, another accumulation order: f32
+    rounding) and against torch.conv_transpose1d in float64; tile edges (496 / 240 input positions per tile)"""
+    ops, packing = _ops()
+    cout = cin // 2
+    x = _rand(B, cin, T, seed=1).to(DEV)
+    w = _rand(cin, cout, 4, seed=2, scale=0.8 / np.sqrt(cin * 2))
+    b = _rand(cout, seed=3, scale=0.1).to(DEV)
+    wc, kp, pl = packing.convtranspose_as_phase_conv(w.to(DEV), 2, 1)
+    wp = packing.pack_conv_weight_f16x3(wc, up=2)
+    xs = ops.act_split(x, 0.1)
+    ys = ops.upsample2(xs, wp, b, B, cin, T, y_split_slope=0.1)
+    ys_ref = ops.split_like(B, cout, 2 * T, DEV)
+    ops.conv1d(x, wp, cout, kp, bias=b, pad_left=pl, up=2, mode=1, x_split=xs, y_split=ys_ref, y_split_slope=0.1, no_y=True)
+    got, ref = ops.unsplit(ys), ops.unsplit(ys_ref)
+    assert (got - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    xd = F.leaky_relu(x.double().cpu(), 0.1)
+    y64 = F.leaky_relu(F.conv_transpose1d(xd, w.double(), b.double().cpu(), stride=2, padding=1), 0.1)
+    assert (got.cpu().double() - y64).abs().max().item() < 1e-5
