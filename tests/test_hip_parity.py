@@ -1078,7 +1078,7 @@ def test_generator_survives_rescaled_layer_pairs():
         model = satools_amd.load_model("synthetic:" + tag)
         model.load_state_dict(sd)
         model.to(DEV)
-        y = model.hifigan(x.to(DEV))
+        y = model.hifigan(x.to(DEV))[0]
         gsd = {k[len("hifigan."):]: v for k, v in sd.items() if k.startswith("hifigan.")}
         ref = ogen.generator(gsd, x)
         err = rms(y.cpu().numpy() - ref.numpy())
