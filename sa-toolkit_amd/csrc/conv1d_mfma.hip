@@ -25,6 +25,7 @@ static int g_k1_gemm = 3;
 // sat_conv_set_option("lean3" | "lean7" | "lean11", v): 3- / 7- / 11-tap convs on split planes (no folded BatchNorm) through
 // the three-blocks-per-CU form of the tile (1, conv_lean.hip) or the two-block form (0)
 static int g_lean3 = 1, g_lean7 = 1, g_lean11 = 1;
+static int g_pair32s = 1;   // the 3-tap fused step at C = 32 on the streaming kernel (pair32s.hip)
 
 template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1, int XWI>
 __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
@@ -1799,6 +1800,7 @@ extern "C" int sat_resblock_pair_scaled_f16x3(const sat_conv1d_desc* d, const fl
     return launch_pair64(a, d->B, s);
   }
   if (a.cin_g == 32 && a.x16 && a.res16) {
+    if (g_pair32s && pair32s_supports(a)) return launch_pair32s(a, d->B, s);
     switch (a.ksize) {
       case 3: return launch_pair32<3>(a, d->B, s);
       case 7: return launch_pair32<7>(a, d->B, s);
@@ -1827,6 +1829,8 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "lean3")) { g_lean3 = value != 0; return SAT_OK; }
   if (!strcmp(name, "lean7")) { g_lean7 = value != 0; return SAT_OK; }
   if (!strcmp(name, "lean11")) { g_lean11 = value != 0; return SAT_OK; }
+  if (!strcmp(name, "pair32s")) { g_pair32s = value != 0; return SAT_OK; }
+  if (!strcmp(name, "pair32s_waves")) { pair32s_set_waves(value); return SAT_OK; }
   if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }
   set_error("conv_set_option: unknown option '%s'", name);
   return SAT_ERR_INVALID;

@@ -549,6 +549,9 @@ int launch_f16x3_ring(const ConvArgs& a, int B, hipStream_t s);
 // fused ResBlock1 step for C = 64, 3 taps (pair64.hip)
 int launch_pair64(const ConvArgs& a, int B, hipStream_t s);
 bool pair64_supports(const ConvArgs& a);
+int launch_pair32s(const ConvArgs& a, int B, hipStream_t s);   // pair32s.hip: the 3-tap step at C = 32 as a streaming kernel
+bool pair32s_supports(const ConvArgs& a);
+void pair32s_set_waves(int n);
 // three-blocks-per-CU form of the 3 / 7 / 11-tap conv tile on split planes (conv_lean.hip)
 int launch_f16x3_lean(const ConvArgs& a, int B, hipStream_t s);
 bool lean_supports(const ConvArgs& a);

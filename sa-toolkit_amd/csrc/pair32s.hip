@@ -1,0 +1,306 @@
+// One ResBlock1 step of the generator's 32-channel stage at 3 taps,
+//     y = x + conv2(lrelu(conv1(lrelu(x), dilation d)))          (satools/satools/hifigan/archi.py:118-122)
+// as a streaming kernel on split planes.
+//
+// At 3 taps the step is HBM-bound (a stage tensor in, one out: 328 MB at 32 x 5 s, 55 us at 6 TB/s) and ran at twice that on
+// the general fused step (three blocks per CU, register-staged loads, weights through LDS).  Here, like ups2.hip: one persistent
+// 8-wave block per CU walks tiles of TQ output positions; the input planes of the NEXT tile arrive by LDS-DMA (inline asm, counted
+// waits) while this one is multiplied; the fragments of both convs (2 x 3 taps x 2 row tiles x (hi, lo)) stay in registers for
+// the block's whole walk (v_mfma_f32_16x16x32_f16: K = the 32 input channels of one tap); the inner activation lives in LDS as
+// split planes; the residual is decoded from the input image; outputs leave from the accumulators (planes: 8 bytes of a unit per
+// lane; f32: four channel rows per lane).
+// Arithmetic: split-f16 (lo*hi, hi*lo, hi*hi per K step), accumulation order (tap; all 32 channels) — not the general step's
+// (chunk; tap), so results agree with it to f32 rounding of the accumulation, not bit for bit.
+#include <algorithm>
+
+#include "conv_common.h"
+
+namespace sat {
+
+namespace {
+// NW waves per block: 8 (one block per CU, tiles of 240 output positions) or 4 (two blocks per CU, tiles of 112: the two
+// blocks' barriers and DMA waits fall at different times)
+template <int NW> struct P32 {
+  static constexpr int TQ = NW == 8 ? 240 : 112;       // output positions per tile
+  static constexpr int PITCH = NW == 8 ? 256 : 128;    // units per plane row of an image
+  static constexpr int ROWS = 8;                       // 2 channel chunks x 4 planes
+  static constexpr int IMG = ROWS * PITCH;
+};
+constexpr int P32_HL = 6;        // the image starts HL positions left of the tile: 1 (second conv) + dilation <= 5 (first conv)
+}  // namespace
+
+struct P32Args {
+  const void* x16;       // input planes [B][2][4][T][16 B] of lrelu(x, slope)
+  void* y16;             // output planes of lrelu(y, y_slope), or null
+  float* y;              // f32 output [B][32][T] (y_bs, y_cs), or null
+  const void *w1, *w2;   // packed weights (SAT_CONV_F16X3, co_pad 64)
+  const float *b1, *b2;
+  int T, B, dil;
+  long long y_bs, y_cs;
+  float d1, d2, slope, inv_slope, y_slope, accum_div;
+  int accum;
+  int tiles_t, total, per_xcd, nslots;
+};
+
+template <bool Y16, bool YF, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) pair32s_kernel(const P32Args p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  constexpr int TQ = P32<NW>::TQ, PITCH = P32<NW>::PITCH, HL = P32_HL, IMG = P32<NW>::IMG;
+  constexpr int NSA = TQ / 16 + 1, NSB = TQ / 16;      // subtiles of the inner activation / of the output
+  constexpr int SPS = (Y16 ? 4 : 0) + (YF ? 8 : 0);    // stores a wave issues per output subtile
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, j16 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned OOB = 0x80000000u;
+  uint4* const T1 = lds4 + 2 * IMG;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_end = min((xcd + 1) * p.per_xcd, p.total);
+  int tile = xcd * p.per_xcd + slot;
+  if (tile >= tile_end) return;
+
+  auto stage = [&](int tl, uint4* img) __attribute__((always_inline)) {
+    const int ub = __builtin_amdgcn_readfirstlane(tl / p.tiles_t);
+    const int p0 = (tl - ub * p.tiles_t) * TQ;
+    const i32x4 xrs = dma_rsrc((const char*)p.x16 + (long long)ub * 32 * p.T * 4, (unsigned)(32 * p.T * 4));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      constexpr int PPR = PITCH / 64;                   // 64-unit pieces per plane row: 32 (16) pieces over 8 (4) waves
+      const int piece = wave + NW * r, row = piece / PPR, c = (piece % PPR) * 64 + lane;
+      const int pos = p0 - HL + c;
+      const unsigned voff = (pos >= 0 && pos < p.T) ? (unsigned)((row * p.T + pos) * 16) : OOB;   // zero padding of the first conv
+      lds_dma16(img + row * PITCH + (piece % PPR) * 64, xrs, voff, 0u);
+    }
+  };
+  stage(tile, lds4);
+
+  // fragments of both convs: [tap][row tile] x (hi, lo); K group g = (chunk g >> 1, half g & 1) of the packing
+  h8 a1h[3][2], a1l[3][2], a2h[3][2], a2l[3][2];
+  {
+    const uint4 *w1 = (const uint4*)p.w1, *w2 = (const uint4*)p.w2;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int u = ((((g >> 1) * 3 + t) * 2) * 2 + (g & 1)) * 64 + 16 * m + j16;
+        a1h[t][m] = __builtin_bit_cast(h8, w1[u]);
+        a1l[t][m] = __builtin_bit_cast(h8, w1[u + 128]);
+        a2h[t][m] = __builtin_bit_cast(h8, w2[u]);
+        a2l[t][m] = __builtin_bit_cast(h8, w2[u + 128]);
+      }
+  }
+  float b1[2][4], b2[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      b1[m][k] = p.b1[16 * m + 4 * g + k];
+      b2[m][k] = p.b2[16 * m + 4 * g + k];
+    }
+
+  int buf = 0;
+  bool first = true;
+  const int d = p.dil;
+  // a K group's plane row: hi rows (chunk * 4 + half), lo rows + 2
+  const int krow = (g >> 1) * 4 + (g & 1);
+  for (;;) {
+    const int b = __builtin_amdgcn_readfirstlane(tile / p.tiles_t);
+    const int p0 = (tile - b * p.tiles_t) * TQ;
+    const int next = tile + p.nslots;
+    const bool more = next < tile_end;
+    const uint4* img = lds4 + buf * IMG;
+    // this tile's image has landed (its pieces were requested BEFORE the last tile's stores: a counted wait — loads, stores and
+    // LDS-DMA retire in issue order); the barrier also says every wave is done with the other image and with T1
+    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (wave == NW - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SPS) : "memory");
+    first = false;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (more) stage(next, lds4 + (buf ^ 1) * IMG);
+
+    // ---- first conv: inner activation column u <-> position p0 - 1 + u, image column u + HL - 1 + (tap - 1) d ----
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {
+      const int s = 2 * wave + i;
+      if (s >= NSA) break;
+      const uint4* xb = img + krow * PITCH + 16 * s + j16 + (HL - 1) - d;
+      h8 bh[3], bl[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        bh[t] = __builtin_bit_cast(h8, xb[t * d]);
+        bl[t] = __builtin_bit_cast(h8, xb[2 * PITCH + t * d]);
+      }
+      const int pos = p0 - 1 + 16 * s + j16;
+      const bool inside = pos >= 0 && pos < p.T;          // zero padding of the second conv
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l[t][m], bh[t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[t][m], bl[t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[t][m], bh[t], acc, 0, 0, 0);
+        }
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = __builtin_fmaf(acc[k], p.d1, b1[m][k]);
+          const float a = v > 0.f ? v : v * p.slope;
+          u[k] = inside ? a : 0.f;
+        }
+        const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+        const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+        const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+        const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+        // channels 16 m + 4 g ..: chunk m, half g >> 1, bytes 8 (g & 1) of the unit
+        u32x2* dst = (u32x2*)(T1 + (m * 4 + (g >> 1)) * PITCH + 16 * s + j16) + (g & 1);
+        dst[0] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+        dst[2 * PITCH * 2] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- second conv: output column o <-> position p0 + o, inner columns o + tap; residual = image column o + HL ----
+    const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(Y16 ? (char*)p.y16 + (long long)b * 32 * p.T * 4 : (char*)p.x16), 0, Y16 ? (unsigned)(32 * p.T * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(YF ? (char*)(p.y + (long long)b * p.y_bs) : (char*)p.x16), 0, YF ? (unsigned)(32 * p.y_cs * 4) : 0u, 0x00020000);
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {
+      const int s = 2 * wave + i;
+      if (s >= NSB) break;
+      const uint4* tb = T1 + krow * PITCH + 16 * s + j16;
+      h8 bh[3], bl[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        bh[t] = __builtin_bit_cast(h8, tb[t]);
+        bl[t] = __builtin_bit_cast(h8, tb[2 * PITCH + t]);
+      }
+      const int pos = p0 + 16 * s + j16;
+      const bool ok = pos < p.T;
+      float yv[2][4];
+      if (YF && p.accum) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            yv[m][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     yrs, ok ? (unsigned)(((16 * m + 4 * g + k) * p.y_cs + pos) * 4) : OOB, 0, 0));
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l[t][m], bh[t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h[t][m], bl[t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h[t][m], bh[t], acc, 0, 0, 0);
+        }
+        // residual: the block input, hi + lo of the image with the leaky-relu undone (conv_common.h decode_res16)
+        // (read as four halves: hipcc of ROCm 7.2 miscompiles `bit_cast<half2>(u32x2 element)` here — both halves of the
+        // pair come out as element 0, a 4-byte LDS read; DESIGN.md toolchain notes)
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4* src = (const h4*)(img + (m * 4 + (g >> 1)) * PITCH + 16 * s + j16 + HL) + (g & 1);
+        const h4 rh = src[0], rl = src[2 * PITCH * 2];
+        float rv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rv[k] = (float)rh[k] + (float)rl[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rv[k] = rv[k] > 0.f ? rv[k] : rv[k] * p.inv_slope;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] = __builtin_fmaf(acc[k], p.d2, b2[m][k]) + rv[k];
+          if (YF && p.accum) v[k] = yv[m][k] + v[k];
+        }
+        if (p.accum_div != 0.f) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = v[k] / p.accum_div;
+        }
+        if (YF) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), yrs,
+                                                  ok ? (unsigned)(((16 * m + 4 * g + k) * p.y_cs + pos) * 4) : OOB, 0, 0);
+        }
+        if (Y16) {
+          float u[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) u[k] = v[k] > 0.f ? v[k] : v[k] * p.y_slope;
+          const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+          const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+          const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+          const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+          const unsigned off = ok ? (unsigned)((((m * 4 + (g >> 1)) * p.T + pos) * 16) + 8 * (g & 1)) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)}, y16rs, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)}, y16rs, off, 2 * p.T * 16, 0);
+        }
+      }
+    }
+    if (!more) break;
+    tile = next;
+    buf ^= 1;
+  }
+}
+
+static int g_pair32s_waves = 8;
+
+template <bool Y16, bool YF, int NW>
+static int launch_pair32s_t(P32Args& p, hipStream_t s) {
+  const size_t lds_bytes = (size_t)(3 * P32<NW>::IMG + 16) * 16;   // two images, the inner activation, slack for the reads past a row's end
+  auto kern = pair32s_kernel<Y16, YF, NW>;
+  static std::atomic<uint64_t> attr_done{0};
+  int dev;
+  if (attr_needed_on_current_device(attr_done, &dev)) {
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done_on_device(attr_done, dev);
+  }
+  p.tiles_t = ceil_div(p.T, P32<NW>::TQ);
+  p.total = p.tiles_t * p.B;
+  p.per_xcd = ceil_div(p.total, 8);
+  p.nslots = std::max(1, std::min(NW == 8 ? 32 : 64, p.per_xcd));
+  hipLaunchKernelGGL(kern, dim3(8 * p.nslots), dim3(64 * NW), lds_bytes, s, p);
+  SAT_LAUNCH_CHECK("pair32s_kernel");
+  return SAT_OK;
+}
+
+// the fused step this kernel serves: C = 32, 3 taps, dilation <= 5, planes in, residual from the planes
+bool pair32s_supports(const ConvArgs& a) {
+  return a.cin_g == 32 && a.rows_g == 32 && a.ksize == 3 && a.dil >= 1 && a.dil <= P32_HL - 1 && a.x16 && a.res16 == a.x16 && !a.res &&
+         !a.ch_scale && !a.relu && !a.gelu && a.co_pad == 64 && a.res_scale == 1.f && !a.y16_f8 && (a.y16 || !a.no_y);
+}
+
+int launch_pair32s(const ConvArgs& a, int B, hipStream_t s) {
+  P32Args p{};
+  p.x16 = a.x16;
+  p.y16 = a.y16;
+  p.y = a.no_y ? nullptr : a.y;
+  p.w1 = a.w;
+  p.w2 = a.w2;
+  p.b1 = a.bias1;
+  p.b2 = a.bias;
+  p.T = a.T_q;
+  p.B = B;
+  p.dil = a.dil;
+  p.y_bs = a.y_bs;
+  p.y_cs = a.y_cs;
+  p.d1 = a.w_descale1;
+  p.d2 = a.w_descale;
+  p.slope = a.in_slope;
+  p.inv_slope = a.res16_inv;
+  p.y_slope = a.y16_slope;
+  p.accum = a.accum;
+  p.accum_div = a.accum_div;
+  if (g_pair32s_waves == 4) {
+    if (p.y16 && p.y) return launch_pair32s_t<true, true, 4>(p, s);
+    if (p.y16) return launch_pair32s_t<true, false, 4>(p, s);
+    return launch_pair32s_t<false, true, 4>(p, s);
+  }
+  if (p.y16 && p.y) return launch_pair32s_t<true, true, 8>(p, s);
+  if (p.y16) return launch_pair32s_t<true, false, 8>(p, s);
+  return launch_pair32s_t<false, true, 8>(p, s);
+}
+
+void pair32s_set_waves(int n) { g_pair32s_waves = n == 4 ? 4 : 8; }
+
+}  // namespace sat
