@@ -1830,6 +1830,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "lean7")) { g_lean7 = value != 0; return SAT_OK; }
   if (!strcmp(name, "lean11")) { g_lean11 = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32s")) { g_pair32s = value != 0; return SAT_OK; }
+  if (!strcmp(name, "lean_balance")) { lean_set_balance(value); return SAT_OK; }
   if (!strcmp(name, "pair32s_waves")) { pair32s_set_waves(value); return SAT_OK; }
   if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }
   set_error("conv_set_option: unknown option '%s'", name);

@@ -43,6 +43,7 @@ struct ConvArgs {
   int cin_g, T_in, rows_g, cout_g, T_q;
   int ksize, dil, stride, pad_left, up;
   int cin_pad, co_pad, xw, co_tiles_g;
+  int bal, bal_fpp, bal_hpp;   // conv_lean.hip: 1-D balanced grid (bal = (row tile, utterance) pairs, 0 = plain 3-D grid) — full 256-column tiles first (fpp per (row tile, utterance)), then the ragged end of every row as 1 or 2 half tiles
   int in_lrelu, relu, accum, gelu, res_after, relu_first;
   float in_slope, accum_div, res_scale;
   int res_toff, res_tstride;
@@ -551,6 +552,7 @@ int launch_pair64(const ConvArgs& a, int B, hipStream_t s);
 bool pair64_supports(const ConvArgs& a);
 int launch_pair32s(const ConvArgs& a, int B, hipStream_t s);   // pair32s.hip: the 3-tap step at C = 32 as a streaming kernel
 bool pair32s_supports(const ConvArgs& a);
+void lean_set_balance(int v);   // conv_lean.hip
 void pair32s_set_waves(int n);
 // three-blocks-per-CU form of the 3 / 7 / 11-tap conv tile on split planes (conv_lean.hip)
 int launch_f16x3_lean(const ConvArgs& a, int B, hipStream_t s);

@@ -35,9 +35,33 @@ __global__ void __launch_bounds__(256, 3) conv1d_f16x3_planes_lean_kernel(const 
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z;
-  const int co_w = blockIdx.y * CO_B;
-  const int q_b = blockIdx.x * T_B;
+  // Plain grid: (column tile, row tile, utterance).  Balanced grid (p.bal): a 1-D grid whose first blocks are the full tiles and
+  // whose last blocks are the ragged end of every (row tile, utterance) as 128-column HALF tiles (waves 2, 3 idle): the
+  // dispatcher hands blocks out in id order, so the small blocks come last.  (Tried for balance — 640 tiles on 768 slots at
+  // C = 256, T = 1250 as 512 full + 256 half tiles, 2.5 per CU: level, a CU with 3 blocks is not 1.5 x slower than one with 2.)
+  int b, co_w, q_b;
+  bool active = true;
+  if (p.bal) {
+    const int id = blockIdx.x, nfull = p.bal_fpp * p.bal;     // p.bal = number of (row tile, utterance) pairs
+    int pair;
+    if (id < nfull) {
+      pair = id / p.bal_fpp;
+      q_b = (id - pair * p.bal_fpp) * T_B;
+    } else {
+      const int hid = id - nfull;
+      pair = hid / p.bal_hpp;
+      q_b = p.bal_fpp * T_B + (hid - pair * p.bal_hpp) * (T_B / 2);
+      active = wave < 2;
+    }
+    pair = __builtin_amdgcn_readfirstlane(pair);
+    q_b = __builtin_amdgcn_readfirstlane(q_b);
+    b = __builtin_amdgcn_readfirstlane(pair / p.co_tiles_g);
+    co_w = (pair - b * p.co_tiles_g) * CO_B;
+  } else {
+    b = blockIdx.z;
+    co_w = blockIdx.y * CO_B;
+    q_b = blockIdx.x * T_B;
+  }
   const int q_w = q_b + wave * (32 * NT);
   const int xi0 = q_b - p.pad_left;
   const int nch = p.cin_pad / CI_CHUNK;
@@ -151,11 +175,16 @@ __global__ void __launch_bounds__(256, 3) conv1d_f16x3_planes_lean_kernel(const 
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma_group(gc);
+      if (active) mfma_group(gc);
     });
   }
-  conv_epilogue<MT, NT, false, false>(p, acc, b, 0, co_w, q_w, l31, lh);
+  if (active) conv_epilogue<MT, NT, false, false>(p, acc, b, 0, co_w, q_w, l31, lh);
 }
+
+// 0 = plain grid; 1 = half tile where ONE covers a row's ragged end (never more blocks than the plain grid, less wasted work);
+// 2 = always (two half tiles for ends of 129 .. 255 columns: measured level to 10 % slower, a half tile stages what a full one does)
+static int g_lean_balance = 1;
+void lean_set_balance(int v) { g_lean_balance = v < 0 ? 0 : v > 2 ? 2 : v; }
 
 bool lean_supports(const ConvArgs& a) {
   return a.x16 && !a.f8 && !a.y16_f8 && !a.poly_planes && !a.ch_scale && a.fast_epi && a.up == 1 && a.stride == 1 &&
@@ -170,6 +199,13 @@ static int launch_lean(const ConvArgs& a, int B, hipStream_t s) {
   const size_t lds_bytes = ((size_t)4 * 320 + (size_t)TG * 4 * 64) * 16;
   auto kern = conv1d_f16x3_planes_lean_kernel<KS, TG>;
   dim3 grid(ceil_div(p.T_q, 256), p.co_tiles_g, B);
+  const int rem = p.T_q % 256;
+  if (rem != 0 && (g_lean_balance == 2 || (g_lean_balance == 1 && rem <= 128))) {
+    p.bal = p.co_tiles_g * B;
+    p.bal_fpp = p.T_q / 256;
+    p.bal_hpp = rem > 128 ? 2 : 1;
+    grid = dim3((unsigned)((p.bal_fpp + p.bal_hpp) * p.bal), 1, 1);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
   SAT_LAUNCH_CHECK("conv1d_f16x3_planes_lean_kernel");
   return SAT_OK;

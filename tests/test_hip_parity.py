@@ -1150,3 +1150,30 @@ def test_streaming_three_tap_step_c32_matches_the_general_fused_step(T, d, B):
     assert (new[1].cpu().double() - (acc0.cpu().double() + y64) / 3).abs().max().item() < 1e-5
     assert (new[0].cpu().double() - F.leaky_relu(y64, 0.1)).abs().max().item() < 1e-5
     assert torch.equal(new[3], ops.unsplit(ops.act_split(new[2], 0.1)))       # the planes are the split of the f32 written beside them
+
+
+@pytest.mark.parametrize("C,T,k,dil", [(256, 1250, 11, 5), (128, 1000, 7, 3), (128, 256, 3, 1), (128, 100, 3, 5), (128, 385, 11, 1), (256, 1100, 7, 1)], ids=lambda v: str(v))
+def test_balanced_grid_of_the_conv_tile_gives_the_same_bits(C, T, k, dil):
+    """sat_conv_set_option("lean_balance"): the ragged end of every row as 128-column half tiles dispatched after the full
+    tiles (1 = only where one half tile covers it, the default; 2 = always, two half tiles if need be) — the same tiles'
+    arithmetic, same bits"""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    B = 2
+    x, w, b = _rand(B, C, T, seed=1).to(DEV), _rand(C, C, k, seed=2, scale=(k * C) ** -0.5).to(DEV), _rand(C, seed=3).to(DEV)
+    xs = ops.act_split(x, 0.1)
+    wp = packing.pack_conv_weight_f16x3(w)
+    out = {}
+    try:
+        for v in (0, 1, 2):
+            _lib.check(_lib.lib().sat_conv_set_option(b"lean_balance", v), "sat_conv_set_option")
+            ys = ops.split_like(B, C, T, DEV)
+            y = ops.conv1d(x, wp, C, k, bias=b, dilation=dil, pad_left=dil * (k - 1) // 2, mode=1, x_split=xs, y_split=ys, y_split_slope=0.1)
+            assert T < 1000 or "lean_kernel" in _lib.lib().sat_last_dispatch_name().decode()
+            out[v] = (y, ys)
+    finally:
+        _lib.check(_lib.lib().sat_conv_set_option(b"lean_balance", 1), "sat_conv_set_option")
+    for v in (1, 2):
+        assert torch.equal(out[0][0], out[v][0]) and torch.equal(out[0][1], out[v][1])
+    ref = F.conv1d(F.leaky_relu(x.double().cpu(), 0.1), w.double().cpu(), b.double().cpu(), dilation=dil, padding=dil * (k - 1) // 2)
+    assert (out[1][0].cpu().double() - ref).abs().max().item() < 3e-5
