@@ -59,6 +59,8 @@ int sat_clock_probe(int64_t* samples, int n, int period_us, void* stream);
 int sat_mrf_debug_stamps(int64_t* buf);
 /* the same for sat_attention_f16x3 (tools/bench_attention.py stamps): block (0, 0, 0), 7 points of the first key block x 8 waves */
 int sat_attention_debug_stamps(int64_t* buf);
+/* the same for block 0 of the wave-specialised ResBlock step at C = 32 (csrc/pair32s.hip: pair32w_kernel): [8 steps][6 stamps][8 waves] */
+int sat_pair32_debug_stamps(int64_t* buf);
 
 /* ------------------------------------------------------------------------------------------
  * Fused 1-D convolution as an implicit GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32;

@@ -77,6 +77,7 @@ _PROTOS = {
                                           C.c_void_p]),
     "sat_mrf_debug_stamps": (C.c_int, [C.c_void_p]),
     "sat_attention_debug_stamps": (C.c_int, [C.c_void_p]),
+    "sat_pair32_debug_stamps": (C.c_int, [C.c_void_p]),
     "sat_resblock_mrf_supported": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sat_resblock_mrf_scratch_bytes": (C.c_size_t, [C.c_int, C.POINTER(C.c_int)]),
     "sat_resblock_mrf_f16x3": (C.c_int, [C.POINTER(MrfDesc), C.c_void_p]),

@@ -1824,12 +1824,15 @@ extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, in
   return SAT_OK;
 }
 
+extern "C" int sat_pair32_debug_stamps(int64_t* buf) { return pair32_debug_stamps((long long*)buf); }
+
 extern "C" int sat_conv_set_option(const char* name, int value) {
   SAT_REQUIRE(name, "conv_set_option: null name");
   if (!strcmp(name, "lean3")) { g_lean3 = value != 0; return SAT_OK; }
   if (!strcmp(name, "lean7")) { g_lean7 = value != 0; return SAT_OK; }
   if (!strcmp(name, "lean11")) { g_lean11 = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32s")) { g_pair32s = value != 0; return SAT_OK; }
+  if (!strcmp(name, "pair32w")) { pair32w_set(value); return SAT_OK; }
   if (!strcmp(name, "lean_balance")) { lean_set_balance(value); return SAT_OK; }
   if (!strcmp(name, "pair32s_waves")) { pair32s_set_waves(value); return SAT_OK; }
   if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }

@@ -40,6 +40,7 @@ struct P32Args {
   float d1, d2, slope, inv_slope, y_slope, accum_div;
   int accum;
   int tiles_t, total, per_xcd, nslots;
+  long long* dbg;        // diagnostics (sat_pair32_debug_stamps): block 0 of pair32w_kernel records cycle counters, [step][stamp][wave]
 };
 
 template <bool Y16, bool YF, int NW>
@@ -243,6 +244,338 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) pair32s_kernel(const
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 7 and 11 taps: the fragments of ONE conv (KS x 2 row tiles x (hi, lo) = 112 / 176 VGPRs) are all a wave can keep, so the
+// waves specialise — waves 0-3 hold conv1 and produce the inner activation of tile n into one of two LDS buffers while waves
+// 4-7 hold conv2 and turn the inner activation of tile n - 1 (the other buffer) into outputs: a two-stage pipeline with ONE
+// barrier per tile, a conv1 and a conv2 wave on every SIMD.  LDS then only serves the B fragments (2 reads per 6 MFMAs,
+// ~65 % of its bandwidth at full MFMA rate; with the weights passing through LDS the general fused step sits at the LDS
+// limit).  Input images by LDS-DMA one tile ahead (issued and awaited by the conv1 waves only: a plain vmcnt(0), they have
+// no other memory traffic); the conv2 waves fetch their residual words from the planes in global memory (L2: the image
+// of the same tile went by a moment ago), so an image is dead once conv1 has read it and two buffers suffice.
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <int KS> struct P32W {
+  static constexpr int TQ = 240;                    // output positions per tile
+  static constexpr int HC = (KS - 1) / 2;           // taps left of the centre
+  static constexpr int HL = HC * 6;                 // image start left of the tile: HC (conv2) + HC * dilation <= 5 HC (conv1)
+  static constexpr int PITCH = 320;                 // units per plane row of an image (TQ + 2 HL <= 300: five DMA pieces)
+  static constexpr int IMG = 8 * PITCH;             // 40 KB
+  static constexpr int T1P = 256;                   // units per plane row of an inner-activation buffer (TQ + 2 HC <= 250)
+  static constexpr int T1IMG = 8 * T1P;             // 32 KB
+};
+}  // namespace
+
+#ifndef P32W_DBG_SPLIT
+#define P32W_DBG_SPLIT 0   // 1: the conv2 waves stamp [after MFMAs, after epilogue] of subtiles 0 and 1 instead of the four subtile ends
+#endif
+#ifndef P32W_SB
+#define P32W_SB 1
+#endif
+constexpr int P32_DBG_STEPS = 8, P32_DBG_STAMPS = 6;
+#define P32_STAMP(idx)                                                                                      \
+  do {                                                                                                      \
+    if (p.dbg && blockIdx.x == 0 && step < P32_DBG_STEPS) {                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      unsigned long long t_;                                                                                \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+      if (lane == 0) p.dbg[(step * P32_DBG_STAMPS + (idx)) * 8 + wave] = (long long)t_;                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }                                                                                                       \
+  } while (0)
+
+template <int KS, bool Y16, bool YF>
+__global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  using G = P32W<KS>;
+  constexpr int TQ = G::TQ, HC = G::HC, HL = G::HL, PITCH = G::PITCH, IMG = G::IMG, T1P = G::T1P, T1IMG = G::T1IMG;
+  constexpr int NSA = 16, NSB = TQ / 16;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, j16 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave < 4;
+  const int rw = wave & 3;                            // wave index inside its role
+  const unsigned OOB = 0x80000000u;
+  uint4* const T1 = lds4 + 2 * IMG;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_end = min((xcd + 1) * p.per_xcd, p.total);
+  const int tile0 = xcd * p.per_xcd + slot;
+  if (tile0 >= tile_end) return;
+  const int n_my = (tile_end - tile0 + p.nslots - 1) / p.nslots;
+
+  // pieces r0 .. r1 - 1 of a tile's image: 8 rows x 5 pieces of 64 units over the 4 producer waves (10 each)
+  auto stage = [&](int tl, uint4* img, int r0, int r1) __attribute__((always_inline)) {
+    const int ub = __builtin_amdgcn_readfirstlane(tl / p.tiles_t);
+    const int p0 = (tl - ub * p.tiles_t) * TQ;
+    const i32x4 xrs = dma_rsrc((const char*)p.x16 + (long long)ub * 32 * p.T * 4, (unsigned)(32 * p.T * 4));
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      if (r < r0 || r >= r1) continue;
+      const int piece = rw + 4 * r, row = piece / 5, c = (piece % 5) * 64 + lane;
+      const int pos = p0 - HL + c;
+      const unsigned voff = (pos >= 0 && pos < p.T) ? (unsigned)((row * p.T + pos) * 16) : OOB;
+      lds_dma16(img + row * PITCH + (piece % 5) * 64, xrs, voff, 0u);
+    }
+  };
+  if (producer) stage(tile0, lds4, 0, 10);
+
+  // this role's fragments: [tap][row tile] x (hi, lo); K group g = (chunk g >> 1, half g & 1) of the packing
+  h8 ah[KS][2], al[KS][2];
+  float4* const bias4 = (float4*)(T1 + 2 * T1IMG);   // [8] this role's bias, read back per epilogue (8 VGPRs the 11-tap consumer lacks)
+  {
+    const uint4* w = (const uint4*)(producer ? p.w1 : p.w2);
+    const float* bp = producer ? p.b1 : p.b2;
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int u = ((((g >> 1) * KS + t) * 2) * 2 + (g & 1)) * 64 + 16 * m + j16;
+        ah[t][m] = __builtin_bit_cast(h8, w[u]);
+        al[t][m] = __builtin_bit_cast(h8, w[u + 128]);
+      }
+    if (rw == 0 && lane < 32) ((float*)(bias4 + (producer ? 0 : 8)))[lane] = bp[lane];
+  }
+  const float4* const my_bias = bias4 + (producer ? 0 : 8) + g;      // channels 16 m + 4 g ..: my_bias[4 m]
+  const float descale = producer ? p.d1 : p.d2;
+  const int d = p.dil;
+  const int krow = (g >> 1) * 4 + (g & 1);           // a K group's plane row: hi rows (chunk * 4 + half), lo rows + 2
+
+  // A role's four 16-column subtiles of a tile.  B fragments of tap t: base[t * step] (hi) and base[lo_off + t * step] (lo),
+  // kept PD taps ahead of their MFMAs in a ring of PD register pairs that runs on across the subtiles (the first taps of
+  // subtile i + 1 are requested under the last MFMAs of subtile i, so its epilogue and their LDS round trip overlap).  Both
+  // loops are fully unrolled: the ring slot (i KS + t) % PD is a compile-time number.  (PD = 1, no real read-ahead, in the
+  // 11-tap kernels with an f32 output: registers they do not have; the SIMD's other wave covers.)
+  constexpr int PD = KS == 11 ? (YF ? 1 : 2) : 3;
+  auto run_conv = [&](auto base_of, int step_, int lo_off, int ns, auto before, auto epi, auto stamp) __attribute__((always_inline)) {
+    h8 ring_h[PD], ring_l[PD];
+    const int s0 = 4 * rw;
+    {
+      const uint4* b0 = base_of(s0);
+#pragma unroll
+      for (int q = 0; q < PD; ++q) {
+        ring_h[q] = __builtin_bit_cast(h8, b0[q * step_]);
+        ring_l[q] = __builtin_bit_cast(h8, b0[lo_off + q * step_]);
+      }
+    }
+    constexpr int UNR = PD > 1 ? 4 : 1;      // (a ring of one needs no compile-time slot: keep the loop rolled, it spares registers)
+#pragma clang loop unroll_count(UNR)
+    for (int i = 0; i < 4; ++i) {
+      const int s_ = s0 + i;
+      if (s_ < ns) {
+        const uint4 *bs = base_of(s_), *nb = base_of(s_ + 1);
+        const bool has_next = i < 3 && s_ + 1 < ns;
+        before(i, s_, has_next);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+          const int slot = (i * KS + t) % PD;
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t][0], ring_h[slot], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t][1], ring_h[slot], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][0], ring_l[slot], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][1], ring_l[slot], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][0], ring_h[slot], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][1], ring_h[slot], acc[1], 0, 0, 0);
+          if (P32W_SB) __builtin_amdgcn_sched_barrier(0);
+          if (t + PD < KS) {
+            ring_h[slot] = __builtin_bit_cast(h8, bs[(t + PD) * step_]);
+            ring_l[slot] = __builtin_bit_cast(h8, bs[lo_off + (t + PD) * step_]);
+          } else if (has_next) {
+            ring_h[slot] = __builtin_bit_cast(h8, nb[(t + PD - KS) * step_]);
+            ring_l[slot] = __builtin_bit_cast(h8, nb[lo_off + (t + PD - KS) * step_]);
+          }
+          if (P32W_SB) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (P32W_DBG_SPLIT && !producer) { if (i < 2) stamp(2 + 2 * i); }
+        epi(i, s_, acc);
+        if (P32W_DBG_SPLIT && !producer) { if (i < 2) stamp(3 + 2 * i); } else stamp(2 + i);
+      }
+    }
+  };
+
+  // conv2 waves: residual words of the lane's four channels per row tile (hi, lo) from the planes in global memory (~1.5-2 us
+  // away under this kernel's own traffic), requested one subtile ahead (RD = 2 register sets) where registers allow, and the
+  // first subtile's of a tile at the end of the previous step, across the barrier
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int RD = KS == 11 ? 1 : 2;
+  constexpr bool XB = KS == 7 && !YF;      // (the other kernels spill with these registers live across the barrier)
+  u32x4 rh[RD][2], rl[RD][2];
+  float yv[2][4];
+  auto res_load = [&](int set, int tile, int s_) __attribute__((always_inline)) {
+    const int b = __builtin_amdgcn_readfirstlane(tile / p.tiles_t);
+    const int pos = (tile - b * p.tiles_t) * TQ + 16 * s_ + j16;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.x16 + (long long)b * 32 * p.T * 4), 0, (unsigned)(32 * p.T * 4), 0x00020000);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const unsigned off = pos < p.T ? (unsigned)((((m * 4 + (g >> 1)) * p.T + pos) * 16) + 8 * (g & 1)) : OOB;
+      rh[set][m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));              // (narrowed to 8 bytes)
+      rl[set][m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 2 * p.T * 16, 0));
+    }
+  };
+  if (XB && !producer) res_load(0, tile0, 4 * rw);
+
+  for (int step = 0; step <= n_my; ++step) {
+    P32_STAMP(0);
+    if (producer && step < n_my) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // image of tile `step` (this wave's pieces)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    P32_STAMP(1);
+    if (producer) {
+      if (step >= n_my) continue;
+      const int tile = tile0 + step * p.nslots;
+      const int b = __builtin_amdgcn_readfirstlane(tile / p.tiles_t);
+      const int p0 = (tile - b * p.tiles_t) * TQ;
+      const uint4* img = lds4 + (step & 1) * IMG;
+      uint4* t1 = T1 + (step & 1) * T1IMG;
+      // inner column u <-> position p0 - HC + u; tap t reads image column u + (HL - HC - HC d) + t d
+      const uint4* xb = img + krow * PITCH + j16 + (HL - HC) - HC * d;
+      run_conv([&](int s_) { return xb + 16 * s_; }, d, 2 * PITCH, NSA, [](int, int, bool) {},
+               [&](int, int s_, f32x4 (&acc)[2]) __attribute__((always_inline)) {
+                 const int pos = p0 - HC + 16 * s_ + j16;
+                 const bool inside = pos >= 0 && pos < p.T;          // zero padding of the second conv
+#pragma unroll
+                 for (int m = 0; m < 2; ++m) {
+                   const float4 bq = my_bias[4 * m];
+                   const float bias_m[4] = {bq.x, bq.y, bq.z, bq.w};
+                   float u[4];
+#pragma unroll
+                   for (int k = 0; k < 4; ++k) {
+                     const float v = __builtin_fmaf(acc[m][k], descale, bias_m[k]);
+                     const float a = v > 0.f ? v : v * p.slope;
+                     u[k] = inside ? a : 0.f;
+                   }
+                   const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+                   const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+                   const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+                   const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+                   u32x2* dst = (u32x2*)(t1 + (m * 4 + (g >> 1)) * T1P + 16 * s_ + j16) + (g & 1);
+                   dst[0] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                   dst[2 * T1P * 2] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+                 }
+               },
+               [&](int idx) __attribute__((always_inline)) {
+                 // the next tile's image, a few pieces after every subtile: ten at once (40 KB per CU) stall the issuing waves
+                 // for ~3500 cycles and hold up the conv2 waves' residual loads (cycle stamps, tools/stamp_pair32.py)
+                 if (step + 1 < n_my) {
+                   const int i = idx - 2;
+                   stage(tile0 + (step + 1) * p.nslots, lds4 + ((step + 1) & 1) * IMG, i == 0 ? 0 : i == 1 ? 3 : i == 2 ? 6 : 8,
+                         i == 0 ? 3 : i == 1 ? 6 : i == 2 ? 8 : 10);
+                 }
+                 P32_STAMP(idx);
+               });
+    } else {
+      if (step == 0) continue;
+      const int tile = tile0 + (step - 1) * p.nslots;
+      const int b = __builtin_amdgcn_readfirstlane(tile / p.tiles_t);
+      const int p0 = (tile - b * p.tiles_t) * TQ;
+      const uint4* t1 = T1 + ((step - 1) & 1) * T1IMG;
+      const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(Y16 ? (char*)p.y16 + (long long)b * 32 * p.T * 4 : (char*)p.x16), 0, Y16 ? (unsigned)(32 * p.T * 4) : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(YF ? (char*)(p.y + (long long)b * p.y_bs) : (char*)p.x16), 0, YF ? (unsigned)(32 * p.y_cs * 4) : 0u, 0x00020000);
+      // output column o <-> position p0 + o, inner columns o + tap
+      const uint4* tb = t1 + krow * T1P + j16;
+      run_conv([&](int s_) { return tb + 16 * s_; }, 1, 2 * T1P, NSB,
+               [&](int i, int s_, bool has_next) __attribute__((always_inline)) {
+                 if (!XB && i == 0) res_load(0, tile, s_);
+                 if (RD == 2) {
+                   if (has_next) res_load((i + 1) & 1, tile, s_ + 1);
+                 } else if (i > 0) {
+                   res_load(0, tile, s_);
+                 }
+                 if (YF && p.accum) {
+                   const int pos = p0 + 16 * s_ + j16;
+#pragma unroll
+                   for (int m = 0; m < 2; ++m)
+#pragma unroll
+                     for (int k = 0; k < 4; ++k)
+                       yv[m][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                yrs, pos < p.T ? (unsigned)(((16 * m + 4 * g + k) * p.y_cs + pos) * 4) : OOB, 0, 0));
+                 }
+               },
+               [&](int i, int s_, f32x4 (&acc)[2]) __attribute__((always_inline)) {
+                 const int pos = p0 + 16 * s_ + j16;
+                 const bool ok = pos < p.T;
+                 const int set = RD == 2 ? (i & 1) : 0;
+#pragma unroll
+                 for (int m = 0; m < 2; ++m) {
+                   const h4 xh = __builtin_bit_cast(h4, u32x2{rh[set][m][0], rh[set][m][1]}), xl = __builtin_bit_cast(h4, u32x2{rl[set][m][0], rl[set][m][1]});
+                   const float4 bq = my_bias[4 * m];
+                   const float bias_m[4] = {bq.x, bq.y, bq.z, bq.w};
+                   float v[4];
+#pragma unroll
+                   for (int k = 0; k < 4; ++k) {
+                     float r = (float)xh[k] + (float)xl[k];
+                     r = r > 0.f ? r : r * p.inv_slope;
+                     v[k] = __builtin_fmaf(acc[m][k], descale, bias_m[k]) + r;
+                     if (YF && p.accum) v[k] = yv[m][k] + v[k];
+                   }
+                   if (p.accum_div != 0.f) {
+#pragma unroll
+                     for (int k = 0; k < 4; ++k) v[k] = v[k] / p.accum_div;
+                   }
+                   if (YF) {
+#pragma unroll
+                     for (int k = 0; k < 4; ++k)
+                       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), yrs,
+                                                             ok ? (unsigned)(((16 * m + 4 * g + k) * p.y_cs + pos) * 4) : OOB, 0, 0);
+                   }
+                   if (Y16) {
+                     float u[4];
+#pragma unroll
+                     for (int k = 0; k < 4; ++k) u[k] = v[k] > 0.f ? v[k] : v[k] * p.y_slope;
+                     const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+                     const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+                     const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+                     const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+                     const unsigned off = ok ? (unsigned)((((m * 4 + (g >> 1)) * p.T + pos) * 16) + 8 * (g & 1)) : OOB;
+                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)}, y16rs, off, 0, 0);
+                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)}, y16rs, off, 2 * p.T * 16, 0);
+                   }
+                 }
+               },
+               [&](int idx) __attribute__((always_inline)) { P32_STAMP(idx); });
+      if (XB && step < n_my) res_load(0, tile0 + step * p.nslots, 4 * rw);      // the next tile's first subtile (set 0 is free again)
+    }
+  }
+}
+
+static long long* g_pair32_dbg = nullptr;
+int pair32_debug_stamps(long long* buf) {
+  g_pair32_dbg = buf;
+  return P32_DBG_STEPS * P32_DBG_STAMPS * 8;
+}
+
+template <int KS, bool Y16, bool YF>
+static int launch_pair32w_t(P32Args& p, hipStream_t s) {
+  using G = P32W<KS>;
+  const size_t lds_bytes = (size_t)(2 * G::IMG + 2 * G::T1IMG + 16) * 16;   // 144 KB + the bias table
+  auto kern = pair32w_kernel<KS, Y16, YF>;
+  static std::atomic<uint64_t> attr_done{0};
+  int dev;
+  if (attr_needed_on_current_device(attr_done, &dev)) {
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done_on_device(attr_done, dev);
+  }
+  p.tiles_t = ceil_div(p.T, G::TQ);
+  p.total = p.tiles_t * p.B;
+  p.per_xcd = ceil_div(p.total, 8);
+  p.nslots = std::max(1, std::min(32, p.per_xcd));
+  p.dbg = g_pair32_dbg;
+  hipLaunchKernelGGL(kern, dim3(8 * p.nslots), dim3(512), lds_bytes, s, p);
+  SAT_LAUNCH_CHECK("pair32w_kernel");
+  return SAT_OK;
+}
+
+template <int KS>
+static int launch_pair32w(P32Args& p, hipStream_t s) {
+  if (p.y16 && p.y) return launch_pair32w_t<KS, true, true>(p, s);
+  if (p.y16) return launch_pair32w_t<KS, true, false>(p, s);
+  return launch_pair32w_t<KS, false, true>(p, s);
+}
+
 static int g_pair32s_waves = 8;
 
 template <bool Y16, bool YF, int NW>
@@ -264,9 +597,14 @@ static int launch_pair32s_t(P32Args& p, hipStream_t s) {
   return SAT_OK;
 }
 
-// the fused step this kernel serves: C = 32, 3 taps, dilation <= 5, planes in, residual from the planes
+static int g_pair32w = 1;   // 7 and 11 taps on the wave-specialised kernel
+void pair32w_set(int v) { g_pair32w = v != 0; }
+
+// the fused steps these kernels serve: C = 32, dilation <= 5, planes in, residual from the planes
 bool pair32s_supports(const ConvArgs& a) {
-  return a.cin_g == 32 && a.rows_g == 32 && a.ksize == 3 && a.dil >= 1 && a.dil <= P32_HL - 1 && a.x16 && a.res16 == a.x16 && !a.res &&
+  // (11 taps with an f32 output: the conv2 waves run out of registers — no read-ahead, spills — and measured 212 against 184 us)
+  return a.cin_g == 32 && a.rows_g == 32 && (a.ksize == 3 || (g_pair32w && (a.ksize == 7 || (a.ksize == 11 && a.no_y)))) && a.dil >= 1 &&
+         a.dil <= P32_HL - 1 && a.x16 && a.res16 == a.x16 && !a.res &&
          !a.ch_scale && !a.relu && !a.gelu && a.co_pad == 64 && a.res_scale == 1.f && !a.y16_f8 && (a.y16 || !a.no_y);
 }
 
@@ -291,6 +629,8 @@ int launch_pair32s(const ConvArgs& a, int B, hipStream_t s) {
   p.y_slope = a.y16_slope;
   p.accum = a.accum;
   p.accum_div = a.accum_div;
+  if (a.ksize == 7) return launch_pair32w<7>(p, s);
+  if (a.ksize == 11) return launch_pair32w<11>(p, s);
   if (g_pair32s_waves == 4) {
     if (p.y16 && p.y) return launch_pair32s_t<true, true, 4>(p, s);
     if (p.y16) return launch_pair32s_t<true, false, 4>(p, s);

@@ -1109,14 +1109,17 @@ def test_streaming_upsampler_matches_the_polyphase_conv_and_torch(cin, T, B):
     assert (got.cpu().double() - y64).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("k", [3, 7, 11])
 @pytest.mark.parametrize("T,d,B", [(1, 1, 1), (5, 5, 2), (239, 3, 1), (240, 1, 2), (241, 5, 2), (1000, 3, 3), (4099, 5, 2)], ids=lambda v: str(v))
-def test_streaming_three_tap_step_c32_matches_the_general_fused_step(T, d, B):
-    """pair32s_kernel (the 3-tap ResBlock1 step of the 32-channel stage, `sat_conv_set_option("pair32s")`) against the general fused
-    step it replaces (same split-f16 products, another accumulation order: f32 rounding) and against torch in float64, in its three
-    output forms — planes only (the first two steps of a branch), f32 with the MRF accumulation, both; tile edges at 240"""
+def test_streaming_resblock_step_c32_matches_the_general_fused_step(T, d, B, k):
+    """pair32s_kernel (3 taps: both convs' fragments resident) and pair32w_kernel (7 / 11 taps: waves specialised by conv, a
+    two-stage pipeline over tiles) — the ResBlock1 step of the 32-channel stage (`sat_conv_set_option("pair32s" / "pair32w")`)
+    against the general fused step they replace (same split-f16 products, another accumulation order: f32 rounding) and against
+    torch in float64, in the three output forms — planes only (the first two steps of a branch), f32 with the MRF accumulation,
+    both; tile edges at 240"""
     ops, packing = _ops()
     from satools_amd import _lib
-    C, k = 32, 3
+    C = 32
     x = _rand(B, C, T, seed=1).to(DEV)
     pk = packing.pack_conv_weight_f16x3
     w1f, w2f = _rand(C, C, k, seed=2, scale=0.6 / np.sqrt(C * k)), _rand(C, C, k, seed=3, scale=0.6 / np.sqrt(C * k))
@@ -1126,7 +1129,8 @@ def test_streaming_three_tap_step_c32_matches_the_general_fused_step(T, d, B):
     acc0 = _rand(B, C, T, seed=6).to(DEV)
 
     def run(opt):
-        _lib.check(_lib.lib().sat_conv_set_option(b"pair32s", opt), "sat_conv_set_option")
+        for name in (b"pair32s", b"pair32w"):
+            _lib.check(_lib.lib().sat_conv_set_option(name, opt), "sat_conv_set_option")
         try:
             ys = ops.split_like(B, C, T, DEV)
             ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, y_split=ys, y_split_slope=0.1, planes_residual=True, no_y=True)
@@ -1137,15 +1141,17 @@ def test_streaming_three_tap_step_c32_matches_the_general_fused_step(T, d, B):
             ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, y_split=ysb, y_split_slope=0.1, planes_residual=True, out=yb)
             return ops.unsplit(ys), yf, yb, ops.unsplit(ysb), name_planes
         finally:
-            _lib.check(_lib.lib().sat_conv_set_option(b"pair32s", 1), "sat_conv_set_option")
+            for name in (b"pair32s", b"pair32w"):
+                _lib.check(_lib.lib().sat_conv_set_option(name, 1), "sat_conv_set_option")
 
     new, old = run(1), run(0)
-    assert "pair32s_kernel" in new[4] and "pair32s_kernel" not in old[4]
+    kern = "pair32s_kernel" if k == 3 else "pair32w_kernel"
+    assert kern in new[4] and kern not in old[4]
     for a, b in zip(new[:4], old[:4]):
         assert (a - b).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item())
     xd = x.double().cpu()
-    t1 = F.conv1d(F.leaky_relu(xd, 0.1), w1f.double(), b1.double().cpu(), dilation=d, padding=d)
-    y64 = xd + F.conv1d(F.leaky_relu(t1, 0.1), w2f.double(), b2.double().cpu(), padding=1)
+    t1 = F.conv1d(F.leaky_relu(xd, 0.1), w1f.double(), b1.double().cpu(), dilation=d, padding=d * (k - 1) // 2)
+    y64 = xd + F.conv1d(F.leaky_relu(t1, 0.1), w2f.double(), b2.double().cpu(), padding=(k - 1) // 2)
     assert (new[2].cpu().double() - y64).abs().max().item() < 1e-5
     assert (new[1].cpu().double() - (acc0.cpu().double() + y64) / 3).abs().max().item() < 1e-5
     assert (new[0].cpu().double() - F.leaky_relu(y64, 0.1)).abs().max().item() < 1e-5
