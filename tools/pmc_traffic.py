@@ -26,7 +26,7 @@ def main():
     w2v2 = len(sys.argv) > 3 and sys.argv[3] == "w2v2"
     if w2v2:
         return main_w2v2(fetch, write, int(sys.argv[4]) if len(sys.argv) > 4 else 5)
-    gen = lambda n: ("conv1d_f16x3" in n or "resblock_pair" in n or "convpost" in n or "act_split" in n or "mrf" in n)
+    gen = lambda n: ("conv1d_f16x3" in n or "resblock_pair" in n or "convpost" in n or "act_split" in n or "mrf" in n or "ups2_kernel" in n or "pair32" in n)
     # generator forwards in that run: 3 convert() steps + 1 warm + 3 timed forwards of the roofline probe
     n_post = max(1, sum(v[0] for k, v in fetch.items() if "convpost_kernel" in k))
     out = {"generator_forwards_in_run": n_post, "kernels": {}}
