@@ -59,7 +59,7 @@ int sat_clock_probe(int64_t* samples, int n, int period_us, void* stream);
 int sat_mrf_debug_stamps(int64_t* buf);
 /* the same for sat_attention_f16x3 (tools/bench_attention.py stamps): block (0, 0, 0), 7 points of the first key block x 8 waves */
 int sat_attention_debug_stamps(int64_t* buf);
-/* the same for block 0 of the wave-specialised ResBlock step at C = 32 (csrc/pair32s.hip: pair32w_kernel): [8 steps][6 stamps][8 waves] */
+/* the same for block 0 of the wave-specialised ResBlock step at C = 32 (csrc/pair32s.hip: pairw_kernel): [8 steps][6 stamps][8 waves] */
 int sat_pair32_debug_stamps(int64_t* buf);
 
 /* ------------------------------------------------------------------------------------------

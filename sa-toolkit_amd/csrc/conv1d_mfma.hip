@@ -1795,6 +1795,7 @@ extern "C" int sat_resblock_pair_scaled_f16x3(const sat_conv1d_desc* d, const fl
       default: return launch_pair16<11>(a, d->B, s);
     }
   }
+  if (a.cin_g == 64 && g_pair32s && pair32s_supports(a)) return launch_pair32s(a, d->B, s);
   if (a.cin_g == 64) {
     SAT_REQUIRE(pair64_supports(a), "resblock_pair(C = 64): split planes in, residual from planes, (ksize - 1) * dilation <= 64");
     return launch_pair64(a, d->B, s);
@@ -1833,6 +1834,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "lean11")) { g_lean11 = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32s")) { g_pair32s = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32w")) { pair32w_set(value); return SAT_OK; }
+  if (!strcmp(name, "pair64w")) { pair64w_set(value); return SAT_OK; }
   if (!strcmp(name, "lean_balance")) { lean_set_balance(value); return SAT_OK; }
   if (!strcmp(name, "pair32s_waves")) { pair32s_set_waves(value); return SAT_OK; }
   if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }

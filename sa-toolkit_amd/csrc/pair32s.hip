@@ -40,7 +40,7 @@ struct P32Args {
   float d1, d2, slope, inv_slope, y_slope, accum_div;
   int accum;
   int tiles_t, total, per_xcd, nslots;
-  long long* dbg;        // diagnostics (sat_pair32_debug_stamps): block 0 of pair32w_kernel records cycle counters, [step][stamp][wave]
+  long long* dbg;        // diagnostics (sat_pair32_debug_stamps): block 0 of pairw_kernel records cycle counters, [step][stamp][wave]
 };
 
 template <bool Y16, bool YF, int NW>
@@ -255,15 +255,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) pair32s_kernel(const
 // no other memory traffic); the conv2 waves fetch their residual words from the planes in global memory (L2: the image
 // of the same tile went by a moment ago), so an image is dead once conv1 has read it and two buffers suffice.
 // ------------------------------------------------------------------------------------------------
+//
+// C = 64 at 3 taps (one conv: 3 taps x 4 row tiles x 2 K steps x (hi, lo) = 192 VGPRs) runs the same pipeline with each role's
+// four waves split 2 x 2 over (row half, column half): a wave keeps the fragments of two row tiles (96 VGPRs) and reads the B
+// fragments of its columns (both row halves read them: twice the LDS reads, still ~65 % of the LDS at full MFMA rate).
 namespace {
-template <int KS> struct P32W {
-  static constexpr int TQ = 240;                    // output positions per tile
+template <int C, int KS> struct P32W {
+  static constexpr int TQ = C == 32 ? 240 : 112;    // output positions per tile
   static constexpr int HC = (KS - 1) / 2;           // taps left of the centre
   static constexpr int HL = HC * 6;                 // image start left of the tile: HC (conv2) + HC * dilation <= 5 HC (conv1)
-  static constexpr int PITCH = 320;                 // units per plane row of an image (TQ + 2 HL <= 300: five DMA pieces)
-  static constexpr int IMG = 8 * PITCH;             // 40 KB
-  static constexpr int T1P = 256;                   // units per plane row of an inner-activation buffer (TQ + 2 HC <= 250)
-  static constexpr int T1IMG = 8 * T1P;             // 32 KB
+  static constexpr int ROWS = C / 4;                // plane rows: C / 16 chunks x 4
+  static constexpr int PITCH = C == 32 ? 320 : 128; // units per plane row of an image (TQ + 2 HL <= 300 / 124: five / two DMA pieces)
+  static constexpr int IMG = ROWS * PITCH;          // 40 / 32 KB
+  static constexpr int T1P = C == 32 ? 256 : 128;   // units per plane row of an inner-activation buffer (TQ + 2 HC <= 250 / 114)
+  static constexpr int T1IMG = ROWS * T1P;          // 32 KB
 };
 }  // namespace
 
@@ -285,18 +290,22 @@ constexpr int P32_DBG_STEPS = 8, P32_DBG_STAMPS = 6;
     }                                                                                                       \
   } while (0)
 
-template <int KS, bool Y16, bool YF>
-__global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
+template <int C, int KS, bool Y16, bool YF>
+__global__ void __launch_bounds__(512, 1) pairw_kernel(const P32Args p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-  using G = P32W<KS>;
+  using G = P32W<C, KS>;
   constexpr int TQ = G::TQ, HC = G::HC, HL = G::HL, PITCH = G::PITCH, IMG = G::IMG, T1P = G::T1P, T1IMG = G::T1IMG;
-  constexpr int NSA = 16, NSB = TQ / 16;
+  constexpr int NSA = T1P / 16, NSB = TQ / 16;
+  constexpr int KST = C / 32;                         // K steps (32 channels) per tap
+  constexpr int CG = 4 / (C / 32);                    // column groups of a role's four waves (x C / 32 row halves)
+  static_assert(NSA == 4 * CG, "four subtiles per wave");
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, j16 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave < 4;
   const int rw = wave & 3;                            // wave index inside its role
+  const int mh = C == 32 ? 0 : rw / CG, cg = C == 32 ? rw : rw % CG;   // its row half (two 16-row tiles: 2 mh, 2 mh + 1) and column group
   const unsigned OOB = 0x80000000u;
   uint4* const T1 = lds4 + 2 * IMG;
 
@@ -306,39 +315,43 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
   if (tile0 >= tile_end) return;
   const int n_my = (tile_end - tile0 + p.nslots - 1) / p.nslots;
 
-  // pieces r0 .. r1 - 1 of a tile's image: 8 rows x 5 pieces of 64 units over the 4 producer waves (10 each)
+  // pieces r0 .. r1 - 1 of a tile's image: ROWS rows x PPR pieces of 64 units over the 4 producer waves (NPW = 10 / 8 each)
+  constexpr int PPR = PITCH / 64, NPW = G::ROWS * PPR / 4;
   auto stage = [&](int tl, uint4* img, int r0, int r1) __attribute__((always_inline)) {
     const int ub = __builtin_amdgcn_readfirstlane(tl / p.tiles_t);
     const int p0 = (tl - ub * p.tiles_t) * TQ;
-    const i32x4 xrs = dma_rsrc((const char*)p.x16 + (long long)ub * 32 * p.T * 4, (unsigned)(32 * p.T * 4));
+    const i32x4 xrs = dma_rsrc((const char*)p.x16 + (long long)ub * C * p.T * 4, (unsigned)(C * p.T * 4));
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < NPW; ++r) {
       if (r < r0 || r >= r1) continue;
-      const int piece = rw + 4 * r, row = piece / 5, c = (piece % 5) * 64 + lane;
+      const int piece = rw + 4 * r, row = piece / PPR, c = (piece % PPR) * 64 + lane;
       const int pos = p0 - HL + c;
       const unsigned voff = (pos >= 0 && pos < p.T) ? (unsigned)((row * p.T + pos) * 16) : OOB;
-      lds_dma16(img + row * PITCH + (piece % 5) * 64, xrs, voff, 0u);
+      lds_dma16(img + row * PITCH + (piece % PPR) * 64, xrs, voff, 0u);
     }
   };
-  if (producer) stage(tile0, lds4, 0, 10);
+  if (producer) stage(tile0, lds4, 0, NPW);
 
-  // this role's fragments: [tap][row tile] x (hi, lo); K group g = (chunk g >> 1, half g & 1) of the packing
-  h8 ah[KS][2], al[KS][2];
-  float4* const bias4 = (float4*)(T1 + 2 * T1IMG);   // [8] this role's bias, read back per epilogue (8 VGPRs the 11-tap consumer lacks)
+  // this role's fragments: [tap][K step][row tile of the wave's half] x (hi, lo); K group g of step ks = (chunk 2 ks + (g >> 1),
+  // half g & 1) of the packing
+  h8 ah[KS][KST][2], al[KS][KST][2];
+  float4* const bias4 = (float4*)(T1 + 2 * T1IMG);   // [2][C / 4] the roles' biases, read back per epilogue (8 VGPRs the 11-tap consumer lacks)
   {
     const uint4* w = (const uint4*)(producer ? p.w1 : p.w2);
     const float* bp = producer ? p.b1 : p.b2;
 #pragma unroll
     for (int t = 0; t < KS; ++t)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int u = ((((g >> 1) * KS + t) * 2) * 2 + (g & 1)) * 64 + 16 * m + j16;
-        ah[t][m] = __builtin_bit_cast(h8, w[u]);
-        al[t][m] = __builtin_bit_cast(h8, w[u + 128]);
-      }
-    if (rw == 0 && lane < 32) ((float*)(bias4 + (producer ? 0 : 8)))[lane] = bp[lane];
+      for (int ks = 0; ks < KST; ++ks)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int u = ((((2 * ks + (g >> 1)) * KS + t) * 2) * 2 + (g & 1)) * 64 + 16 * (2 * mh + m) + j16;
+          ah[t][ks][m] = __builtin_bit_cast(h8, w[u]);
+          al[t][ks][m] = __builtin_bit_cast(h8, w[u + 128]);
+        }
+    if (rw == 0 && lane < C) ((float*)(bias4 + (producer ? 0 : C / 4)))[lane] = bp[lane];
   }
-  const float4* const my_bias = bias4 + (producer ? 0 : 8) + g;      // channels 16 m + 4 g ..: my_bias[4 m]
+  const float4* const my_bias = bias4 + (producer ? 0 : C / 4) + 8 * mh + g;      // channels 16 (2 mh + m) + 4 g ..: my_bias[4 m]
   const float descale = producer ? p.d1 : p.d2;
   const int d = p.dil;
   const int krow = (g >> 1) * 4 + (g & 1);           // a K group's plane row: hi rows (chunk * 4 + half), lo rows + 2
@@ -348,16 +361,19 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
   // subtile i + 1 are requested under the last MFMAs of subtile i, so its epilogue and their LDS round trip overlap).  Both
   // loops are fully unrolled: the ring slot (i KS + t) % PD is a compile-time number.  (PD = 1, no real read-ahead, in the
   // 11-tap kernels with an f32 output: registers they do not have; the SIMD's other wave covers.)
+  // With two K steps per tap (C = 64) the ring runs over (tap, K step): entry q = t KST + ks at base[t step + ks ks_off].
   constexpr int PD = KS == 11 ? (YF ? 1 : 2) : 3;
-  auto run_conv = [&](auto base_of, int step_, int lo_off, int ns, auto before, auto epi, auto stamp) __attribute__((always_inline)) {
+  constexpr int KQ = KS * KST;
+  auto run_conv = [&](auto base_of, int step_, int ks_off, int lo_off, int ns, auto before, auto epi, auto stamp) __attribute__((always_inline)) {
     h8 ring_h[PD], ring_l[PD];
-    const int s0 = 4 * rw;
+    const int s0 = 4 * cg;
+    auto at = [&](int q) __attribute__((always_inline)) { return KST == 1 ? q * step_ : (q / KST) * step_ + (q % KST) * ks_off; };
     {
       const uint4* b0 = base_of(s0);
 #pragma unroll
       for (int q = 0; q < PD; ++q) {
-        ring_h[q] = __builtin_bit_cast(h8, b0[q * step_]);
-        ring_l[q] = __builtin_bit_cast(h8, b0[lo_off + q * step_]);
+        ring_h[q] = __builtin_bit_cast(h8, b0[at(q)]);
+        ring_l[q] = __builtin_bit_cast(h8, b0[lo_off + at(q)]);
       }
     }
     constexpr int UNR = PD > 1 ? 4 : 1;      // (a ring of one needs no compile-time slot: keep the loop rolled, it spares registers)
@@ -370,21 +386,21 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
         before(i, s_, has_next);
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int t = 0; t < KS; ++t) {
-          const int slot = (i * KS + t) % PD;
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t][0], ring_h[slot], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t][1], ring_h[slot], acc[1], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][0], ring_l[slot], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][1], ring_l[slot], acc[1], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][0], ring_h[slot], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][1], ring_h[slot], acc[1], 0, 0, 0);
+        for (int q = 0; q < KQ; ++q) {
+          const int slot = (i * KQ + q) % PD, t = q / KST, ks = q % KST;
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t][ks][0], ring_h[slot], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t][ks][1], ring_h[slot], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][ks][0], ring_l[slot], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][ks][1], ring_l[slot], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][ks][0], ring_h[slot], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][ks][1], ring_h[slot], acc[1], 0, 0, 0);
           if (P32W_SB) __builtin_amdgcn_sched_barrier(0);
-          if (t + PD < KS) {
-            ring_h[slot] = __builtin_bit_cast(h8, bs[(t + PD) * step_]);
-            ring_l[slot] = __builtin_bit_cast(h8, bs[lo_off + (t + PD) * step_]);
+          if (q + PD < KQ) {
+            ring_h[slot] = __builtin_bit_cast(h8, bs[at(q + PD)]);
+            ring_l[slot] = __builtin_bit_cast(h8, bs[lo_off + at(q + PD)]);
           } else if (has_next) {
-            ring_h[slot] = __builtin_bit_cast(h8, nb[(t + PD - KS) * step_]);
-            ring_l[slot] = __builtin_bit_cast(h8, nb[lo_off + (t + PD - KS) * step_]);
+            ring_h[slot] = __builtin_bit_cast(h8, nb[at(q + PD - KQ)]);
+            ring_l[slot] = __builtin_bit_cast(h8, nb[lo_off + at(q + PD - KQ)]);
           }
           if (P32W_SB) __builtin_amdgcn_sched_barrier(0);
         }
@@ -400,22 +416,22 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
   // first subtile's of a tile at the end of the previous step, across the barrier
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   constexpr int RD = KS == 11 ? 1 : 2;
-  constexpr bool XB = KS == 7 && !YF;      // (the other kernels spill with these registers live across the barrier)
+  constexpr bool XB = (KS == 7 && !YF) || C == 64;      // (the other kernels spill with these registers live across the barrier)
   u32x4 rh[RD][2], rl[RD][2];
   float yv[2][4];
   auto res_load = [&](int set, int tile, int s_) __attribute__((always_inline)) {
     const int b = __builtin_amdgcn_readfirstlane(tile / p.tiles_t);
     const int pos = (tile - b * p.tiles_t) * TQ + 16 * s_ + j16;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.x16 + (long long)b * 32 * p.T * 4), 0, (unsigned)(32 * p.T * 4), 0x00020000);
+        (void*)((const char*)p.x16 + (long long)b * C * p.T * 4), 0, (unsigned)(C * p.T * 4), 0x00020000);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const unsigned off = pos < p.T ? (unsigned)((((m * 4 + (g >> 1)) * p.T + pos) * 16) + 8 * (g & 1)) : OOB;
+      const unsigned off = pos < p.T ? (unsigned)(((((2 * mh + m) * 4 + (g >> 1)) * p.T + pos) * 16) + 8 * (g & 1)) : OOB;
       rh[set][m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));              // (narrowed to 8 bytes)
       rl[set][m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 2 * p.T * 16, 0));
     }
   };
-  if (XB && !producer) res_load(0, tile0, 4 * rw);
+  if (XB && !producer) res_load(0, tile0, 4 * cg);
 
   for (int step = 0; step <= n_my; ++step) {
     P32_STAMP(0);
@@ -431,7 +447,7 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
       uint4* t1 = T1 + (step & 1) * T1IMG;
       // inner column u <-> position p0 - HC + u; tap t reads image column u + (HL - HC - HC d) + t d
       const uint4* xb = img + krow * PITCH + j16 + (HL - HC) - HC * d;
-      run_conv([&](int s_) { return xb + 16 * s_; }, d, 2 * PITCH, NSA, [](int, int, bool) {},
+      run_conv([&](int s_) { return xb + 16 * s_; }, d, 8 * PITCH, 2 * PITCH, NSA, [](int, int, bool) {},
                [&](int, int s_, f32x4 (&acc)[2]) __attribute__((always_inline)) {
                  const int pos = p0 - HC + 16 * s_ + j16;
                  const bool inside = pos >= 0 && pos < p.T;          // zero padding of the second conv
@@ -450,7 +466,7 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
                    const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
                    const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
                    const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
-                   u32x2* dst = (u32x2*)(t1 + (m * 4 + (g >> 1)) * T1P + 16 * s_ + j16) + (g & 1);
+                   u32x2* dst = (u32x2*)(t1 + ((2 * mh + m) * 4 + (g >> 1)) * T1P + 16 * s_ + j16) + (g & 1);
                    dst[0] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
                    dst[2 * T1P * 2] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
                  }
@@ -460,8 +476,9 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
                  // for ~3500 cycles and hold up the conv2 waves' residual loads (cycle stamps, tools/stamp_pair32.py)
                  if (step + 1 < n_my) {
                    const int i = idx - 2;
-                   stage(tile0 + (step + 1) * p.nslots, lds4 + ((step + 1) & 1) * IMG, i == 0 ? 0 : i == 1 ? 3 : i == 2 ? 6 : 8,
-                         i == 0 ? 3 : i == 1 ? 6 : i == 2 ? 8 : 10);
+                   const int r0 = NPW == 10 ? (i == 0 ? 0 : i == 1 ? 3 : i == 2 ? 6 : 8) : 2 * i;
+                   const int r1 = NPW == 10 ? (i == 0 ? 3 : i == 1 ? 6 : i == 2 ? 8 : 10) : 2 * i + 2;
+                   stage(tile0 + (step + 1) * p.nslots, lds4 + ((step + 1) & 1) * IMG, r0, r1);
                  }
                  P32_STAMP(idx);
                });
@@ -472,12 +489,12 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
       const int p0 = (tile - b * p.tiles_t) * TQ;
       const uint4* t1 = T1 + ((step - 1) & 1) * T1IMG;
       const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(Y16 ? (char*)p.y16 + (long long)b * 32 * p.T * 4 : (char*)p.x16), 0, Y16 ? (unsigned)(32 * p.T * 4) : 0u, 0x00020000);
+          (void*)(Y16 ? (char*)p.y16 + (long long)b * C * p.T * 4 : (char*)p.x16), 0, Y16 ? (unsigned)(C * p.T * 4) : 0u, 0x00020000);
       const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(YF ? (char*)(p.y + (long long)b * p.y_bs) : (char*)p.x16), 0, YF ? (unsigned)(32 * p.y_cs * 4) : 0u, 0x00020000);
+          (void*)(YF ? (char*)(p.y + (long long)b * p.y_bs) : (char*)p.x16), 0, YF ? (unsigned)(C * p.y_cs * 4) : 0u, 0x00020000);
       // output column o <-> position p0 + o, inner columns o + tap
       const uint4* tb = t1 + krow * T1P + j16;
-      run_conv([&](int s_) { return tb + 16 * s_; }, 1, 2 * T1P, NSB,
+      run_conv([&](int s_) { return tb + 16 * s_; }, 1, 8 * T1P, 2 * T1P, NSB,
                [&](int i, int s_, bool has_next) __attribute__((always_inline)) {
                  if (!XB && i == 0) res_load(0, tile, s_);
                  if (RD == 2) {
@@ -492,7 +509,7 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
 #pragma unroll
                      for (int k = 0; k < 4; ++k)
                        yv[m][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                                yrs, pos < p.T ? (unsigned)(((16 * m + 4 * g + k) * p.y_cs + pos) * 4) : OOB, 0, 0));
+                                                                yrs, pos < p.T ? (unsigned)(((16 * (2 * mh + m) + 4 * g + k) * p.y_cs + pos) * 4) : OOB, 0, 0));
                  }
                },
                [&](int i, int s_, f32x4 (&acc)[2]) __attribute__((always_inline)) {
@@ -520,7 +537,7 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
 #pragma unroll
                      for (int k = 0; k < 4; ++k)
                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), yrs,
-                                                             ok ? (unsigned)(((16 * m + 4 * g + k) * p.y_cs + pos) * 4) : OOB, 0, 0);
+                                                             ok ? (unsigned)(((16 * (2 * mh + m) + 4 * g + k) * p.y_cs + pos) * 4) : OOB, 0, 0);
                    }
                    if (Y16) {
                      float u[4];
@@ -530,14 +547,14 @@ __global__ void __launch_bounds__(512, 1) pair32w_kernel(const P32Args p) {
                      const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
                      const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
                      const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
-                     const unsigned off = ok ? (unsigned)((((m * 4 + (g >> 1)) * p.T + pos) * 16) + 8 * (g & 1)) : OOB;
+                     const unsigned off = ok ? (unsigned)(((((2 * mh + m) * 4 + (g >> 1)) * p.T + pos) * 16) + 8 * (g & 1)) : OOB;
                      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)}, y16rs, off, 0, 0);
                      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)}, y16rs, off, 2 * p.T * 16, 0);
                    }
                  }
                },
                [&](int idx) __attribute__((always_inline)) { P32_STAMP(idx); });
-      if (XB && step < n_my) res_load(0, tile0 + step * p.nslots, 4 * rw);      // the next tile's first subtile (set 0 is free again)
+      if (XB && step < n_my) res_load(0, tile0 + step * p.nslots, 4 * cg);      // the next tile's first subtile (set 0 is free again)
     }
   }
 }
@@ -548,11 +565,11 @@ int pair32_debug_stamps(long long* buf) {
   return P32_DBG_STEPS * P32_DBG_STAMPS * 8;
 }
 
-template <int KS, bool Y16, bool YF>
-static int launch_pair32w_t(P32Args& p, hipStream_t s) {
-  using G = P32W<KS>;
-  const size_t lds_bytes = (size_t)(2 * G::IMG + 2 * G::T1IMG + 16) * 16;   // 144 KB + the bias table
-  auto kern = pair32w_kernel<KS, Y16, YF>;
+template <int C, int KS, bool Y16, bool YF>
+static int launch_pairw_t(P32Args& p, hipStream_t s) {
+  using G = P32W<C, KS>;
+  const size_t lds_bytes = (size_t)(2 * G::IMG + 2 * G::T1IMG + 32) * 16;   // 144 / 128 KB + the bias table
+  auto kern = pairw_kernel<C, KS, Y16, YF>;
   static std::atomic<uint64_t> attr_done{0};
   int dev;
   if (attr_needed_on_current_device(attr_done, &dev)) {
@@ -565,15 +582,15 @@ static int launch_pair32w_t(P32Args& p, hipStream_t s) {
   p.nslots = std::max(1, std::min(32, p.per_xcd));
   p.dbg = g_pair32_dbg;
   hipLaunchKernelGGL(kern, dim3(8 * p.nslots), dim3(512), lds_bytes, s, p);
-  SAT_LAUNCH_CHECK("pair32w_kernel");
+  SAT_LAUNCH_CHECK("pairw_kernel");
   return SAT_OK;
 }
 
-template <int KS>
-static int launch_pair32w(P32Args& p, hipStream_t s) {
-  if (p.y16 && p.y) return launch_pair32w_t<KS, true, true>(p, s);
-  if (p.y16) return launch_pair32w_t<KS, true, false>(p, s);
-  return launch_pair32w_t<KS, false, true>(p, s);
+template <int C, int KS>
+static int launch_pairw(P32Args& p, hipStream_t s) {
+  if (p.y16 && p.y) return launch_pairw_t<C, KS, true, true>(p, s);
+  if (p.y16) return launch_pairw_t<C, KS, true, false>(p, s);
+  return launch_pairw_t<C, KS, false, true>(p, s);
 }
 
 static int g_pair32s_waves = 8;
@@ -597,13 +614,18 @@ static int launch_pair32s_t(P32Args& p, hipStream_t s) {
   return SAT_OK;
 }
 
-static int g_pair32w = 1;   // 7 and 11 taps on the wave-specialised kernel
+static int g_pair32w = 1;   // 7 and 11 taps at C = 32 on the wave-specialised kernel
+static int g_pair64w = 0;   // 3 taps at C = 64: level with the general fused step (133-141 against 136-157 us: with 36 MFMAs per wave and
+                            // subtile the conv2 waves' epilogue, the same per subtile as at C = 32, bounds the step) — off by default
 void pair32w_set(int v) { g_pair32w = v != 0; }
+void pair64w_set(int v) { g_pair64w = v != 0; }
 
-// the fused steps these kernels serve: C = 32, dilation <= 5, planes in, residual from the planes
+// the fused steps these kernels serve: C = 32 (3 / 7 / 11 taps) and C = 64 (3 taps), dilation <= 5, planes in, residual from the planes
 bool pair32s_supports(const ConvArgs& a) {
   // (11 taps with an f32 output: the conv2 waves run out of registers — no read-ahead, spills — and measured 212 against 184 us)
-  return a.cin_g == 32 && a.rows_g == 32 && (a.ksize == 3 || (g_pair32w && (a.ksize == 7 || (a.ksize == 11 && a.no_y)))) && a.dil >= 1 &&
+  const bool shape = (a.cin_g == 32 && a.rows_g == 32 && (a.ksize == 3 || (g_pair32w && (a.ksize == 7 || (a.ksize == 11 && a.no_y))))) ||
+                     (a.cin_g == 64 && a.rows_g == 64 && a.ksize == 3 && g_pair64w);
+  return shape && a.dil >= 1 &&
          a.dil <= P32_HL - 1 && a.x16 && a.res16 == a.x16 && !a.res &&
          !a.ch_scale && !a.relu && !a.gelu && a.co_pad == 64 && a.res_scale == 1.f && !a.y16_f8 && (a.y16 || !a.no_y);
 }
@@ -629,8 +651,9 @@ int launch_pair32s(const ConvArgs& a, int B, hipStream_t s) {
   p.y_slope = a.y16_slope;
   p.accum = a.accum;
   p.accum_div = a.accum_div;
-  if (a.ksize == 7) return launch_pair32w<7>(p, s);
-  if (a.ksize == 11) return launch_pair32w<11>(p, s);
+  if (a.cin_g == 64) return launch_pairw<64, 3>(p, s);
+  if (a.ksize == 7) return launch_pairw<32, 7>(p, s);
+  if (a.ksize == 11) return launch_pairw<32, 11>(p, s);
   if (g_pair32s_waves == 4) {
     if (p.y16 && p.y) return launch_pair32s_t<true, true, 4>(p, s);
     if (p.y16) return launch_pair32s_t<true, false, 4>(p, s);

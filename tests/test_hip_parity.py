@@ -1109,17 +1109,16 @@ def test_streaming_upsampler_matches_the_polyphase_conv_and_torch(cin, T, B):
     assert (got.cpu().double() - y64).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("k", [3, 7, 11])
-@pytest.mark.parametrize("T,d,B", [(1, 1, 1), (5, 5, 2), (239, 3, 1), (240, 1, 2), (241, 5, 2), (1000, 3, 3), (4099, 5, 2)], ids=lambda v: str(v))
-def test_streaming_resblock_step_c32_matches_the_general_fused_step(T, d, B, k):
-    """pair32s_kernel (3 taps: both convs' fragments resident) and pair32w_kernel (7 / 11 taps: waves specialised by conv, a
-    two-stage pipeline over tiles) — the ResBlock1 step of the 32-channel stage (`sat_conv_set_option("pair32s" / "pair32w")`)
-    against the general fused step they replace (same split-f16 products, another accumulation order: f32 rounding) and against
-    torch in float64, in the three output forms — planes only (the first two steps of a branch), f32 with the MRF accumulation,
-    both; tile edges at 240"""
+@pytest.mark.parametrize("C,k", [(32, 3), (32, 7), (32, 11), (64, 3)])
+@pytest.mark.parametrize("T,d,B", [(1, 1, 1), (5, 5, 2), (111, 3, 1), (112, 1, 2), (113, 5, 2), (239, 3, 1), (240, 1, 2), (241, 5, 2), (1000, 3, 3), (4099, 5, 2)], ids=lambda v: str(v))
+def test_streaming_resblock_step_matches_the_general_fused_step(T, d, B, C, k):
+    """pair32s_kernel (C = 32, 3 taps: both convs' fragments resident) and pairw_kernel (C = 32 at 7 / 11 taps, C = 64 at 3 taps:
+    waves specialised by conv, a two-stage pipeline over tiles) — the ResBlock1 steps of the 32- and 64-channel stages
+    (`sat_conv_set_option("pair32s" / "pair32w" / "pair64w")`) against the general fused steps they replace (same split-f16
+    products, another accumulation order: f32 rounding) and against torch in float64, in the three output forms — planes only
+    (the first two steps of a branch), f32 with the MRF accumulation, both; tile edges at 240 (C = 32) and 112 (C = 64)"""
     ops, packing = _ops()
     from satools_amd import _lib
-    C = 32
     x = _rand(B, C, T, seed=1).to(DEV)
     pk = packing.pack_conv_weight_f16x3
     w1f, w2f = _rand(C, C, k, seed=2, scale=0.6 / np.sqrt(C * k)), _rand(C, C, k, seed=3, scale=0.6 / np.sqrt(C * k))
@@ -1129,7 +1128,7 @@ def test_streaming_resblock_step_c32_matches_the_general_fused_step(T, d, B, k):
     acc0 = _rand(B, C, T, seed=6).to(DEV)
 
     def run(opt):
-        for name in (b"pair32s", b"pair32w"):
+        for name in (b"pair32s", b"pair32w", b"pair64w"):
             _lib.check(_lib.lib().sat_conv_set_option(name, opt), "sat_conv_set_option")
         try:
             ys = ops.split_like(B, C, T, DEV)
@@ -1141,11 +1140,11 @@ def test_streaming_resblock_step_c32_matches_the_general_fused_step(T, d, B, k):
             ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, y_split=ysb, y_split_slope=0.1, planes_residual=True, out=yb)
             return ops.unsplit(ys), yf, yb, ops.unsplit(ysb), name_planes
         finally:
-            for name in (b"pair32s", b"pair32w"):
-                _lib.check(_lib.lib().sat_conv_set_option(name, 1), "sat_conv_set_option")
+            for name, default in ((b"pair32s", 1), (b"pair32w", 1), (b"pair64w", 0)):
+                _lib.check(_lib.lib().sat_conv_set_option(name, default), "sat_conv_set_option")
 
     new, old = run(1), run(0)
-    kern = "pair32s_kernel" if k == 3 else "pair32w_kernel"
+    kern = "pair32s_kernel" if (C, k) == (32, 3) else "pairw_kernel"
     assert kern in new[4] and kern not in old[4]
     for a, b in zip(new[:4], old[:4]):
         assert (a - b).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item())

@@ -6,8 +6,10 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import satools_amd
 from satools_amd import ops, packing, _lib
 
-B, C, T, dev = 32, 32, 40000, "cuda"
+B, dev = 32, "cuda"
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+T = 40000 * 32 // C
 
 
 def timed(f, n=20):
@@ -35,10 +37,11 @@ for d in (1, 3, 5):
     for opt in (0, 8, 4):
         _lib.check(_lib.lib().sat_conv_set_option(b"pair32s", int(opt > 0)), "set_option")
         _lib.check(_lib.lib().sat_conv_set_option(b"pair32w", int(opt > 0)), "set_option")
+        _lib.check(_lib.lib().sat_conv_set_option(b"pair64w", int(opt > 0)), "set_option")
         _lib.check(_lib.lib().sat_conv_set_option(b"pair32s_waves", opt), "set_option")
         t_planes = timed(lambda: ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, y_split=ys, y_split_slope=0.1, planes_residual=True, no_y=True))
         t_f32 = timed(lambda: ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, planes_residual=True, out=acc))
         row.append((t_planes, t_f32))
     mb = 2 * B * C * T * 4 / 1e6
-    print(f"k {k} dilation {d}: planes -> planes: general {row[0][0]:6.1f}, 8 waves {row[1][0]:6.1f}, 2 x 4 waves {row[2][0]:6.1f} us ({mb / row[2][0]:.2f} TB/s)   "
+    print(f"C {C} k {k} dilation {d}: planes -> planes: general {row[0][0]:6.1f}, 8 waves {row[1][0]:6.1f}, 2 x 4 waves {row[2][0]:6.1f} us ({mb / row[2][0]:.2f} TB/s)   "
           f"planes -> f32: {row[0][1]:6.1f}, {row[1][1]:6.1f}, {row[2][1]:6.1f} us")

@@ -1,4 +1,4 @@
-"""per-step timeline of the wave-specialised ResBlock step at C = 32 (csrc/pair32s.hip: pair32w_kernel) from its in-kernel cycle
+"""per-step timeline of the wave-specialised ResBlock step at C = 32 (csrc/pair32s.hip: pairw_kernel) from its in-kernel cycle
 stamps: python tools/stamp_pair32.py [k]"""
 import sys
 import numpy as np
