@@ -212,8 +212,12 @@ int sat_upsample2_f16x3(const void* x_split, const void* w_packed, const float* 
  * 0 = the conv tile, 1 = the 128 x 128 GEMM kernel, 2 = the LDS-DMA ring GEMM (32x32x16 MFMA shape) where its
  * 256-column tiles fit, 3 (default) = the ring GEMM on the 16x16x32 shape (results of 3 agree with 0-2 to f32 rounding
  * of the accumulation, 0-2 agree bit for bit); "lean3" / "lean7" / "lean11" (default 1) run 3- / 7- / 11-tap convs on
- * split planes without folded BatchNorm through the three-blocks-per-CU form of the conv tile (same bits as 0).  Unknown names return
- * SAT_ERR_INVALID. */
+ * split planes without folded BatchNorm through the three-blocks-per-CU form of the conv tile (same bits as 0); "lean_balance"
+ * (0 / 1 default / 2) dispatches the ragged end of every row of that tile as 128-column half tiles after the full ones (same
+ * bits); "pair32s" (default 1), "pair32w" (1), "pair64w" (0) send sat_resblock_pair_scaled_f16x3 at C = 32 with 3 taps,
+ * C = 32 with 7 / 11 taps and C = 64 with 3 taps (planes in, residual from the planes, dilation <= 5) through the streaming /
+ * wave-specialised kernels of csrc/pair32s.hip (agree with the general fused step to f32 rounding of the accumulation);
+ * "pair32s_waves" (8 / 4) picks that file's block shape at 3 taps.  Unknown names return SAT_ERR_INVALID. */
 int sat_conv_set_option(const char* name, int value);
 /* f32 [B][C][T] -> split planes of lrelu(x, slope) in `format` (SAT_SPLIT_*); C % 16 == 0 */
 int sat_act_split_f32(const float* x, void* x_split, int B, int C, int T, float slope, int format, void* stream);
