@@ -360,7 +360,10 @@ __device__ __forceinline__ void fft8192_pass(float* re, float* im, const float2*
   __syncthreads();
 }
 
-// stages first .. 13 of the 8192-point radix-2 DIT FFT (input in bit-reversed order)
+// stages first .. 13 of the 8192-point radix-2 DIT FFT (input in bit-reversed order).
+// (Round 3, measured and not kept: the twiddles of a radix-8 pass in registers, requested one pass ahead — nlfer 268 -> 418 us;
+// the last pass computing only the wanted output bins, 7 of 24 butterfly results and 1 of 8 LDS writes — 268 -> 309 us.
+// The compiler's interleaving of the table loads with the butterflies of the plain pass beats both.)
 __device__ void fft8192_from(float* re, float* im, const float2* __restrict__ tw, int first) {
   int s = first;
   const int lead = (FFT_LOG - first + 1) % 3;
@@ -426,12 +429,51 @@ __global__ void __launch_bounds__(256) yaapt_energy_norm_kernel(const float* __r
 
 // spectral track, per voiced frame: 1120 samples x kaiser, minus mean -> FFT -> |X| -> SHC -> peaks
 // cand layout: [b][8][nframes] = pitch[0..3], merit[0..3]
+// Two kernels (round 3): the FFT block holds 64 KB of LDS and 16 waves, the SHC / peak search after it is a 256-thread,
+// then one-thread, latency-bound tail of about the same duration — kept in one kernel it pinned those 64 KB for twice as
+// long, and two such blocks leave no room on a CU for the generator's conv blocks of the other job streams.  The FFT kernel
+// now ends at the magnitude window (n_mag <= 1280 floats per frame, through the workspace); the tail runs with 6 KB of LDS.
+// Same arithmetic in the same order: the F0 track is unchanged bit for bit.
+constexpr int SPEC_MAGP = 5 * 256;      // floats per frame of the magnitude hand-over (the kernels' 5 x 256 window)
 __global__ void __launch_bounds__(FFT_THREADS) yaapt_spec_kernel(const float* __restrict__ filt, const float* __restrict__ kaiser,
                                                         const float2* __restrict__ tw, const int* __restrict__ vuv,
-                                                        float* __restrict__ cand, const int* __restrict__ U, const Plan P) {
+                                                        float* __restrict__ magbuf, const int* __restrict__ U, const Plan P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* re = lds;
   float* im = lds + FFT_N;
+  __shared__ float red[8];
+  const int tid = threadIdx.x;
+  const int f = blockIdx.x, b = blockIdx.y;
+  const int nf = P.nframes;                       // row stride
+  if (f >= ulen(U, b, 2, nf)) return;
+  if (!vuv[(size_t)b * nf + f]) return;           // unvoiced: the tail kernel writes the defaults
+  const float* x = filt + ((size_t)b * 2 + 1) * P.Lz + (size_t)f * P.frame_jump;
+  // windowed slice and its mean (nframe_size <= 5*256)
+  float part = 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = tid + 256 * k;
+    if (tid < 256 && j < P.nframe_size) part += x[j] * kaiser[j];
+  }
+  const float mean = block_sum256(part, red) / (float)P.nframe_size;
+  const int first = fft8192_load_padded(re, im, P.nframe_size, [&](int j) { return x[j] * kaiser[j] - mean; });
+  const int n_mag = P.min_shc * (P.nharm + 1) + (P.max_shc - P.min_shc) * (P.nharm + 1) + P.wl;  // exclusive bound
+  fft8192_from(re, im, tw, first);
+  if (tid >= 256) return;
+  // magnitude[i] = i < half_wl ? 0 : |X[i - half_wl]|
+  float* mo = magbuf + ((size_t)b * nf + f) * SPEC_MAGP;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = tid + 256 * k;
+    float v = 0.f;
+    if (i < n_mag && i >= P.half_wl) v = hypotf(re[i - P.half_wl], im[i - P.half_wl]);
+    if (i < n_mag) mo[i] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) yaapt_spec_peaks_kernel(const float* __restrict__ magbuf, const int* __restrict__ vuv,
+                                                               float* __restrict__ cand, const int* __restrict__ U, const Plan P) {
+  __shared__ float mag[SPEC_MAGP];
   __shared__ float red[8];
   __shared__ float s_shc[256];
   __shared__ unsigned char s_flag[256];
@@ -445,35 +487,12 @@ __global__ void __launch_bounds__(FFT_THREADS) yaapt_spec_kernel(const float* __
     if (tid < MAXP) { cp[(size_t)tid * nf + f] = 0.f; cm[(size_t)tid * nf + f] = 1.f; }
     return;
   }
-  const float* x = filt + ((size_t)b * 2 + 1) * P.Lz + (size_t)f * P.frame_jump;
-  // windowed slice and its mean (nframe_size <= 5*256)
-  float part = 0.f;
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int j = tid + 256 * k;
-    if (tid < 256 && j < P.nframe_size) part += x[j] * kaiser[j];
-  }
-  const float mean = block_sum256(part, red) / (float)P.nframe_size;
-  const int first = fft8192_load_padded(re, im, P.nframe_size, [&](int j) { return x[j] * kaiser[j] - mean; });
-  fft8192_from(re, im, tw, first);
-  if (tid >= 256) return;                  // whole waves: everything after the FFT keeps its 256-thread shape
-  // magnitude[i] = i < half_wl ? 0 : |X[i - half_wl]| ; written over the front of `im` is unsafe
-  // (both are inputs), so it goes to a separate region: reuse re[] after reading (two passes).
   const int n_mag = P.min_shc * (P.nharm + 1) + (P.max_shc - P.min_shc) * (P.nharm + 1) + P.wl;  // exclusive bound
-  float mg[5];
+  const float* mi = magbuf + ((size_t)b * nf + f) * SPEC_MAGP;
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int i = tid + 256 * k;
-    float v = 0.f;
-    if (i < n_mag && i >= P.half_wl) v = hypotf(re[i - P.half_wl], im[i - P.half_wl]);
-    mg[k] = v;
-  }
-  __syncthreads();
-  float* mag = re;
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int i = tid + 256 * k;
-    if (i < n_mag) mag[i] = mg[k];
+    if (i < n_mag) mag[i] = mi[i];
   }
   __syncthreads();
   // SHC[min_shc-1 + r] = sum_w prod_h mag[min_shc*(h+1) + r*(h+1) + w]
@@ -1038,7 +1057,7 @@ using namespace sat;
 static size_t yaapt_ws_floats(const Plan& P, int B) {
   const size_t nf = P.nframes;
   return (size_t)B * (2 * (size_t)P.Lz + 3 * nf /*e_raw, energy, vuv*/ + 8 * nf /*cand*/ + nf /*spec*/ + 4 /*scal*/ +
-                      2 * nf /*fmean*/ + 4 * nf /*tp, tm*/) + 64;
+                      2 * nf /*fmean*/ + 4 * nf /*tp, tm*/ + (size_t)SPEC_MAGP * nf /*magnitude windows*/) + 64;
 }
 
 extern "C" size_t sat_yaapt_workspace_bytes(const sat_yaapt_plan* plan, int B) {
@@ -1082,6 +1101,7 @@ static int yaapt_run(const sat_yaapt_plan* plan, const float* wav, const int32_t
   float* fmean = w;           w += (size_t)B * 2 * nf;
   float* tp = w;              w += (size_t)B * 2 * nf;
   float* tm = w;              w += (size_t)B * 2 * nf;
+  float* magbuf = w;          w += (size_t)B * nf * SPEC_MAGP;
   const float2* tw = (const float2*)twiddle;
   SAT_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
 
@@ -1104,8 +1124,10 @@ static int yaapt_run(const sat_yaapt_plan* plan, const float* wav, const int32_t
   SAT_LAUNCH_CHECK("yaapt_nlfer_kernel");
   hipLaunchKernelGGL(yaapt_energy_norm_kernel, dim3(B), dim3(256), 0, s, e_raw, energy, vuv, U, P);
   SAT_LAUNCH_CHECK("yaapt_energy_norm_kernel");
-  hipLaunchKernelGGL(yaapt_spec_kernel, dim3(P.nframes, B), dim3(FFT_THREADS), fft_lds, s, filt, kaiser, tw, vuv, cand, U, P);
+  hipLaunchKernelGGL(yaapt_spec_kernel, dim3(P.nframes, B), dim3(FFT_THREADS), fft_lds, s, filt, kaiser, tw, vuv, magbuf, U, P);
   SAT_LAUNCH_CHECK("yaapt_spec_kernel");
+  hipLaunchKernelGGL(yaapt_spec_peaks_kernel, dim3(P.nframes, B), dim3(256), 0, s, magbuf, vuv, cand, U, P);
+  SAT_LAUNCH_CHECK("yaapt_spec_peaks_kernel");
   const size_t post_lds = (size_t)nf * (4 + 4 + 3) * sizeof(float) + nf * 2 * sizeof(short) + nf * 5;
   hipLaunchKernelGGL(yaapt_spec_post_kernel, dim3(B), dim3(64), post_lds, s, cand, spec, scal, status, U, P);
   SAT_LAUNCH_CHECK("yaapt_spec_post_kernel");

@@ -8,14 +8,13 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import torch
 import satools_amd
 from satools_amd import synthetic
-import bench
 
 model = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1")
 model.to("cuda")
 model.eval()
 seeds = list(range(32))
 wav = synthetic.harm_batch(seeds).to("cuda")
-f0 = bench.analytic_f0(seeds).to("cuda")
+f0 = model.get_f0(wav).clone()        # what convert() computes on-path (YAAPT), handed over in the second line
 tg = synthetic.targets(model.spk, seeds)
 streams = [torch.cuda.Stream() for _ in range(4)]
 bn = model.get_bn(wav)
