@@ -336,12 +336,15 @@ __device__ __forceinline__ void fft8192_pass(float* re, float* im, const float2*
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
       const int d = 1 << st;                              // partner distance in group slots at stage s + st
-      const int tstep = (FFT_N / 2) >> (s - 1 + st);
+      // staged table (yaapt_stage_twiddles_kernel): stage s + st's 2^(s + st - 1) twiddles tw[p * tstep] are contiguous from
+      // entry 2^(s + st - 1) - 1 on, so consecutive lanes (consecutive pos) read consecutive entries instead of a gather at
+      // stride tstep (64 cache lines per wave instruction at the middle stages)
+      const float2* __restrict__ ts = tw + ((h << st) - 1);
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         if (j & d) continue;                              // j = the "a" element, j + d = the "c" element
         const int p = pos + (j & (d - 1)) * h;            // index of a inside its half-block of stage s + st
-        const float2 w = tw[p * tstep];
+        const float2 w = ts[p];
         const float tr = xr[j + d] * w.x - xi[j + d] * w.y;
         const float ti = xr[j + d] * w.y + xi[j + d] * w.x;
         const float ur = xr[j], ui = xi[j];
@@ -362,8 +365,8 @@ __device__ __forceinline__ void fft8192_pass(float* re, float* im, const float2*
 
 // stages first .. 13 of the 8192-point radix-2 DIT FFT (input in bit-reversed order).
 // (Round 3, measured and not kept: the twiddles of a radix-8 pass in registers, requested one pass ahead — nlfer 268 -> 418 us;
-// the last pass computing only the wanted output bins, 7 of 24 butterfly results and 1 of 8 LDS writes — 268 -> 309 us.
-// The compiler's interleaving of the table loads with the butterflies of the plain pass beats both.)
+// the last pass computing only the wanted output bins, 7 of 24 butterfly results and 1 of 8 LDS writes — 229 -> 238 us at
+// the same occupancy.  What did pay: the per-stage contiguous twiddle table below, 268 -> 229 and 304 -> 222 us.)
 __device__ void fft8192_from(float* re, float* im, const float2* __restrict__ tw, int first) {
   int s = first;
   const int lead = (FFT_LOG - first + 1) % 3;
@@ -388,6 +391,16 @@ __device__ __forceinline__ int fft8192_load_padded(float* re, float* im, int L, 
   }
   __syncthreads();
   return z + 1;
+}
+
+// staged twiddles: out[(h - 1) + p] = tw[p * (4096 / h)] for every stage half-size h = 1, 2, ... 4096 and p < h (8191 entries):
+// the same table values, laid out so that a stage's twiddles are contiguous
+__global__ void __launch_bounds__(256) yaapt_stage_twiddles_kernel(const float2* __restrict__ tw, float2* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;          // 0 .. 8190
+  if (i >= FFT_N - 1) return;
+  const int h = 1 << (31 - __clz(i + 1));                // largest power of two <= i + 1
+  const int p = i + 1 - h;
+  out[i] = tw[p * ((FFT_N / 2) / h)];
 }
 
 // nlfer: frame (560 samples) x hann -> FFT -> sum |X[nl_lo:nl_hi]|
@@ -1057,7 +1070,7 @@ using namespace sat;
 static size_t yaapt_ws_floats(const Plan& P, int B) {
   const size_t nf = P.nframes;
   return (size_t)B * (2 * (size_t)P.Lz + 3 * nf /*e_raw, energy, vuv*/ + 8 * nf /*cand*/ + nf /*spec*/ + 4 /*scal*/ +
-                      2 * nf /*fmean*/ + 4 * nf /*tp, tm*/ + (size_t)SPEC_MAGP * nf /*magnitude windows*/) + 64;
+                      2 * nf /*fmean*/ + 4 * nf /*tp, tm*/ + (size_t)SPEC_MAGP * nf /*magnitude windows*/) + 2 * FFT_N /*staged twiddles*/ + 8 + 64;
 }
 
 extern "C" size_t sat_yaapt_workspace_bytes(const sat_yaapt_plan* plan, int B) {
@@ -1102,6 +1115,8 @@ static int yaapt_run(const sat_yaapt_plan* plan, const float* wav, const int32_t
   float* tp = w;              w += (size_t)B * 2 * nf;
   float* tm = w;              w += (size_t)B * 2 * nf;
   float* magbuf = w;          w += (size_t)B * nf * SPEC_MAGP;
+  w += (4 - ((uintptr_t)w / 4) % 4) % 4;                     // 16-byte alignment of the float2 table
+  float2* stw = (float2*)w;   w += 2 * FFT_N;
   const float2* tw = (const float2*)twiddle;
   SAT_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
 
@@ -1120,11 +1135,13 @@ static int yaapt_run(const sat_yaapt_plan* plan, const float* wav, const int32_t
     SAT_HIP(hipFuncSetAttribute((const void*)yaapt_refine_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done_on_device(attr_done, dev);
   }
-  hipLaunchKernelGGL(yaapt_nlfer_kernel, dim3(P.nframes, B), dim3(FFT_THREADS), fft_lds, s, filt, hann, tw, e_raw, U, P);
+  hipLaunchKernelGGL(yaapt_stage_twiddles_kernel, dim3(FFT_N / 256), dim3(256), 0, s, tw, stw);
+  SAT_LAUNCH_CHECK("yaapt_stage_twiddles_kernel");
+  hipLaunchKernelGGL(yaapt_nlfer_kernel, dim3(P.nframes, B), dim3(FFT_THREADS), fft_lds, s, filt, hann, stw, e_raw, U, P);
   SAT_LAUNCH_CHECK("yaapt_nlfer_kernel");
   hipLaunchKernelGGL(yaapt_energy_norm_kernel, dim3(B), dim3(256), 0, s, e_raw, energy, vuv, U, P);
   SAT_LAUNCH_CHECK("yaapt_energy_norm_kernel");
-  hipLaunchKernelGGL(yaapt_spec_kernel, dim3(P.nframes, B), dim3(FFT_THREADS), fft_lds, s, filt, kaiser, tw, vuv, magbuf, U, P);
+  hipLaunchKernelGGL(yaapt_spec_kernel, dim3(P.nframes, B), dim3(FFT_THREADS), fft_lds, s, filt, kaiser, stw, vuv, magbuf, U, P);
   SAT_LAUNCH_CHECK("yaapt_spec_kernel");
   hipLaunchKernelGGL(yaapt_spec_peaks_kernel, dim3(P.nframes, B), dim3(256), 0, s, magbuf, vuv, cand, U, P);
   SAT_LAUNCH_CHECK("yaapt_spec_peaks_kernel");
