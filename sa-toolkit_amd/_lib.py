@@ -159,6 +159,12 @@ def lib():
             fn.argtypes = args
         if l.sat_abi_version() != 3:
             raise SatError("libsatools_hip.so ABI version mismatch")
+        # A/B switches of the conv dispatch for whole-program measurements (bench.py under different kernels):
+        # SATOOLS_AMD_CONV_OPTIONS="pair32w=0,lean_balance=2" -> sat_conv_set_option(name, value) at load time
+        for item in filter(None, os.environ.get("SATOOLS_AMD_CONV_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            if l.sat_conv_set_option(name.strip().encode(), int(value)) != 0:
+                raise SatError(f"SATOOLS_AMD_CONV_OPTIONS: {l.sat_last_error().decode('utf-8', 'replace')}")
         _lib = l
     return _lib
 
