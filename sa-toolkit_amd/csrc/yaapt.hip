@@ -381,13 +381,19 @@ __device__ void fft8192_from(float* re, float* im, const float2* __restrict__ tw
 template <typename Get>
 __device__ __forceinline__ int fft8192_load_padded(float* re, float* im, int L, Get get) {
   const int z = L <= 1024 ? 3 : (L <= 2048 ? 2 : (L <= 4096 ? 1 : 0));
-  const int rep = 1 << z;
   for (int i = threadIdx.x; i < FFT_N; i += FFT_THREADS) im[i] = 0.f;
-  const int nblk = FFT_N >> z;                             // sample j lands on block brev13(j) >> z
-  for (int j = threadIdx.x; j < nblk; j += FFT_THREADS) {
+  // Element (j, r) = re[brev13(j) + r], j < 8192 >> z, r < 2^z.  The LDS bank of brev13(j) is set by the TOP 6 - z bits of j
+  // (bits 7 .. 12 - z reversed), so a wave that walks 64 consecutive j writes all its lanes to ONE bank (64-way conflict on
+  // every store; with 8000 blocks per launch this fill was a third of the FFT kernels' time).  Here a lane is (r, q):
+  // r = the low z bits, q = the top 6 - z bits of j; the 7 low bits of j come from (wave, round) — 64 distinct banks per store.
+  static_assert(FFT_THREADS == 1024, "16 waves x 8 rounds = the 128 low-bit values of j");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & ((1 << z) - 1), q = lane >> z;
+#pragma unroll
+  for (int round = 0; round < 8; ++round) {
+    const int j = (q << 7) | (wave * 8 + round);
     const float v = j < L ? get(j) : 0.f;
-    const int b0 = brev13(j);
-    for (int r = 0; r < rep; ++r) re[b0 + r] = v;
+    re[brev13(j) + r] = v;
   }
   __syncthreads();
   return z + 1;
