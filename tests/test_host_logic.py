@@ -264,3 +264,21 @@ def test_bench_gpus_2_as_typed_spawns_its_ranks(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_conv_options_from_the_environment(monkeypatch):
+    """SATOOLS_AMD_CONV_OPTIONS="name=value,..." is applied through sat_conv_set_option when the library is loaded
+    (whole-program A/B runs, tools/ab_bench.sh); an unknown name fails loudly"""
+    from satools_amd import _lib
+    saved = _lib._lib
+    try:
+        _lib._lib = None
+        monkeypatch.setenv("SATOOLS_AMD_CONV_OPTIONS", "pair32w=0, lean_balance=2")
+        l = _lib.lib()
+        assert l.sat_conv_set_option(b"pair32w", 1) == 0 and l.sat_conv_set_option(b"lean_balance", 1) == 0      # back to the defaults
+        _lib._lib = None
+        monkeypatch.setenv("SATOOLS_AMD_CONV_OPTIONS", "no_such_switch=1")
+        with pytest.raises(_lib.SatError, match="no_such_switch"):
+            _lib.lib()
+    finally:
+        _lib._lib = saved
