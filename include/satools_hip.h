@@ -61,6 +61,10 @@ int sat_mrf_debug_stamps(int64_t* buf);
 int sat_attention_debug_stamps(int64_t* buf);
 /* the same for block 0 of the wave-specialised ResBlock step at C = 32 (csrc/pair32s.hip: pairw_kernel): [8 steps][6 stamps][8 waves] */
 int sat_pair32_debug_stamps(int64_t* buf);
+/* the same for the LDS-DMA ring conv (csrc/conv_ring16.hip): waves 0 and 4 of EVERY block record [prologue, K loop, waits at the
+ * step heads, epilogue, whole kernel] in shader cycles, the kernel's span and start in 100 MHz ticks, the step count:
+ * buf[block][2][8].  Returns 8 (entries per wave record). */
+int sat_convring_debug_stamps(int64_t* buf);
 
 /* ------------------------------------------------------------------------------------------
  * Fused 1-D convolution as an implicit GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32;
@@ -157,6 +161,16 @@ typedef struct {
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
                    void* stream);
+/* n = 1..3 convolutions d[0..n-1] (x[j], w_packed[j], y[j] as for sat_conv1d_f32) that do not depend on each other's
+ * results within the call — the three branches of a multi-receptive-field block (reference hifigan/archi.py:82-86: kernel
+ * sizes 3 / 7 / 11 on the same stage) — or that depend on them only through y[j] accumulated in index order (d[j].accum on the
+ * same y: job j + 1 adds to what job j stored).  Where all of them are split-plane k-tap convs of one shape that the LDS-DMA
+ * ring kernel serves (csrc/conv_ring16.hip: C_out > 64, C_in % 32 == 0, ksize >= 3, option "convring"), ONE launch walks the
+ * tiles of all jobs: a block finishes job 0, 1, 2 of its region in turn (in a per-block rotated order when no job reads what
+ * another writes), requesting the next tile's operands before the epilogue of the current one.  Otherwise: n calls of
+ * sat_conv1d_f32 in index order.  Results are those of the n single calls. */
+int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const* x, const void* const* w_packed, float* const* y, int n,
+                         void* stream);
 /* One fused ResBlock1 step of the thin generator stages (C = 16 or 32; C = 64 with split planes end to end: x_split in,
  * res_split == x_split), split-f16 arithmetic:
  *   y = conv2(lrelu(conv1(lrelu(x)) + bias1)) + d->bias + x      (hifigan/nn.py:179-186)

@@ -62,6 +62,7 @@ _PROTOS = {
     "sat_last_dispatch_name": (C.c_char_p, []),
     "sat_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "sat_conv1d_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sat_conv1d_multi_f32": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "sat_conv1d_packed_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sat_convtranspose_phase_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sat_hifigan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
@@ -78,6 +79,7 @@ _PROTOS = {
     "sat_mrf_debug_stamps": (C.c_int, [C.c_void_p]),
     "sat_attention_debug_stamps": (C.c_int, [C.c_void_p]),
     "sat_pair32_debug_stamps": (C.c_int, [C.c_void_p]),
+    "sat_convring_debug_stamps": (C.c_int, [C.c_void_p]),
     "sat_resblock_mrf_supported": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sat_resblock_mrf_scratch_bytes": (C.c_size_t, [C.c_int, C.POINTER(C.c_int)]),
     "sat_resblock_mrf_f16x3": (C.c_int, [C.POINTER(MrfDesc), C.c_void_p]),

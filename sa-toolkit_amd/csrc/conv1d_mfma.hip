@@ -1590,15 +1590,15 @@ extern "C" int sat_conv1d_packed_dims(int C_in, int C_out, int up, int groups, i
   return SAT_OK;
 }
 
-extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed,
-                              float* y, void* stream) {
+// descriptor -> launch arguments (every check of sat_conv1d_f32 but the choice of the kernel)
+static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y, ConvArgs& a) {
   SAT_REQUIRE(d && w_packed && (x || d->x_split) && (y || (d->no_y && d->y_split)), "conv1d: null pointer");
   SAT_REQUIRE(d->B > 0 && d->C_in > 0 && d->C_out > 0 && d->T_in > 0 && d->T_q > 0, "conv1d: empty shape");
   SAT_REQUIRE(d->ksize >= 1 && d->dilation >= 1 && d->stride >= 1 && d->up >= 1 && d->groups >= 1,
               "conv1d: bad ksize/dilation/stride/up/groups");
   SAT_REQUIRE(d->C_in % d->groups == 0 && d->C_out % d->groups == 0, "conv1d: groups must divide channels");
   SAT_REQUIRE(d->up == 1 || d->stride == 1, "conv1d: polyphase output requires stride 1");
-  ConvArgs a{};
+  a = ConvArgs{};
   a.x = x;
   a.w = (const float*)w_packed;
   a.y = y;
@@ -1645,7 +1645,6 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     const long long rlim = d->res ? ((long long)a.rows_g * a.r_cs + (long long)a.T_q * a.res_tstride + a.res_toff) * 4 : 0;
     a.fast_epi = d->up == 1 && ylim < (1LL << 31) && rlim < (1LL << 31) && ylim > 0;
   }
-  hipStream_t s = (hipStream_t)stream;
   SAT_REQUIRE(d->mode != SAT_CONV_F32 || (!d->x_split && !d->y_split && !d->no_y), "conv1d: split planes need a split-f16 mode");
   if (d->mode == SAT_CONV_F16X3 || d->mode == SAT_CONV_F16F8) {
     a.f8 = d->mode == SAT_CONV_F16F8;
@@ -1691,6 +1690,19 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
       SAT_REQUIRE(!(d->no_y && d->accum), "conv1d: no_y with accum");
     }
     a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;   // bytes per group
+    return SAT_OK;
+  }
+  SAT_REQUIRE(d->mode == SAT_CONV_F32, "conv1d: unknown mode %d", d->mode);
+  return SAT_OK;
+}
+
+extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed,
+                              float* y, void* stream) {
+  ConvArgs a;
+  int st = conv1d_prepare(d, x, w_packed, y, a);
+  if (st != SAT_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->mode == SAT_CONV_F16X3 || d->mode == SAT_CONV_F16F8) {
     // 1x1 on split planes with enough rows: the GEMM kernel (activation fragments straight from the planes)
     if (a.x16 && a.ksize == 1 && !a.f8 && !a.poly_planes && a.fast_epi && d->groups == 1 && a.rows_g >= 128 &&
         (a.cin_pad / CI_CHUNK) % 4 == 0 && g_k1_gemm) {
@@ -1711,13 +1723,14 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     if (a.x16 && a.ksize == 3 && !a.f8 && !a.poly_planes && a.rows_g > 32 && a.T_q > 128 &&
         (long long)ceil_div(a.rows_g, 64) * ceil_div(a.T_q, 256) * d->B * d->groups < 256)
       return launch_f16x3<2, 1, 3>(a, d->B, d->groups, s);
+    // the generator's resblock convs at C >= 128: the LDS-DMA ring on the 16x16x32 shape (conv_ring16.hip)
+    if (d->groups == 1 && convring_supports(a)) return launch_f16x3_convring(a, d->B, s);
     // the generator's resblock convs: the three-blocks-per-CU form of the tile (conv_lean.hip)
     if (d->groups == 1 && (a.ksize == 3 ? g_lean3 : a.ksize == 7 ? g_lean7 : g_lean11) && lean_supports(a))
       return launch_f16x3_lean(a, d->B, s);
     if (a.rows_g > 32) return launch_f16x3_ks<2, 2>(a, d->B, d->groups, s);   // 64 rows x 256 positions
     return launch_f16x3_ks<1, 4>(a, d->B, d->groups, s);                       // 32 rows x 512 positions
   }
-  SAT_REQUIRE(d->mode == SAT_CONV_F32, "conv1d: unknown mode %d", d->mode);
   // tile shape by output rows per group: wide-in-time tiles for thin layers
   if (a.rows_g > 64) {
     // few, long GEMM-like layers (TDNNF: 128 rows x ~530 frames per utterance, K = 3072) would
@@ -1728,6 +1741,35 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
   }
   if (a.rows_g > 32) return launch_ks<2, 2, 1, 4>(a, d->B, d->groups, s);   //  64 rows x 256 positions
   return launch_ks<1, 4, 1, 4>(a, d->B, d->groups, s);                       //  32 rows x 512 positions
+}
+
+extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const* x, const void* const* w_packed, float* const* y,
+                                    int n, void* stream) {
+  SAT_REQUIRE(d && x && w_packed && y && n >= 1 && n <= 3, "conv1d_multi: 1..3 convolutions");
+  ConvArgs a[3];
+  bool ring = true, writes_read = false;
+  for (int j = 0; j < n; ++j) {
+    int st = conv1d_prepare(&d[j], x[j], w_packed[j], y[j], a[j]);
+    if (st != SAT_OK) return st;
+    ring = ring && (d[j].mode == SAT_CONV_F16X3) && d[j].groups == 1 && d[j].B == d[0].B && convring_supports(a[j]) && convring_same_shape(a[j], a[0]);
+  }
+  // the order of the jobs may rotate from block to block unless a job reads (accumulates into, takes its residual or
+  // input from) what another one writes
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      if (i == j) continue;
+      const void* wr0 = a[i].no_y ? nullptr : (const void*)a[i].y;
+      const void* wr1 = a[i].y16;
+      const void* rd[5] = {a[j].accum ? (const void*)a[j].y : nullptr, a[j].res, a[j].res16, a[j].x16, a[j].x};
+      for (const void* r : rd) writes_read = writes_read || (r && (r == wr0 || r == wr1));
+      writes_read = writes_read || (wr0 && wr0 == (a[j].no_y ? nullptr : (const void*)a[j].y)) || (wr1 && wr1 == a[j].y16);
+    }
+  if (ring && n > 1) return launch_f16x3_convring_multi(a, n, !writes_read, d[0].B, (hipStream_t)stream);
+  for (int j = 0; j < n; ++j) {
+    int st = sat_conv1d_f32(&d[j], x[j], w_packed[j], y[j], stream);
+    if (st != SAT_OK) return st;
+  }
+  return SAT_OK;
 }
 
 
@@ -1826,6 +1868,7 @@ extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, in
 }
 
 extern "C" int sat_pair32_debug_stamps(int64_t* buf) { return pair32_debug_stamps((long long*)buf); }
+extern "C" int sat_convring_debug_stamps(int64_t* buf) { return convring_debug_stamps((long long*)buf); }
 
 extern "C" int sat_conv_set_option(const char* name, int value) {
   SAT_REQUIRE(name, "conv_set_option: null name");
@@ -1835,6 +1878,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "pair32s")) { g_pair32s = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32w")) { pair32w_set(value); return SAT_OK; }
   if (!strcmp(name, "pair64w")) { pair64w_set(value); return SAT_OK; }
+  if (!strcmp(name, "convring")) { convring_set(value); return SAT_OK; }
   if (!strcmp(name, "lean_balance")) { lean_set_balance(value); return SAT_OK; }
   if (!strcmp(name, "pair32s_waves")) { pair32s_set_waves(value); return SAT_OK; }
   if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }

@@ -394,47 +394,68 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 // The order of operations is conv_epilogue's.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int MT, int NT>
-__device__ __forceinline__ void epilogue16_prefetch_res(const ConvArgs& p, f32x4 (&rpre)[MT][NT], int b, int co_w, int q_w,
-                                                        int li, int lg) {
+// acc += a x b on v_mfma_f32_16x16x32_f16 with the accumulator PINNED: destination = the C operand's registers.  Through
+// the builtin, hipcc (ROCm 7.2) let the accumulators of the two-steps-per-trip ring loops alternate between two register
+// sets — `v_mfma d, a, b, c` with d != c for 302 of the 480 MFMAs of gemm_f16x3_ring16_kernel: a dependent chain that
+// does not accumulate in place loses its back-to-back issue, and a second copy of every accumulator stays live.
+// The compiler does not see an MFMA in this statement: it still orders it behind the loads of its operands (register
+// dependences of inline asm are tracked), but it inserts no wait states for the matrix pipe's result latency — the
+// kernel calls mfma16_drain() between its last MFMA and the first vector instruction that reads an accumulator.
+__device__ __forceinline__ void mfma16_acc(f32x4& acc, const h8& a, const h8& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#endif
+}
+__device__ __forceinline__ void mfma16_drain() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+
+// residual words of ONE 16-row strip of the wave tile (rows co_r .. co_r + 15): raw plane words (res16) or f32 values
+template <int NT>
+__device__ __forceinline__ void epilogue16_load_res_row(const ConvArgs& p, f32x4 (&out)[NT], int b, int co_r, int q_w, int li, int lg) {
   const unsigned OOB = 0x80000000u;
   if (p.res16) {
     const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)p.res16 + (long long)b * p.rows_g * p.T_q * 4), 0, (unsigned)(p.rows_g * p.T_q * 4), 0x00020000);
+    const int chunk = co_r >> 4;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int chunk = (co_w >> 4) + m;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int q = q_w + n * 16 + li;
-        const unsigned off = (q < p.T_q && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (lg >> 1)) * p.T_q + q) * 16 + 8 * (lg & 1)) : OOB;
-        // narrowed to 8 bytes each (the b64 load builtin of this hipcc loads one dword)
-        const uint4 hv = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 0, 0));
-        const uint4 lv = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * p.T_q * 16, 0));
-        rpre[m][n] = f32x4{__builtin_bit_cast(float, hv.x), __builtin_bit_cast(float, hv.y),
-                           __builtin_bit_cast(float, lv.x), __builtin_bit_cast(float, lv.y)};
-      }
+    for (int n = 0; n < NT; ++n) {
+      const int q = q_w + n * 16 + li;
+      const unsigned off = (q < p.T_q && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (lg >> 1)) * p.T_q + q) * 16 + 8 * (lg & 1)) : OOB;
+      // exactly the 8 bytes of this lane's four channels, as two dwords (the b64 load builtin of this hipcc loads one dword, and
+      // a 16-byte load at an 8-byte offset would reach past the last unit of the plane image)
+      const unsigned h0 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 0, 0), h1 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 4, 0);
+      const unsigned l0 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 2 * p.T_q * 16, 0), l1 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 2 * p.T_q * 16 + 4, 0);
+      out[n] = f32x4{__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1), __builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1)};
     }
     return;
   }
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.res ? p.res + (long long)b * p.r_bs : p.y), 0, p.res ? (unsigned)(p.rows_g * p.r_cs * 4) : 0u, 0x00020000);
   const int r_rb = (int)p.r_cs * 4;
+  const int row0 = co_r + 4 * lg;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int row0 = co_w + m * 16 + 4 * lg;
+  for (int n = 0; n < NT; ++n) {
+    const int q = q_w + n * 16 + li;
+    const unsigned roff = q < p.T_q ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : OOB;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int q = q_w + n * 16 + li;
-      const unsigned roff = q < p.T_q ? (unsigned)(row0 * r_rb + (q * p.res_tstride + p.res_toff) * 4) : OOB;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        rpre[m][n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, roff + r * r_rb, 0, 0));
-    }
+    for (int r = 0; r < 4; ++r) out[n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, roff + r * r_rb, 0, 0));
   }
 }
 
 template <int MT, int NT>
+__device__ __forceinline__ void epilogue16_prefetch_res(const ConvArgs& p, f32x4 (&rpre)[MT][NT], int b, int co_w, int q_w,
+                                                        int li, int lg) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m) epilogue16_load_res_row<NT>(p, rpre[m], b, co_w + 16 * m, q_w, li, lg);
+}
+
+// HAS_BN = false compiles the folded-BatchNorm step out (32 registers of scale / shift): for kernels that are only dispatched without ch_scale
+// ROWRES: the residual is requested strip by strip inside (the strip after the one being finished: 2 x NT registers
+// instead of MT x NT); `rpre` is not read
+template <int MT, int NT, bool HAS_BN = true, bool ROWRES = false>
 __device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[MT][NT], f32x4 (&rpre)[MT][NT], int b, int co_w,
                                                 int q_w, int li, int lg) {
   const unsigned OOB = 0x80000000u;
@@ -449,39 +470,73 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[
       p.y16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
   const int y_rb = (int)p.y_cs * 4;
   const bool has_res = p.res != nullptr || p.res16 != nullptr;
+  // Every load of the epilogue is requested BEFORE the first store: vmcnt retires in issue order, so a load behind a row's
+  // stores returns only once those stores have been acknowledged — with the per-row channel constants loaded row by row
+  // (the first form of this epilogue) each row paid a full store round trip (stamps of conv1d_f16x3_ring16_kernel: 15-17 k
+  // cycles for 80 outputs per lane).  Channel constants of all MT rows up front; the MRF accumulator of row m + 1 before
+  // the stores of row m.
+  float bi[MT][4], sc[MT][4], sh[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int row0 = co_w + m * 16 + 4 * lg;
-    float bi[4], sc[4], sh[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (row0 + r) * 4, 0, 0));
-    if (p.ch_scale) {
+    for (int r = 0; r < 4; ++r) bi[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (row0 + r) * 4, 0, 0));
+  }
+  if (HAS_BN && p.ch_scale) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row0 = co_w + m * 16 + 4 * lg;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scs, (row0 + r) * 4, 0, 0));
-        sh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shs, (row0 + r) * 4, 0, 0));
+        sc[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scs, (row0 + r) * 4, 0, 0));
+        sh[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shs, (row0 + r) * 4, 0, 0));
       }
     }
+  }
+  f32x4 yn[NT];
+  auto load_accum = [&](int m) __attribute__((always_inline)) {
+    const int row0 = co_w + m * 16 + 4 * lg;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int q = q_w + n * 16 + li;
+      const unsigned yoff = q < p.T_q ? (unsigned)(row0 * y_rb + q * 4) : OOB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yn[n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yoff + r * y_rb, 0, 0));
+    }
+  };
+  f32x4 rn[NT];
+  if (ROWRES && has_res) epilogue16_load_res_row<NT>(p, rn, b, co_w, q_w, li, lg);
+  if (p.accum) load_accum(0);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row0 = co_w + m * 16 + 4 * lg;
     const bool rows_ok = co_w + m * 16 < p.rows_g;       // wave-uniform: padding rows of the block's tile
+    f32x4 yv[NT], rr[NT];
+    if (ROWRES && has_res) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) rr[n] = rn[n];
+      if (m + 1 < MT) epilogue16_load_res_row<NT>(p, rn, b, co_w + 16 * (m + 1), q_w, li, lg);
+    }
+    if (p.accum) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) yv[n] = yn[n];
+      if (m + 1 < MT) load_accum(m + 1);
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int q = q_w + n * 16 + li;
       const bool qok = q < p.T_q;
       const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
-      float rv[4], yv[4], v[4];
+      float rv[4], v[4];
+      const f32x4 rw = ROWRES ? rr[n] : rpre[m][n];
       if (p.res16) {
-        decode_res16(rpre[m][n][0], rpre[m][n][1], rpre[m][n][2], rpre[m][n][3], p.res16_inv, rv);
+        decode_res16(rw[0], rw[1], rw[2], rw[3], p.res16_inv, rv);
       } else if (p.res) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rv[r] = rpre[m][n][r];
-      }
-      if (p.accum) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yoff + r * y_rb, 0, 0));
+        for (int r = 0; r < 4; ++r) rv[r] = rw[r];
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[m][n][r], p.w_descale, bi[r]);
+      for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[m][n][r], p.w_descale, bi[m][r]);
       if (has_res && !p.res_after) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += p.res_scale * rv[r];
@@ -490,9 +545,9 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
       }
-      if (p.ch_scale) {
+      if (HAS_BN && p.ch_scale) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[m][r] + sh[m][r];
       }
       if (p.relu && !p.relu_first) {
 #pragma unroll
@@ -508,7 +563,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[
       }
       if (p.accum) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = yv[r] + v[r];
+        for (int r = 0; r < 4; ++r) v[r] = yv[n][r] + v[r];
       }
       if (p.accum_div != 0.f) {
 #pragma unroll
@@ -561,6 +616,13 @@ int pair32_debug_stamps(long long* buf);
 int launch_f16x3_lean(const ConvArgs& a, int B, hipStream_t s);
 bool lean_supports(const ConvArgs& a);
 int launch_f16x3_ring16(const ConvArgs& a, int B, hipStream_t s);   // the same ring on v_mfma_f32_16x16x32_f16
+// k-tap convs at C >= 128 as an LDS-DMA ring on the 16x16x32 shape, 256 x 160 / 128 x 320 tiles (conv_ring16.hip)
+int launch_f16x3_convring(const ConvArgs& a, int B, hipStream_t s);
+int launch_f16x3_convring_multi(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s);   // up to three convs of one shape in one launch
+bool convring_same_shape(const ConvArgs& a, const ConvArgs& b);
+bool convring_supports(const ConvArgs& a);
+void convring_set(int v);
+int convring_debug_stamps(long long* buf);
 bool ring16_supports(const ConvArgs& a);
 
 

@@ -1,0 +1,550 @@
+// k-tap convolution on split planes as an LDS-DMA ring on v_mfma_f32_16x16x32_f16 (the generator's resblock convs at
+// C >= 128: reference satools/satools/hifigan/nn.py:96-175, archi.py:82-86).
+#include "conv_common.h"
+
+#include <type_traits>
+
+namespace sat {
+
+// ------------------------------------------------------------------------------------------------
+// What the register-staged conv tile (conv_lean.hip: 64 rows x 256 positions, three 4-wave blocks per CU) loses, by
+// its own diagnostic builds: 13 % to the registers -> ds_write publish of both operands, 14 % to 640 tiles
+// on 768 slots at C = 256 / T = 1250 / 32 utterances, and its LDS is as busy as its matrix pipe.  This form:
+//   * BOTH operands travel global -> LDS by LDS-DMA (inline asm, counted vmcnt; no staging registers, no ds_write);
+//   * one 8-wave block per CU over a tile of (64 WR) rows x (80 WC) positions, WR x WC = 8: 256 x 160 for C >= 256
+//     (1250 positions x 32 utterances = 256 tiles = ONE per CU, nothing ragged), 128 x 320 for C = 128; the wave tile
+//     is 64 x 80 = 4 x 5 accumulators of 16 x 16, so the weights of a step are fetched once per 160 / 320 positions
+//     instead of once per 256 and an activation tile once per 256 / 128 rows instead of once per 64;
+//   * the 16x16x32 MFMA shape (holds a ~20 % higher clock than 32x32x16 at the same cycles per FLOP, gemm_ring.hip):
+//     K = 32 of one instruction = the same tap of TWO consecutive 16-channel chunks, lane (li, lg) reads the 16-byte
+//     unit (chunk lg >> 1, half lg & 1, row / column li) of each operand.
+// One step = (chunk pair, tap): 60 MFMAs per wave behind ONE raw s_barrier.
+//   W ring, three slots:  [chunk of the pair][hi0 hi1 lo0 lo1][64 WR rows] x 16 B — the packed weights as they lie in
+//                         memory; step s + 3 is requested into the slot of step s right behind barrier s (the A fragments
+//                         of step s are in registers by then: they were read during step s - 1)
+//   X tiles, two slots:   [chunk of the pair][4 planes][XW columns] x 16 B — the planes as they lie in memory, with the
+//                         halo of the dilated taps; pair p + 1 is requested behind the barrier of step (p, tap 0)
+// Fragments flow: the B pair of column n + 1 is read while column n is multiplied (two pairs live), the A pairs of the
+// next step during columns 1..4 (two A sets, alternating by step parity: the loop is instantiated per parity).
+// The SIMD partners (waves k and k + 4) issue their DMA pieces at different points of a step (gemm_ring.hip).
+// Per accumulator: pairs of chunks ascending, taps ascending, lo*hi, hi*lo, hi*hi — K = 32 inside one instruction
+// associates differently from the 32x32x16 tile: agreement to f32 rounding of the accumulation, not bit for bit.
+// ------------------------------------------------------------------------------------------------
+
+#define SAT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define SAT_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
+
+// lanes 0-31 only (the last, half-filled piece of an X row)
+__device__ __forceinline__ void lds_dma16_lo32(const uint4* lds_dst, const i32x4 rs, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+  unsigned keep;
+  unsigned long long ex;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xffffffff\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %3, %4, %5 offen lds\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(ex)
+      : "s"(la), "v"(voff), "s"(rs), "s"(soff)
+      : "memory");
+#endif
+}
+
+// diagnostic instantiation (STAMP): waves 0 and 4 of every block record cycle counters (sat_convring_debug_stamps)
+constexpr int CR_STAMPS = 8;
+__device__ __forceinline__ long long cr_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return (long long)t;
+}
+__device__ __forceinline__ long long cr_realtime() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return (long long)t;
+}
+
+// up to three convolutions of one shape (the three branches of an MRF block: archi.py:82-86) served by one launch.
+// What a tile needs of its conv, compact (the K loop and the epilogue copy it into scalar registers once per tile: read field
+// by field from a ConvArgs table in the kernel-argument segment, every use was a scalar load with its own round trip)
+struct RingJob {
+  const void* x16;       // input planes
+  const void* w;         // packed split-f16 weights
+  const float* bias;
+  float* y;              // f32 output (and MRF accumulator), or null
+  void* y16;             // output planes of lrelu(y, y16_slope), or null
+  const void* res16;     // residual as planes of lrelu(r, 1 / res16_inv), or null
+  float w_descale, y16_slope, res16_inv, accum_div;
+  int ksize, dil, pad_left, accum;
+  unsigned w_bytes;
+  int pad_;
+};
+struct RingArgs {
+  RingJob job[3];
+  long long y_bs, y_cs;   // f32 output strides (elements)
+  int cin_g, cin_pad, rows_g, co_pad, T_in, T_q;
+  int njobs;        // 1..3
+  int rotate;       // the order of the jobs rotates with the region (no job reads what another one writes)
+  int n_rt, n_ct;   // row tiles, column tiles per utterance
+  int total;        // column tiles x utterances
+  int n_vb;         // regions, numbered like the blocks of gemm_ring.hip: 8 * n_rt * ceil(total / 8), some of them empty
+  int diag;         // diagnostic builds (results are wrong): 2 = no K loop, 4 = no epilogue; with stamps: 8 = no DMA issue, 16 = no fragment reads in the loop
+};
+
+// ---- epilogue of a wave tile (MT x NT accumulators of 16 x 16; D: row 4 lg + r, column li): bias, residual rebuilt from
+// planes, MRF accumulation, f32 and / or plane stores — the arithmetic of conv_epilogue16 for exactly these options, in its
+// order (same bits).  Every load is requested before the stores that would delay it (vmcnt retires in issue order): the
+// biases of all rows first, then per 16-row strip the residual words and the accumulator values of the NEXT strip.
+template <int MT, int NT>
+__device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& A, f32x4 (&acc)[MT][NT], int b, int co_w, int q_w, int li, int lg) {
+  const unsigned OOB = 0x80000000u;
+  const int rows_g = A.rows_g, T_q = A.T_q;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(e.y ? e.y + (long long)b * A.y_bs : (float*)e.y16), 0, e.y ? (unsigned)(rows_g * A.y_cs * 4) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)e.bias, 0, (unsigned)(rows_g * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(e.y16 ? (char*)e.y16 + (long long)b * rows_g * T_q * 4 : (char*)e.y), 0, e.y16 ? (unsigned)(rows_g * T_q * 4) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(e.res16 ? (const char*)e.res16 + (long long)b * rows_g * T_q * 4 : (const char*)e.bias), 0,
+      e.res16 ? (unsigned)(rows_g * T_q * 4) : 0u, 0x00020000);
+  const int y_rb = (int)A.y_cs * 4;
+  const bool has_y = e.y != nullptr, has_y16 = e.y16 != nullptr, has_res = e.res16 != nullptr, accum = e.accum != 0;
+  const float descale = e.w_descale, slope = e.y16_slope, inv = e.res16_inv, div = e.accum_div;
+  float bi[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row0 = co_w + m * 16 + 4 * lg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bi[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (row0 + r) * 4, 0, 0));
+  }
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 rn[NT];
+  f32x4 yn[NT];
+  auto load_strip = [&](int m) __attribute__((always_inline)) {
+    const int chunk = (co_w >> 4) + m, row0 = co_w + m * 16 + 4 * lg;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int q = q_w + n * 16 + li;
+      if (has_res) {
+        // one WHOLE 16-byte unit per lane: lanes of even lg the hi unit of (chunk, half lg >> 1), their partners lg ^ 1 the lo
+        // unit; the halves are exchanged when the strip is consumed (v_permlane16_swap)
+        const unsigned off = (q < T_q && chunk * 16 < rows_g) ? (unsigned)(((chunk * 4 + (lg >> 1) + 2 * (lg & 1)) * T_q + q) * 16) : OOB;
+        // (kept as an UNSIGNED vector until the words are used: hipcc of ROCm 7.2 narrows `bit_cast<float x 4>(raw_buffer_load_b128)` to a one-dword load
+        // whose value fills all four elements — tools/scratch/b128_bitcast_repro.hip)
+        rn[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 0, 0));
+      }
+      if (accum) {
+        const unsigned yoff = q < T_q ? (unsigned)(row0 * y_rb + q * 4) : OOB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yn[n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yoff + r * y_rb, 0, 0));
+      }
+    }
+  };
+  if (has_res || accum) load_strip(0);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row0 = co_w + m * 16 + 4 * lg, chunk = (co_w >> 4) + m;
+    const bool rows_ok = co_w + m * 16 < rows_g;       // wave-uniform: padding rows of the block's tile
+    u32x4 rr[NT];
+    f32x4 yv[NT];
+    if (has_res || accum) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) rr[n] = rn[n], yv[n] = yn[n];
+      if (m + 1 < MT) load_strip(m + 1);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int q = q_w + n * 16 + li;
+      const bool qok = q < T_q;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[m][n][r], descale, bi[m][r]);
+      if (has_res) {
+        float rv[4];
+        // (hi01, hi23) of this lane's four channels = words 0, 1 of the hi unit (even lg) or 2, 3 (odd lg), the lo words likewise
+        // of the lo unit, which the partner lane holds: swap(u0, u2), swap(u1, u3) hand every lane its (hi, lo) pair
+        const auto s0 = __builtin_amdgcn_permlane16_swap(rr[n][0], rr[n][2], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(rr[n][1], rr[n][3], false, false);
+        // (each pair read as ONE vector of four halves: bit_cast<half2> of the elements of a 2 x u32 vector is miscompiled by
+        // this hipcc — element 0 used for both, tools/hipcc_bitcast_repro.hip)
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 c01 = __builtin_bit_cast(h4, s0), c23 = __builtin_bit_cast(h4, s1);      // (hi, hi, lo, lo) of channels 0, 1 / 2, 3
+        rv[0] = (float)c01[0] + (float)c01[2];
+        rv[1] = (float)c01[1] + (float)c01[3];
+        rv[2] = (float)c23[0] + (float)c23[2];
+        rv[3] = (float)c23[1] + (float)c23[3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rv[r] > 0.f ? rv[r] : rv[r] * inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+      }
+      if (accum) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = yv[n][r] + v[r];
+      }
+      if (div != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] / div;
+      }
+      if (has_y) {
+        const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs, yoff + r * y_rb, 0, 0);
+      }
+      if (has_y16 && rows_ok) {
+        float u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = v[r] > 0.f ? v[r] : v[r] * slope;
+        const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+        const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+        const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+        const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+        // a lane holds 8 bytes of the hi unit and 8 of the lo unit of (chunk, half lg >> 1), its partner lg ^ 1 the other 8 of
+        // each: after swap(hi, lo) per word the lanes of even lg hold the whole hi unit and their partners the whole lo unit —
+        // ONE 16-byte store per lane instead of two 8-byte ones (the epilogue is bound by the issue of its stores)
+        const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, l01), false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, l23), false, false);
+        const u32x4 unit = {s0[0], s1[0], s0[1], s1[1]};
+        const unsigned off = qok ? (unsigned)(((chunk * 4 + (lg >> 1) + 2 * (lg & 1)) * T_q + q) * 16) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(unit, y16rs, off, 0, 0);
+      }
+    }
+  }
+}
+
+// A block walks the tiles (region, job) of its regions vb = blockIdx.x, + gridDim.x, ...: the next tile's first X tile and
+// W slots are requested BEFORE the epilogue of the current one (the rings are free behind the barrier that ends a K
+// loop), and with `rotate` neighbouring blocks take the jobs in different orders, so that their epilogues — 164 KB of
+// output per tile — do not reach HBM as one burst of every CU at once (measured on the one-tile-per-launch form: the
+// epilogue of 256 blocks finishing together ran at the HBM write rate, 7.5 us for 42 MB).
+template <int WR, bool STAMP = false>
+__global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingArgs A, long long* dbg) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  constexpr int WC = 8 / WR, MT = 4, NT = 5, ROWS = 64 * WR, COLS = 80 * WC;
+  constexpr int XW = WR == 4 ? 224 : 384;               // columns of an X tile (>= COLS + (ksize - 1) * dilation)
+  constexpr int XP = (XW + 63) / 64;                     // DMA pieces per X row; the last one half-filled when XW % 64 == 32
+  constexpr bool XHALF = XW % 64 != 0;
+  constexpr int X_UNITS = 8 * XW, W_UNITS = 8 * ROWS, W0 = 2 * X_UNITS;     // 16-byte units
+  constexpr int PW = WR, PX = XP;                        // pieces per wave: of a W slot, of an X tile
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2, idx = wave & 3;
+  const int wr = WR == 4 ? idx : (idx & 1), wc = WR == 4 ? half : ((idx >> 1) + 2 * half);
+  const int njobs = A.njobs;
+  const int nreg = (A.n_vb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // regions of this block
+  const int ntiles = nreg * njobs;
+  long long st_t0 = 0, st_r0 = 0, st_wait = 0, st_pro = 0, st_loop = 0, st_epi = 0;
+  if constexpr (STAMP) st_t0 = cr_clock(), st_r0 = cr_realtime();
+
+  // tile k of this block -> job and coordinates; regions like the blocks of gemm_ring.hip (the row tiles of one
+  // (utterance, column tile) share an XCD); an empty region (past the last column tile) has b < 0
+  struct Tile { int j, b, co_b, q_b; };
+  auto locate = [&](int k) __attribute__((always_inline)) {
+    Tile t;
+    const int i = __builtin_amdgcn_readfirstlane(k / njobs), jj = k - i * njobs;
+    const int vb = (int)blockIdx.x + i * (int)gridDim.x;
+    const int xcd = vb & 7, rest = vb >> 3;
+    const int rt = __builtin_amdgcn_readfirstlane(rest % A.n_rt);
+    const int g = __builtin_amdgcn_readfirstlane((rest / A.n_rt) * 8 + xcd);
+    t.j = A.rotate ? __builtin_amdgcn_readfirstlane((jj + vb) % njobs) : jj;
+    t.b = g < A.total ? __builtin_amdgcn_readfirstlane(g / A.n_ct) : -1;
+    t.co_b = rt * ROWS;
+    t.q_b = (g - t.b * A.n_ct) * COLS;
+    return t;
+  };
+
+  // ---- DMA state of the tile whose operands are being requested
+  i32x4 xrs, wrs;
+  int KS = 1, dil = 1, NP = 1, NS = 1, seg_bytes = 0, x_chunk_bytes = 0;
+  int d_co = 0, d_q0 = 0, d_copad = 0, d_tin = 0;      // row / first input position of the tile, padded rows, input length
+  // this wave's DMA pieces: of every W slot the (chunk of the pair = wave >> 2, segment = wave & 3) row, of every X tile the
+  // (chunk of the pair, plane = wave & 3) row
+  const int my_w_unit = half * 4 * ROWS + idx * ROWS, my_x_unit = half * 4 * XW + idx * XW;
+  auto setup = [&](const Tile& t) __attribute__((always_inline)) {
+    const RingJob p = A.job[t.j];
+    KS = p.ksize, dil = p.dil;
+    NP = A.cin_pad / (2 * CI_CHUNK), NS = NP * KS;
+    seg_bytes = A.co_pad * 16;
+    x_chunk_bytes = 4 * A.T_in * 16;
+    xrs = dma_rsrc((const char*)p.x16 + (long long)t.b * A.cin_g * A.T_in * 4, (unsigned)(A.cin_g * A.T_in * 4));
+    wrs = dma_rsrc(p.w, p.w_bytes);
+    d_co = t.co_b, d_q0 = t.q_b - p.pad_left, d_copad = A.co_pad, d_tin = A.T_in;
+  };
+  // per-lane byte offsets of a piece, computed where it is issued (a handful of vector instructions per piece; kept in
+  // registers across the K loop they were what the allocator spilled INTO the loop)
+  auto voff_w = [&](int j) __attribute__((always_inline)) {
+    const int row = d_co + j * 64 + lane;
+    return row < d_copad ? (unsigned)(row * 16 + idx * seg_bytes) : 0x80000000u;
+  };
+  auto voff_x = [&](int k) __attribute__((always_inline)) {
+    const int xi = d_q0 + k * 64 + lane;
+    return (xi >= 0 && xi < d_tin) ? (unsigned)((idx * d_tin + xi) * 16) : 0x80000000u;
+  };
+  auto issue_w = [&](int pp, int t, int slot) __attribute__((always_inline)) {
+    const uint4* dst = lds4 + W0 + slot * W_UNITS + my_w_unit;
+    const unsigned soff = (unsigned)((((2 * pp + half) * KS + t) * 4) * seg_bytes);
+#pragma unroll
+    for (int j = 0; j < PW; ++j) lds_dma16(dst + j * 64, wrs, voff_w(j), soff);
+  };
+  auto issue_x = [&](int pp) __attribute__((always_inline)) {
+    const uint4* dst = lds4 + (pp & 1) * X_UNITS + my_x_unit;
+    const unsigned soff = (unsigned)((2 * pp + half) * x_chunk_bytes);
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      if (XHALF && k == PX - 1) lds_dma16_lo32(dst + k * 64, xrs, voff_x(k), soff);
+      else lds_dma16(dst + k * 64, xrs, voff_x(k), soff);
+    }
+  };
+  // first requests of a tile: X tile of pairs 0 and 1, W of steps 0..2 (taps >= 3: at least three steps)
+  auto issue_prologue = [&]() __attribute__((always_inline)) {
+    issue_x(0);
+    issue_w(0, 0, 0);
+    if (NP > 1) issue_x(1);
+    issue_w(0, 1, 1);
+    issue_w(0, 2, 2);
+  };
+
+  // fragment addresses (units): lane (li, lg) reads chunk lg >> 1, half lg & 1; lo planes 2 segments further
+  const int a_lane = (lg >> 1) * 4 * ROWS + (lg & 1) * ROWS + wr * 64 + li;
+  const int b_lane = (lg >> 1) * 4 * XW + (lg & 1) * XW + wc * 80 + li;
+  h8 fa[2][MT][2], fb[2][2];
+  auto read_a = [&](h8 (&dst)[2], const uint4* wb, int m) __attribute__((always_inline)) {
+    dst[0] = __builtin_bit_cast(h8, wb[m * 16]);
+    dst[1] = __builtin_bit_cast(h8, wb[m * 16 + 2 * ROWS]);
+  };
+  auto read_b = [&](h8 (&dst)[2], const uint4* xb, int n) __attribute__((always_inline)) {
+    dst[0] = __builtin_bit_cast(h8, xb[n * 16]);
+    dst[1] = __builtin_bit_cast(h8, xb[n * 16 + 2 * XW]);
+  };
+  f32x4 acc[MT][NT];
+
+  int s = 0, pp = 0, t = 0, ws = 0;          // current step, its pair, tap, W slot
+  int p3 = 0, t3 = 0;                        // pair and tap of step s + 3
+  auto body = [&](auto cur, auto late_c, auto more_c) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(cur)::value;
+    constexpr bool LATE = decltype(late_c)::value, MORE = decltype(more_c)::value;
+    constexpr int N_HAND = LATE ? 2 : 0;     // the DMA issue stands in front of this column's MFMAs
+    if constexpr (MORE) {
+      long long w0 = 0;
+      if constexpr (STAMP) w0 = cr_clock();
+      // barrier s: W of step s + 1 landed (this wave's pieces: all but the youngest step's, and an X tile requested in
+      // between), this wave's reads of slot s are back; behind it everybody's are: slot s is free for step s + 3
+      if (s + 2 < NS) {
+        if (t == 1 && pp >= 1 && pp + 1 < NP) SAT_WAIT_VM_LGKM0(PW + PX);
+        else SAT_WAIT_VM_LGKM0(PW);
+      } else {
+        SAT_WAIT_VM_LGKM0(0);
+      }
+      asm volatile("s_barrier" ::: "memory");
+      if constexpr (STAMP) st_wait += cr_clock() - w0;
+    }
+    int t1 = t + 1, p1 = pp;
+    if (t1 == KS) t1 = 0, p1 = pp + 1;
+    const int ws1 = ws == 2 ? 0 : ws + 1;
+    const uint4* wnext = lds4 + W0 + ws1 * W_UNITS + a_lane;
+    const uint4* xcur = lds4 + (pp & 1) * X_UNITS + b_lane + t * dil;
+    const uint4* xnext = lds4 + (p1 & 1) * X_UNITS + b_lane + t1 * dil;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      __builtin_amdgcn_sched_barrier(0);
+      // (diagnostic instantiation only: diag 8 = no DMA issue in the loop, 16 = no fragment reads in the loop)
+      if (n == N_HAND && !(STAMP && (A.diag & 8))) {
+        if (t == 0 && pp >= 1 && pp + 1 < NP) issue_x(pp + 1);
+        if (s + 3 < NS) issue_w(p3, t3, ws);
+      }
+      if (!(STAMP && (A.diag & 16))) {
+        if (n + 1 < NT) read_b(fb[(n + 1 + CUR) & 1], xcur, n + 1);
+        else if constexpr (MORE) read_b(fb[(NT + CUR) & 1], xnext, 0);
+        if constexpr (MORE) {
+          if (n >= 1) read_a(fa[CUR ^ 1][n - 1], wnext, n - 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        mfma16_acc(acc[m][n], fa[CUR][m][1], fb[(n + CUR) & 1][0]);
+        mfma16_acc(acc[m][n], fa[CUR][m][0], fb[(n + CUR) & 1][1]);
+        mfma16_acc(acc[m][n], fa[CUR][m][0], fb[(n + CUR) & 1][0]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ++s, pp = p1, t = t1, ws = ws1;
+    if (++t3 == KS) t3 = 0, ++p3;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto loop = [&](auto late_c) __attribute__((always_inline)) {
+    using L = decltype(late_c);
+    while (s + 2 < NS) {
+      body(I0{}, L{}, std::true_type{});
+      body(I1{}, L{}, std::true_type{});
+    }
+    if (s + 1 < NS) {
+      body(I0{}, L{}, std::true_type{});
+      body(I1{}, L{}, std::false_type{});
+    } else {
+      body(I0{}, L{}, std::false_type{});
+    }
+  };
+
+  // ---- the walk
+  int k = 0;
+  Tile cur = locate(0);
+  while (k < ntiles && cur.b < 0) cur = locate(++k);
+  if (k >= ntiles) return;
+  setup(cur);
+  issue_prologue();
+  while (true) {
+    long long e0 = 0;
+    if constexpr (STAMP) e0 = cr_clock();
+    // pair 0 and step 0 landed (everything older than this tile's last three requests: the previous tile's stores too)
+    if (NP > 1) SAT_WAIT_VM(PX + 2 * PW);
+    else SAT_WAIT_VM(2 * PW);
+    asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < MT; ++m) read_a(fa[0][m], lds4 + W0 + a_lane, m);
+    read_b(fb[0], lds4 + b_lane, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_nop 3" ::: "memory");       // (vector write of the accumulators -> matrix read, were the loop to start at once)
+    s = 0, pp = 0, t = 0, ws = 0;
+    p3 = KS > 3 ? 0 : 1, t3 = KS > 3 ? 3 : 0;
+    if constexpr (STAMP) st_pro += cr_clock() - e0;
+    long long l0 = 0;
+    if constexpr (STAMP) l0 = cr_clock();
+    if (!(A.diag & 2)) {
+      if (wave >= 4) loop(std::true_type{});
+      else loop(std::false_type{});
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if constexpr (STAMP) st_loop += cr_clock() - l0;
+    // the tile whose results are in the accumulators; then the next tile's first requests: every wave has read its last
+    // fragments behind this barrier, the rings are free
+    const Tile done = cur;
+    int kn = k + 1;
+    Tile nxt = done;
+    while (kn < ntiles) {
+      nxt = locate(kn);
+      if (nxt.b >= 0) break;
+      ++kn;
+    }
+    const bool more = kn < ntiles;
+    if (more) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      setup(nxt);
+      issue_prologue();
+    }
+    long long p0 = 0;
+    if constexpr (STAMP) p0 = cr_clock();
+    mfma16_drain();
+    if (!(A.diag & 4)) {
+      const RingJob ej = A.job[done.j];
+      ring_epilogue<MT, NT>(ej, A, acc, done.b, done.co_b + wr * 64, done.q_b + wc * 80, li, lg);
+    }
+    if constexpr (STAMP) st_epi += cr_clock() - p0;
+    if (!more) break;
+    k = kn;
+    cur = nxt;
+  }
+  if constexpr (STAMP) {
+    if (dbg && (wave & 3) == 0 && lane == 0) {
+      long long* d = dbg + ((long long)blockIdx.x * 2 + half) * CR_STAMPS;
+      const long long t_end = cr_clock(), r_end = cr_realtime();
+      d[0] = st_pro;              // waits for the first operands of the tiles
+      d[1] = st_loop;             // K loops
+      d[2] = st_wait;             // of them: s_waitcnt + s_barrier at the step heads
+      d[3] = st_epi;              // epilogues (issue; the stores drain behind them)
+      d[4] = t_end - st_t0;
+      d[5] = r_end - st_r0;       // the same span in 100 MHz ticks
+      d[6] = st_r0;
+      d[7] = ntiles;
+    }
+  }
+}
+
+static int g_convring = 1;
+void convring_set(int v) { g_convring = v; }
+static long long* g_convring_dbg = nullptr;
+int convring_debug_stamps(long long* buf) {
+  g_convring_dbg = buf;
+  return CR_STAMPS;
+}
+
+// rows > 64 (the 64-row stage keeps the register-staged tile), taps >= 3, channel pairs, the halo inside the X tile
+bool convring_supports(const ConvArgs& a) {
+  if (!(g_convring & 1)) return false;
+  if (!(a.x16 && !a.f8 && !a.y16_f8 && !a.poly_planes && !a.k1_wrap && a.fast_epi && a.up == 1 && a.stride == 1)) return false;
+  if (!epilogue16_supports(a) || a.ksize < 3 || a.cin_g % 32 != 0 || a.rows_g <= 64) return false;
+  // what ring_epilogue carries: bias, residual from planes (scale 1, before the activation), accumulation, f32 / plane stores
+  if (a.ch_scale || a.relu || a.gelu || a.res || a.res_after || !a.bias || (a.res16 && a.res_scale != 1.f) || (a.accum && a.no_y)) return false;
+  const int halo = (a.ksize - 1) * a.dil;
+  return a.rows_g > 128 ? halo <= 224 - 160 : halo <= 384 - 320;
+}
+
+// jobs of one shape (channels, lengths, batch): what one launch can walk
+bool convring_same_shape(const ConvArgs& a, const ConvArgs& b) {
+  return a.cin_g == b.cin_g && a.cin_pad == b.cin_pad && a.rows_g == b.rows_g && a.co_pad == b.co_pad && a.T_in == b.T_in && a.T_q == b.T_q &&
+         (a.no_y || b.no_y || (a.y_bs == b.y_bs && a.y_cs == b.y_cs));
+}
+
+static int cu_count() {
+  static std::atomic<int> n{0};
+  int v = n.load(std::memory_order_relaxed);
+  if (!v) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) v = pr.multiProcessorCount;
+    if (v <= 0) v = 256;
+    n.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+template <int WR>
+static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s) {
+  constexpr int WC = 8 / WR, ROWS = 64 * WR, COLS = 80 * WC, XW = WR == 4 ? 224 : 384;
+  RingArgs A{};
+  for (int j = 0; j < njobs; ++j) {
+    RingJob& r = A.job[j];
+    r.x16 = a[j].x16, r.w = a[j].w, r.bias = a[j].bias;
+    r.y = a[j].no_y ? nullptr : a[j].y;
+    r.y16 = a[j].y16, r.res16 = a[j].res16;
+    r.w_descale = a[j].w_descale, r.y16_slope = a[j].y16_slope, r.res16_inv = a[j].res16_inv, r.accum_div = a[j].accum_div;
+    r.ksize = a[j].ksize, r.dil = a[j].dil, r.pad_left = a[j].pad_left, r.accum = a[j].accum;
+    r.w_bytes = (unsigned)a[j].w_gs;
+  }
+  A.y_bs = a[0].y_bs, A.y_cs = a[0].y_cs;
+  A.cin_g = a[0].cin_g, A.cin_pad = a[0].cin_pad, A.rows_g = a[0].rows_g, A.co_pad = a[0].co_pad, A.T_in = a[0].T_in, A.T_q = a[0].T_q;
+  A.njobs = njobs;
+  A.rotate = rotate && njobs > 1;
+  A.diag = g_convring & 30;
+  A.n_rt = ceil_div(a[0].rows_g, ROWS);
+  A.n_ct = ceil_div(a[0].T_q, COLS);
+  A.total = A.n_ct * B;
+  A.n_vb = 8 * A.n_rt * ceil_div(A.total, 8);
+  const size_t lds_bytes = ((size_t)2 * 8 * XW + (size_t)3 * 8 * ROWS) * 16;
+  // one block per CU (the LDS of a block is most of a CU's): a block walks regions blockIdx.x, + gridDim.x, ...
+  const int grid = std::min(A.n_vb, std::max(8, cu_count() / 8 * 8));
+  auto kern = conv1d_f16x3_ring16_kernel<WR, false>;
+  auto kern_st = conv1d_f16x3_ring16_kernel<WR, true>;
+  static std::atomic<uint64_t> attr_done{0};      // per device
+  int dev;
+  if (attr_needed_on_current_device(attr_done, &dev)) {
+    SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    SAT_HIP(hipFuncSetAttribute((const void*)kern_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done_on_device(attr_done, dev);
+  }
+  if (g_convring_dbg) hipLaunchKernelGGL(kern_st, dim3(grid), dim3(512), lds_bytes, s, A, g_convring_dbg);
+  else hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, s, A, (long long*)nullptr);
+  SAT_LAUNCH_CHECK("conv1d_f16x3_ring16_kernel");
+  return SAT_OK;
+}
+
+int launch_f16x3_convring_multi(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s) {
+  return a[0].rows_g > 128 ? launch_convring<4>(a, njobs, rotate, B, s) : launch_convring<2>(a, njobs, rotate, B, s);
+}
+
+int launch_f16x3_convring(const ConvArgs& a, int B, hipStream_t s) { return launch_f16x3_convring_multi(&a, 1, 0, B, s); }
+
+}  // namespace sat

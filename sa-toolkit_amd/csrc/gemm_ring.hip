@@ -360,9 +360,9 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m][1], fb[CUR][n][0], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m][0], fb[CUR][n][1], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m][0], fb[CUR][n][0], acc[m][n], 0, 0, 0);
+        mfma16_acc(acc[m][n], fa[m][1], fb[CUR][n][0]);
+        mfma16_acc(acc[m][n], fa[m][0], fb[CUR][n][1]);
+        mfma16_acc(acc[m][n], fa[m][0], fb[CUR][n][0]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -396,6 +396,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
 
   // the residual of the whole wave tile is requested in one go (the fragment registers are dead by now): one memory
   // round trip in the exposed epilogue of a one-block-per-CU kernel
+  mfma16_drain();
   f32x4 rpre[MT][NT];
   if (p.res || p.res16) epilogue16_prefetch_res<MT, NT>(p, rpre, b, co_b + wm * 64, q_b + wn * 64, li, lg);
   conv_epilogue16<MT, NT>(p, acc, rpre, b, co_b + wm * 64, q_b + wn * 64, li, lg);

@@ -138,6 +138,7 @@ struct sat_hifigan {
   int mrf_exact = 0;         // fused MRF block: 0 = residuals of steps 2 / 3 rebuilt from the 22-bit planes like the launch-by-launch path (bit-identical
                              // to it, and measured 5 % faster: fewer live registers); 1 = kept in f32 registers
   int ups2 = 1;              // the thin upsamplers (C_in = 64, 32; k 4, stride 2) on the streaming kernel of ups2.hip
+  int multi_branch = 1;      // thick stages (C > 64): the i-th conv of all MRF branches as one sat_conv1d_multi_f32 call (one launch where the ring kernel serves them)
   int fuse_mrf = 1;          // a whole MRF block (all branches, all steps, the mean) as one launch where mrf.hip supports the stage (C = 16)
   int split_acts = 1;
   int planes_residual = 1;
@@ -268,6 +269,7 @@ extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int valu
   if (std::string(name) == "fuse_pairs") { h->fuse_pairs = value; return SAT_OK; }
   if (std::string(name) == "fuse_pair64") { h->fuse_pair64 = value; return SAT_OK; }
   if (std::string(name) == "fuse_mrf") { h->fuse_mrf = value; return SAT_OK; }
+  if (std::string(name) == "multi_branch") { h->multi_branch = value; return SAT_OK; }
   if (std::string(name) == "mrf_exact") { h->mrf_exact = value; return SAT_OK; }
   if (std::string(name) == "ups2") { h->ups2 = value; return SAT_OK; }
   if (std::string(name) == "split_acts") { h->split_acts = value; return SAT_OK; }
@@ -436,6 +438,82 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         C = Cn;
         Tc = Tn;
         continue;
+      }
+      // The thick stages (no fused ResBlock step: C > 64): the i-th conv of ALL branches in one launch
+      // (sat_conv1d_multi_f32: the LDS-DMA ring kernel walks the tiles of the three kernel sizes; the MRF sum is
+      // accumulated branch by branch inside a block, in the order of the loop below) — 6 launches per stage instead of 18.
+      {
+        const bool planes_res = cmode == SAT_CONV_F16X3 && h->planes_residual;
+        const bool fan = side && i < h->branch_streams;
+        if (h->multi_branch && planes_res && !fan && nk >= 2 && nk <= 3 && Cn > 64) {
+          const float* xnull[3] = {nullptr, nullptr, nullptr};
+          const void* rs[3] = {Hs, Hs, Hs};
+          for (int pair = 0; pair < 3; ++pair) {
+            sat_conv1d_desc d1[3], d2[3];
+            const void* w1[3];
+            const void* w2[3];
+            float* y1[3] = {nullptr, nullptr, nullptr};
+            float* y2[3];
+            void* dst_s[3];
+            for (int j = 0; j < nk; ++j) {
+              const int rk = h->rb_kernels[j], dil = h->rb_dil[j * 3 + pair];
+              const auto& cv1 = h->convs[h->id_rb(i, j, pair, 0)];
+              const auto& cv2 = h->convs[h->id_rb(i, j, pair, 1)];
+              void* T1s = br(j, 0);
+              void* RAs = br(j, 2);
+              void* RBs = br(j, 4);
+              d1[j] = base_desc(Cn, Cn, Tn, Tn, 1);
+              d1[j].ksize = rk;
+              d1[j].dilation = dil;
+              d1[j].pad_left = (rk * dil - dil) / 2;
+              d1[j].bias = cv1.bias;
+              d1[j].w_descale = cv1.descale;
+              d1[j].mode = cmode;
+              d1[j].x_split = rs[j];
+              d1[j].y_split = T1s;
+              d1[j].y_split_slope = 0.1f;
+              d1[j].no_y = 1;
+              w1[j] = cv1.w;
+              d2[j] = base_desc(Cn, Cn, Tn, Tn, 1);
+              d2[j].ksize = rk;
+              d2[j].dilation = 1;
+              d2[j].pad_left = (rk - 1) / 2;
+              d2[j].in_lrelu = 1;
+              d2[j].in_slope = 0.1f;
+              d2[j].bias = cv2.bias;
+              d2[j].w_descale = cv2.descale;
+              d2[j].mode = cmode;
+              d2[j].res_split = rs[j];
+              d2[j].res_split_slope = 0.1f;
+              d2[j].res_scale = 1.f;
+              d2[j].y_split_slope = 0.1f;
+              d2[j].x_split = T1s;
+              if (pair < 2) {
+                dst_s[j] = (rs[j] == RAs) ? RBs : RAs;
+                d2[j].no_y = 1;
+                y2[j] = nullptr;
+              } else {
+                y2[j] = ACCf;
+                d2[j].accum = j > 0;
+                d2[j].accum_div = (j == nk - 1) ? (float)nk : 0.f;
+                dst_s[j] = (j == nk - 1 && !last_stage) ? XSn : nullptr;
+              }
+              d2[j].y_split = dst_s[j];
+              w2[j] = cv2.w;
+            }
+            int s = sat_conv1d_multi_f32(d1, xnull, w1, y1, nk, stream);
+            if (s != SAT_OK) return s;
+            s = sat_conv1d_multi_f32(d2, xnull, w2, y2, nk, stream);
+            if (s != SAT_OK) return s;
+            for (int j = 0; j < nk; ++j) rs[j] = dst_s[j];
+          }
+          void* t = XS;
+          XS = XSn;
+          XSn = t;
+          C = Cn;
+          Tc = Tn;
+          continue;
+        }
       }
       if (side && i < h->branch_streams) {
         SAT_HIP(hipEventRecord(side->fork, (hipStream_t)stream));

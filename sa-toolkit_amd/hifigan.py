@@ -34,6 +34,10 @@ class CoreHifiGan(CoreHifiGanParams):
     #: (C = 16); same bits as the launch-by-launch path
     fuse_mrf = int(os.environ.get("SATOOLS_AMD_GEN_FUSE_MRF", "1"))
 
+    #: thick stages (C > 64): the i-th conv of all three MRF branches as ONE sat_conv1d_multi_f32 call (one launch of the
+    #: LDS-DMA ring kernel, csrc/conv_ring16.hip, where it serves them; else the single launches) — same bits either way
+    multi_branch = int(os.environ.get("SATOOLS_AMD_GEN_MULTI_BRANCH", "1"))
+
     #: the two thin upsamplers (64 -> 32 and 32 -> 16 channels) on the streaming kernel of csrc/ups2.hip
     ups2 = int(os.environ.get("SATOOLS_AMD_GEN_UPS2", "1"))
 
@@ -56,7 +60,7 @@ class CoreHifiGan(CoreHifiGanParams):
         ps = self.__dict__.get("_flat_params")
         if ps is None:
             ps = self.__dict__["_flat_params"] = list(self.parameters())
-        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf, self.ups2) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf, self.ups2, self.multi_branch) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def invalidate(self):
         self._packed_key = None
@@ -131,6 +135,7 @@ class CoreHifiGan(CoreHifiGanParams):
         check(l.sat_hifigan_set_option(self._handle, b"branch_streams", int(self.branch_streams)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"fuse_pair64", int(self.fuse_pair64)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"fuse_mrf", int(self.fuse_mrf)), "sat_hifigan_set_option")
+        check(l.sat_hifigan_set_option(self._handle, b"multi_branch", int(self.multi_branch)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"ups2", int(self.ups2)), "sat_hifigan_set_option")
         self._packed = packed  # keeps the device buffers alive
         self._packed_modes = list(modes)

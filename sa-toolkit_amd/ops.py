@@ -22,12 +22,37 @@ def _strided3(t):
     return t if t.stride(-1) == 1 else t.contiguous()
 
 
-def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_left=0, pad_right=None, groups=1,
-           up=1, in_lrelu=None, res=None, res_scale=1.0, res_toff=0, res_tstride=1, ch_scale=None, ch_shift=None,
-           relu=False, gelu=False, post_res=None, out=None, accum=False, accum_div=0.0, mode=0, t_out=None,
-           x_split=None, y_split=None, y_split_slope=1.0, no_y=False, y_split_format=0, res_split=None,
-           res_split_slope=1.0, relu_first=False, x_wrap_channels=0, c_in=None):
-    """Fused conv (see include/satools_hip.h sat_conv1d_f32).  `pad_right` defaults to the
+def conv1d(x, w_packed, c_out, ksize, **kw):
+    """Fused conv (see include/satools_hip.h sat_conv1d_f32); keyword arguments: `_conv1d_desc`."""
+    d, x, out, keep = _conv1d_desc(x, w_packed, c_out, ksize, **kw)
+    check(lib().sat_conv1d_f32(C.byref(d), ptr(x, strided=True), ptr(w_packed), ptr(out, strided=True), stream()),
+          "sat_conv1d_f32")
+    return out
+
+
+def conv1d_multi(jobs):
+    """`jobs` = 1..3 tuples (x, w_packed, c_out, ksize, kwargs) as for `conv1d`, independent of each other (or coupled only
+    through `accum` on one `out` in list order): sat_conv1d_multi_f32 — one launch of the LDS-DMA ring kernel where it
+    serves them all, else the single calls in order.  Returns the list of outputs."""
+    n = len(jobs)
+    descs = (ConvDesc * n)()
+    xs, ws, ys, outs, keep = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)(), [], []
+    for j, (x, w, c_out, ksize, kw) in enumerate(jobs):
+        d, x, out, k = _conv1d_desc(x, w, c_out, ksize, **kw)
+        descs[j] = d
+        xs[j], ws[j], ys[j] = ptr(x, strided=True), ptr(w), ptr(out, strided=True)
+        outs.append(out)
+        keep.append((x, k))
+    check(lib().sat_conv1d_multi_f32(descs, xs, ws, ys, n, stream()), "sat_conv1d_multi_f32")
+    return outs
+
+
+def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_left=0, pad_right=None, groups=1,
+                 up=1, in_lrelu=None, res=None, res_scale=1.0, res_toff=0, res_tstride=1, ch_scale=None, ch_shift=None,
+                 relu=False, gelu=False, post_res=None, out=None, accum=False, accum_div=0.0, mode=0, t_out=None,
+                 x_split=None, y_split=None, y_split_slope=1.0, no_y=False, y_split_format=0, res_split=None,
+                 res_split_slope=1.0, relu_first=False, x_wrap_channels=0, c_in=None):
+    """Descriptor of a fused conv (see include/satools_hip.h sat_conv1d_f32).  `pad_right` defaults to the
     'same'-style value implied by pad_left for stride 1; T_q is derived like torch does:
     T_q = (T_in + pad_left + pad_right - dilation*(ksize-1) - 1)//stride + 1 (`t_out` caps it).
     `post_res` is a residual added AFTER the activation (y = post_res + act(conv(x))).
@@ -80,9 +105,7 @@ def conv1d(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, pad_le
     d.res_split, d.res_split_slope = ptr(res_split), float(res_split_slope)
     d.relu_first = int(relu_first)
     d.x_wrap_channels = int(x_wrap_channels)
-    check(lib().sat_conv1d_f32(C.byref(d), ptr(x, strided=True), ptr(w_packed), ptr(out, strided=True), stream()),
-          "sat_conv1d_f32")
-    return out
+    return d, x, out, res      # (res: the possibly re-laid-out residual must outlive the launch)
 
 
 def convpost(x, w, bias):
