@@ -308,17 +308,32 @@ def last_dispatch():
     return _lib.lib().sat_last_dispatch_name().decode()
 
 
-def time_events(fn, reps, warm=2):
+def time_events(fn, reps, warm=2, samples=5):
+    """Per-call time of `fn` in ms from events on the launch stream: warmed until two successive batches of 5 calls agree
+    within 3 % (at least `warm` calls, at most 10 batches: the first calls of a leg pay allocations, code loading and a cold
+    clock), then the MEDIAN of `samples` timings of `reps` calls each.  Returns (median, {"min", "max", "samples", "warm_batches"})."""
     import torch
+
+    def batch(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    prev, batches = batch(5), 1
+    while batches < 10:
+        cur = batch(5)
+        batches += 1
+        if abs(cur - prev) <= 0.03 * min(cur, prev):
+            break
+        prev = cur
+    ts = sorted(batch(max(1, reps)) for _ in range(samples))
+    return ts[len(ts) // 2], {"min": round(ts[0], 4), "max": round(ts[-1], 4), "samples": samples, "calls_per_sample": max(1, reps), "warm_batches_of_5": batches}
 
 
 def roofline_generator(model, dev, reps):
@@ -335,22 +350,28 @@ def roofline_generator(model, dev, reps):
         spk = model.get_spk_id(wav, targets)
         ops.f0_norm_transform_(f0n)
         x = ops.assemble_input(bn, f0n, spk.to(dev, torch.float32).contiguous(), spk.shape[1])
-        gen_ms = time_events(lambda: model.hifigan(x), reps)
+        gen_ms, gen_t = time_events(lambda: model.hifigan(x), reps)
     split = model.hifigan.precision == "f16x3"
     dom = None
     if split:
-        C, T, k, d = 256, 1250, 11, 5
+        # what the generator launches on its thick stages (hifigan.hip, option multi_branch): ONE launch for the second conv of the
+        # three MRF branches (3 / 7 / 11 taps, residual from planes, planes out) — here at C = 256, T = 1250
+        C, T, ks = 256, 1250, (3, 7, 11)
         g = torch.Generator(device="cpu").manual_seed(0)
         xk = torch.randn(BATCH, C, T, generator=g).to(dev)
-        wk = packing.pack_conv_weight_f16x3((torch.randn(C, C, k, generator=g) * 0.02).to(dev))
-        bk = torch.zeros(C, device=dev)
-        xs, rs, ys = ops.act_split(xk, 0.1), ops.act_split(xk * 0.5, 0.1), ops.split_like(BATCH, C, T, dev)
-        run = lambda: ops.conv1d(xk, wk, C, k, bias=bk, dilation=d, pad_left=(k * d - d) // 2, mode=1, x_split=xs,
-                                 y_split=ys, y_split_slope=0.1, res_split=rs, res_split_slope=0.1, no_y=True, out=xk)
-        us = time_events(run, 20, warm=3) * 1e3
-        flop = 2.0 * BATCH * C * C * k * T
-        dom = {"name": last_dispatch() + " — the generator's split-f16 conv tile at 11 taps, C=256, T=1250, dilation 5, batch 32 (18 launches per forward)",
-               "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
+        xs, rs = ops.act_split(xk, 0.1), ops.act_split(xk * 0.5, 0.1)
+        jobs = []
+        for k in ks:
+            wk = packing.pack_conv_weight_f16x3((torch.randn(C, C, k, generator=g) * 0.02).to(dev))
+            jobs.append((xk, wk, C, k, dict(bias=torch.zeros(C, device=dev), dilation=1, pad_left=(k - 1) // 2, mode=1, x_split=xs,
+                                            y_split=ops.split_like(BATCH, C, T, dev), y_split_slope=0.1, res_split=rs, res_split_slope=0.1, no_y=True)))
+        run = lambda: ops.conv1d_multi(jobs)
+        us, us_t = time_events(run, 20, warm=3)
+        us, us_t = us * 1e3, {k_: (round(v * 1e3, 1) if k_ in ("min", "max") else v) for k_, v in us_t.items()}
+        flop = 2.0 * BATCH * C * C * sum(ks) * T
+        dom = {"name": last_dispatch() + " — one launch = the second conv (3 + 7 + 11 taps, residual from planes, planes out) of the three MRF "
+                                         "branches at C=256, T=1250, batch 32 (12 launches of this kind per forward: 6 per thick stage)",
+               "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "us_per_launch_min_max": us_t, "achieved": round(flop / us / 1e6, 1),
                "frac": round(flop / us / 1e6 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)}
     achieved = GEN_FLOP_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
     peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
@@ -371,6 +392,7 @@ def roofline_generator(model, dev, reps):
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note,
             "kernel": ("split-f16 conv family of the generator" if split else "conv1d_mfma_kernel (exact f32)")
                       + f": all launches of one forward, {gen_ms:.3f} ms per batch of {BATCH}",
+            "timing_ms": dict(gen_t, median=round(gen_ms, 4)),
             "dominant_kernel": dom,
             "arithmetic": ("f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 "
                            "MFMA peak / 3" if split else "exact f32 MFMA"),
@@ -386,7 +408,7 @@ def roofline_w2v2(model, dev, reps):
     from satools_amd import ops, packing, synthetic
     wav = synthetic.harm_batch(list(range(BATCH))).to(dev)
     with torch.no_grad():
-        ext_ms = time_events(lambda: model.get_bn(wav), reps)
+        ext_ms, ext_t = time_events(lambda: model.get_bn(wav), reps)
         cin, cout, T = 1024, 4096, 249
         g = torch.Generator(device="cpu").manual_seed(0)
         x = torch.randn(BATCH, cin, T, generator=g).to(dev)
@@ -394,7 +416,8 @@ def roofline_w2v2(model, dev, reps):
         b = torch.zeros(cout, device=dev)
         xs, ys = ops.act_split(x, 1.0), ops.split_like(BATCH, cout, T, dev)
         run = lambda: ops.conv1d(x, w, cout, 1, bias=b, gelu=True, mode=1, x_split=xs, y_split=ys, y_split_slope=1.0, no_y=True)
-        us = time_events(run, 20, warm=3) * 1e3
+        us, us_t = time_events(run, 20, warm=3)
+        us, us_t = us * 1e3, {k_: (round(v * 1e3, 1) if k_ in ("min", "max") else v) for k_, v in us_t.items()}
         dom_name = last_dispatch()
     flop = 2.0 * BATCH * T * cin * cout
     peak = PEAK_F16_MFMA_TFLOPS / 3.0
@@ -414,8 +437,9 @@ def roofline_w2v2(model, dev, reps):
             "hbm_model": {"achieved_TBps": round(hbm, 3), "peak_TBps": PEAK_HBM_TBS, "frac": round(hbm / PEAK_HBM_TBS, 4),
                           "bytes_per_launch_group": model_bytes},
             "kernel": f"wav2vec2-large + TDNNF tail bottleneck extractor (get_bn): all launches, {ext_ms:.3f} ms per batch of {BATCH}",
+            "timing_ms": dict(ext_t, median=round(ext_ms, 4)),
             "dominant_kernel": {"name": dom_name + " — the 1x1 GEMM on split planes of the encoder's Linear layers: FFN 1024 -> 4096 + GELU, 249 frames, batch 32",
-                                "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "achieved": round(flop / us / 1e6, 1),
+                                "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "us_per_launch_min_max": us_t, "achieved": round(flop / us / 1e6, 1),
                                 "frac": round(flop / us / 1e6 / peak, 4)},
             "arithmetic": "f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 MFMA peak / 3",
             "algorithmic_flop_per_launch_group": W2V2_FLOP_PER_UTT * BATCH}

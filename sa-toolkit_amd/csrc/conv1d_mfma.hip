@@ -1718,13 +1718,13 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
       return launch_f16x3_k1(a, d->B, s);
     }
     SAT_REQUIRE(!a.k1_wrap, "conv1d: x_wrap_channels is only served by the 1x1 GEMM path (C_in %% 64 == 0, up 1, 31-bit slabs)");
+    // the generator's resblock convs at C >= 128: the LDS-DMA ring on the 16x16x32 shape (conv_ring16.hip)
+    if (d->groups == 1 && convring_supports(a, d->B)) return launch_f16x3_convring(a, d->B, s);
     // few blocks (TDNNF linearB: 128 rows x 250 frames x 32 utterances = 64 tiles of 64 x 256 on 256 CUs): half-width
     // tiles double the blocks of these latency-bound launches
     if (a.x16 && a.ksize == 3 && !a.f8 && !a.poly_planes && a.rows_g > 32 && a.T_q > 128 &&
         (long long)ceil_div(a.rows_g, 64) * ceil_div(a.T_q, 256) * d->B * d->groups < 256)
       return launch_f16x3<2, 1, 3>(a, d->B, d->groups, s);
-    // the generator's resblock convs at C >= 128: the LDS-DMA ring on the 16x16x32 shape (conv_ring16.hip)
-    if (d->groups == 1 && convring_supports(a)) return launch_f16x3_convring(a, d->B, s);
     // the generator's resblock convs: the three-blocks-per-CU form of the tile (conv_lean.hip)
     if (d->groups == 1 && (a.ksize == 3 ? g_lean3 : a.ksize == 7 ? g_lean7 : g_lean11) && lean_supports(a))
       return launch_f16x3_lean(a, d->B, s);
@@ -1751,7 +1751,7 @@ extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const
   for (int j = 0; j < n; ++j) {
     int st = conv1d_prepare(&d[j], x[j], w_packed[j], y[j], a[j]);
     if (st != SAT_OK) return st;
-    ring = ring && (d[j].mode == SAT_CONV_F16X3) && d[j].groups == 1 && d[j].B == d[0].B && convring_supports(a[j]) && convring_same_shape(a[j], a[0]);
+    ring = ring && (d[j].mode == SAT_CONV_F16X3) && d[j].groups == 1 && d[j].B == d[0].B && convring_supports(a[j], d[j].B) && convring_same_shape(a[j], a[0]);
   }
   // the order of the jobs may rotate from block to block unless a job reads (accumulates into, takes its residual or
   // input from) what another one writes

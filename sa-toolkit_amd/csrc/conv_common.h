@@ -620,7 +620,7 @@ int launch_f16x3_ring16(const ConvArgs& a, int B, hipStream_t s);   // the same 
 int launch_f16x3_convring(const ConvArgs& a, int B, hipStream_t s);
 int launch_f16x3_convring_multi(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s);   // up to three convs of one shape in one launch
 bool convring_same_shape(const ConvArgs& a, const ConvArgs& b);
-bool convring_supports(const ConvArgs& a);
+bool convring_supports(const ConvArgs& a, int B);
 void convring_set(int v);
 int convring_debug_stamps(long long* buf);
 bool ring16_supports(const ConvArgs& a);

@@ -471,23 +471,6 @@ int convring_debug_stamps(long long* buf) {
   return CR_STAMPS;
 }
 
-// rows > 64 (the 64-row stage keeps the register-staged tile), taps >= 3, channel pairs, the halo inside the X tile
-bool convring_supports(const ConvArgs& a) {
-  if (!(g_convring & 1)) return false;
-  if (!(a.x16 && !a.f8 && !a.y16_f8 && !a.poly_planes && !a.k1_wrap && a.fast_epi && a.up == 1 && a.stride == 1)) return false;
-  if (!epilogue16_supports(a) || a.ksize < 3 || a.cin_g % 32 != 0 || a.rows_g <= 64) return false;
-  // what ring_epilogue carries: bias, residual from planes (scale 1, before the activation), accumulation, f32 / plane stores
-  if (a.ch_scale || a.relu || a.gelu || a.res || a.res_after || !a.bias || (a.res16 && a.res_scale != 1.f) || (a.accum && a.no_y)) return false;
-  const int halo = (a.ksize - 1) * a.dil;
-  return a.rows_g > 128 ? halo <= 224 - 160 : halo <= 384 - 320;
-}
-
-// jobs of one shape (channels, lengths, batch): what one launch can walk
-bool convring_same_shape(const ConvArgs& a, const ConvArgs& b) {
-  return a.cin_g == b.cin_g && a.cin_pad == b.cin_pad && a.rows_g == b.rows_g && a.co_pad == b.co_pad && a.T_in == b.T_in && a.T_q == b.T_q &&
-         (a.no_y || b.no_y || (a.y_bs == b.y_bs && a.y_cs == b.y_cs));
-}
-
 static int cu_count() {
   static std::atomic<int> n{0};
   int v = n.load(std::memory_order_relaxed);
@@ -499,6 +482,27 @@ static int cu_count() {
     n.store(v, std::memory_order_relaxed);
   }
   return v;
+}
+
+// rows > 64 (the 64-row stage keeps the register-staged tile), taps >= 3, channel pairs, the halo inside the X tile — and enough
+// tiles for three quarters of the CUs (one 8-wave block per CU: a batch of a few utterances is better served by the small
+// tiles of conv_lean.hip).  Option "convring": 0 = off, 1 = on (default), + 32 = whatever the number of tiles
+bool convring_supports(const ConvArgs& a, int B) {
+  if (!(g_convring & 1)) return false;
+  if (!(a.x16 && !a.f8 && !a.y16_f8 && !a.poly_planes && !a.k1_wrap && a.fast_epi && a.up == 1 && a.stride == 1)) return false;
+  if (!epilogue16_supports(a) || a.ksize < 3 || a.cin_g % 32 != 0 || a.rows_g <= 64) return false;
+  // what ring_epilogue carries: bias, residual from planes (scale 1, before the activation), accumulation, f32 / plane stores
+  if (a.ch_scale || a.relu || a.gelu || a.res || a.res_after || !a.bias || (a.res16 && a.res_scale != 1.f) || (a.accum && a.no_y)) return false;
+  const int halo = (a.ksize - 1) * a.dil;
+  if (a.rows_g > 128 ? halo > 224 - 160 : halo > 384 - 320) return false;
+  const long long tiles = a.rows_g > 128 ? (long long)ceil_div(a.rows_g, 256) * ceil_div(a.T_q, 160) * B : (long long)ceil_div(a.T_q, 320) * B;
+  return (g_convring & 32) || tiles * 4 >= (long long)cu_count() * 3;
+}
+
+// jobs of one shape (channels, lengths, batch): what one launch can walk
+bool convring_same_shape(const ConvArgs& a, const ConvArgs& b) {
+  return a.cin_g == b.cin_g && a.cin_pad == b.cin_pad && a.rows_g == b.rows_g && a.co_pad == b.co_pad && a.T_in == b.T_in && a.T_q == b.T_q &&
+         (a.no_y || b.no_y || (a.y_bs == b.y_bs && a.y_cs == b.y_cs));
 }
 
 template <int WR>

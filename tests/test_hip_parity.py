@@ -21,6 +21,22 @@ def _rand(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
+class conv_option:
+    """sat_conv_set_option(name, value) for the duration of a with-block (restored to `default` afterwards)"""
+
+    def __init__(self, name, value, default):
+        self.name, self.value, self.default = name.encode(), value, default
+
+    def __enter__(self):
+        from satools_amd import _lib
+        _lib.check(_lib.lib().sat_conv_set_option(self.name, self.value), "sat_conv_set_option")
+
+    def __exit__(self, *a):
+        from satools_amd import _lib
+        _lib.check(_lib.lib().sat_conv_set_option(self.name, self.default), "sat_conv_set_option")
+
+
+
 # ---------------------------------------------------------------------------------------------
 # fused conv1d kernel vs torch (f32 CPU) on the shapes the path uses
 # tolerance: f32 re-association only: |err| <= 2e-5 * (|x| . |w|) scale
@@ -426,6 +442,16 @@ def test_generator_split_plane_pipeline_equals_f32_handover(model, gold):
     if g.precision != "f16x3":
         pytest.skip("split planes belong to the split-f16 generator")
     x = torch.randn(2, g.imput_dim, 25, generator=torch.Generator().manual_seed(3)).to(DEV)
+    with conv_option("convring", 33, 1):
+        y_ring = g(x)[0].clone()             # the thick stages on the LDS-DMA ring conv (16x16x32 MFMA shape; + 32: also for this small batch)
+    with conv_option("convring", 0, 1):      # the register-staged tiles below accumulate in ONE order whatever the staging
+        _split_plane_pipeline_equals_f32_handover(g, x, lib, check)
+        y_lean = g(x)[0]
+    # K = 32 per instruction associates differently: agreement to f32 rounding of the accumulation
+    assert rms((y_ring - y_lean).cpu().numpy()) < 5e-7
+
+
+def _split_plane_pipeline_equals_f32_handover(g, x, lib, check):
     y2 = g(x)[0].clone()                     # default: planes only, residuals rebuilt from hi + lo (22 bits)
     check(lib().sat_hifigan_set_option(g._handle, b"branch_streams", 0), "set_option")
     y2s = g(x)[0].clone()                    # the three resblock branches of a stage on one stream
@@ -856,6 +882,7 @@ def test_three_blocks_per_cu_form_of_the_conv_tile_gives_the_same_bits(C, T, dil
     wp = packing.pack_conv_weight_f16x3(w)
     out = {}
     try:
+        _lib.check(_lib.lib().sat_conv_set_option(b"convring", 0), "sat_conv_set_option")     # (else C >= 128 goes to conv_ring16.hip)
         for v in (0, 1):
             _lib.check(_lib.lib().sat_conv_set_option(b"lean%d" % k, v), "sat_conv_set_option")
             ys = ops.split_like(B, C, T, DEV)
@@ -864,6 +891,7 @@ def test_three_blocks_per_cu_form_of_the_conv_tile_gives_the_same_bits(C, T, dil
             out[v] = (y, ys)
     finally:
         _lib.check(_lib.lib().sat_conv_set_option(b"lean%d" % k, 1), "sat_conv_set_option")
+        _lib.check(_lib.lib().sat_conv_set_option(b"convring", 1), "sat_conv_set_option")
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     ref = (acc0.double().cpu() + F.conv1d(F.leaky_relu(x.double().cpu(), 0.1), w.double().cpu(), b.double().cpu(), dilation=dil, padding=dil * (k - 1) // 2)
            + r.double().cpu()) / 3.0
@@ -1170,6 +1198,7 @@ def test_balanced_grid_of_the_conv_tile_gives_the_same_bits(C, T, k, dil):
     wp = packing.pack_conv_weight_f16x3(w)
     out = {}
     try:
+        _lib.check(_lib.lib().sat_conv_set_option(b"convring", 0), "sat_conv_set_option")     # (else C >= 128 goes to conv_ring16.hip)
         for v in (0, 1, 2):
             _lib.check(_lib.lib().sat_conv_set_option(b"lean_balance", v), "sat_conv_set_option")
             ys = ops.split_like(B, C, T, DEV)
@@ -1178,7 +1207,140 @@ def test_balanced_grid_of_the_conv_tile_gives_the_same_bits(C, T, k, dil):
             out[v] = (y, ys)
     finally:
         _lib.check(_lib.lib().sat_conv_set_option(b"lean_balance", 1), "sat_conv_set_option")
+        _lib.check(_lib.lib().sat_conv_set_option(b"convring", 1), "sat_conv_set_option")
     for v in (1, 2):
         assert torch.equal(out[0][0], out[v][0]) and torch.equal(out[0][1], out[v][1])
     ref = F.conv1d(F.leaky_relu(x.double().cpu(), 0.1), w.double().cpu(), b.double().cpu(), dilation=dil, padding=dil * (k - 1) // 2)
     assert (out[1][0].cpu().double() - ref).abs().max().item() < 3e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# round 4: the LDS-DMA ring conv on the 16x16x32 MFMA shape (csrc/conv_ring16.hip) and sat_conv1d_multi_f32
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,T,k,dil", [(256, 1250, 11, 5), (256, 333, 7, 3), (128, 700, 3, 5), (128, 97, 11, 1), (192, 401, 7, 1), (512, 200, 3, 1),
+                                       (320, 161, 11, 3), (128, 5000, 7, 5), (256, 159, 3, 3), (128, 321, 3, 1)], ids=lambda v: str(v))
+def test_ring_conv_on_split_planes(C, T, k, dil):
+    """conv1d_f16x3_ring16_kernel (C_out > 64, taps >= 3: the generator's resblock convs of the 256- and 128-channel stages,
+    reference hifigan/nn.py:96-175) against float64 and against the register-staged tile it replaces: tile edges of both
+    layouts (256 x 160, 128 x 320), row counts that do not fill a tile, every dilation of the generator; the three
+    epilogues of a ResBlock (planes only; residual from planes; residual + MRF accumulate / 3 with f32 and planes out).
+    K = 32 per MFMA associates differently from the 32x32x16 tile: agreement to f32 rounding, not bit for bit; the planes
+    it writes are exactly the split of the f32 values it writes beside them"""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    B = 3
+    x, w, b = _rand(B, C, T, seed=1).to(DEV), _rand(C, C, k, seed=2, scale=(k * C) ** -0.5).to(DEV), _rand(C, seed=3).to(DEV)
+    r, acc0 = _rand(B, C, T, seed=4).to(DEV), _rand(B, C, T, seed=5).to(DEV)
+    xs, rs = ops.act_split(x, 0.1), ops.act_split(r, 0.1)
+    wp = packing.pack_conv_weight_f16x3(w)
+    kw = dict(bias=b, dilation=dil, pad_left=dil * (k - 1) // 2, mode=1, x_split=xs, y_split_slope=0.1)
+    conv64 = F.conv1d(F.leaky_relu(x.double().cpu(), 0.1), w.double().cpu(), b.double().cpu(), dilation=dil, padding=dil * (k - 1) // 2)
+    r64 = r.double().cpu()
+    res = {}
+    for ring in (0, 1):
+        with conv_option("convring", 33 * ring, 1):          # (+ 32: also for the handful of tiles of a three-utterance batch)
+            ys1 = ops.split_like(B, C, T, DEV).zero_()
+            ops.conv1d(x, wp, C, k, y_split=ys1, no_y=True, **kw)
+            name = _lib.lib().sat_last_dispatch_name().decode()
+            assert ("ring16" in name) == bool(ring), name
+            ys2 = ops.split_like(B, C, T, DEV).zero_()
+            y2 = ops.conv1d(x, wp, C, k, y_split=ys2, res_split=rs, res_split_slope=0.1, **kw)
+            ys3 = ops.split_like(B, C, T, DEV).zero_()
+            y3 = ops.conv1d(x, wp, C, k, y_split=ys3, res_split=rs, res_split_slope=0.1, out=acc0.clone(), accum=True, accum_div=3.0, **kw)
+            res[ring] = (ops.unsplit(ys1), y2, ops.unsplit(ys2), y3, ops.unsplit(ys3), ys2, ys3)
+    new, old = res[1], res[0]
+    scale = float(conv64.abs().max())
+    assert (new[0].cpu().double() - F.leaky_relu(conv64, 0.1)).abs().max().item() < 3e-5
+    assert (new[1].cpu().double() - (conv64 + r64)).abs().max().item() < 3e-5
+    assert (new[3].cpu().double() - (acc0.double().cpu() + conv64 + r64) / 3).abs().max().item() < 3e-5
+    for a, bb in zip(new[:5], old[:5]):
+        assert (a - bb).abs().max().item() <= 3e-6 * scale
+    assert torch.equal(new[5], ops.act_split(new[1], 0.1)) and torch.equal(new[6], ops.act_split(new[3], 0.1))
+
+
+@pytest.mark.parametrize("C,T", [(256, 1250), (128, 700), (192, 333)], ids=lambda v: str(v))
+def test_conv1d_multi_equals_the_single_calls(C, T):
+    """sat_conv1d_multi_f32: the i-th conv of the three branches of an MRF block (kernel sizes 3 / 7 / 11, reference
+    hifigan/archi.py:82-86) in ONE launch of the ring kernel — independent jobs (the order rotates from block to block), jobs
+    chained through the MRF accumulator (index order), and a set the ring kernel does not serve (falls back to the single
+    calls): the bits of the single calls every time"""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    B, ks, dils = 4, (3, 7, 11), (1, 3, 5)
+    x = _rand(B, C, T, seed=1).to(DEV)
+    xs = ops.act_split(x, 0.1)
+    ws = [packing.pack_conv_weight_f16x3(_rand(C, C, k, seed=10 + k, scale=(k * C) ** -0.5).to(DEV)) for k in ks]
+    bs = [_rand(C, seed=20 + k).to(DEV) for k in ks]
+
+    def jobs(kind, ys, acc):
+        out = []
+        for j, k in enumerate(ks):
+            kw = dict(bias=bs[j], dilation=dils[j], pad_left=dils[j] * (k - 1) // 2, mode=1, x_split=xs, y_split_slope=0.1)
+            if kind == "conv1":
+                kw.update(y_split=ys[j], no_y=True)
+            elif kind == "conv2":
+                kw.update(y_split=ys[j], no_y=True, res_split=xs, res_split_slope=0.1)
+            else:
+                kw.update(res_split=xs, res_split_slope=0.1, out=acc, accum=j > 0, accum_div=3.0 if j == 2 else 0.0, y_split=ys[2] if j == 2 else None)
+            out.append((x, ws[j], C, k, kw))
+        return out
+
+    from satools_amd import _lib as L
+    L.check(L.lib().sat_conv_set_option(b"convring", 33), "sat_conv_set_option")      # (+ 32: also for the few tiles of this batch)
+    try:
+        _multi_equals_singles(ops, packing, _lib, jobs, ks, B, C, T, x, xs, bs)
+    finally:
+        L.check(L.lib().sat_conv_set_option(b"convring", 1), "sat_conv_set_option")
+
+
+def _multi_equals_singles(ops, packing, _lib, jobs, ks, B, C, T, x, xs, bs):
+    for kind in ("conv1", "conv2", "last"):
+        got = {}
+        for how in ("single", "multi"):
+            ys = [ops.split_like(B, C, T, DEV).zero_() for _ in ks]
+            acc = torch.full((B, C, T), 7.0, device=DEV)
+            if how == "single":
+                for (xx, w, c, k, kw) in jobs(kind, ys, acc):
+                    ops.conv1d(xx, w, c, k, **kw)
+            else:
+                ops.conv1d_multi(jobs(kind, ys, acc))
+                assert "ring16" in _lib.lib().sat_last_dispatch_name().decode()
+            got[how] = (ys, acc)
+        for a, bb in zip(got["single"][0], got["multi"][0]):
+            assert torch.equal(a, bb), kind
+        assert torch.equal(got["single"][1], got["multi"][1]), kind
+    # two jobs; and a set with a 1-tap member: served by the single calls
+    ys = [ops.split_like(B, C, T, DEV).zero_() for _ in range(2)]
+    ops.conv1d_multi(jobs("conv1", ys + [None], None)[:2])
+    ys1 = [ops.split_like(B, C, T, DEV).zero_() for _ in range(2)]
+    for (xx, w, c, k, kw) in jobs("conv1", ys1 + [None], None)[:2]:
+        ops.conv1d(xx, w, c, k, **kw)
+    assert all(torch.equal(a, bb) for a, bb in zip(ys, ys1))
+    w1 = packing.pack_conv_weight_f16x3(_rand(C, C, 1, seed=5, scale=C ** -0.5).to(DEV))
+    ya, yb = ops.split_like(B, C, T, DEV).zero_(), ops.split_like(B, C, T, DEV).zero_()
+    j3 = jobs("conv1", [ya, None, None], None)[0]
+    j1 = (x, w1, C, 1, dict(bias=bs[0], mode=1, x_split=xs, y_split=yb, y_split_slope=0.1, no_y=True))
+    ops.conv1d_multi([j3, j1])
+    yc = ops.split_like(B, C, T, DEV).zero_()
+    ops.conv1d(x, w1, C, 1, bias=bs[0], mode=1, x_split=xs, y_split=yc, y_split_slope=0.1, no_y=True)
+    assert torch.equal(yb, yc)
+    with pytest.raises(_lib.SatError):
+        ops.conv1d_multi([j3] * 4)
+
+
+def test_generator_multi_branch_launches_give_the_same_bits(model):
+    """generator option "multi_branch": the i-th conv of all three MRF branches of the thick stages as one
+    sat_conv1d_multi_f32 call against the eighteen single launches per stage"""
+    from satools_amd._lib import lib, check
+    g = model.hifigan
+    if g.precision != "f16x3":
+        pytest.skip("the ring conv belongs to the split-f16 generator")
+    x = torch.randn(3, g.imput_dim, 57, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with conv_option("convring", 33, 1):                 # (the ring kernel also for this small batch)
+        y1 = g(x)[0].clone()
+        check(lib().sat_hifigan_set_option(g._handle, b"multi_branch", 0), "set_option")
+        try:
+            y0 = g(x)[0].clone()
+        finally:
+            check(lib().sat_hifigan_set_option(g._handle, b"multi_branch", g.multi_branch), "set_option")
+    assert torch.equal(y0, y1)
