@@ -165,7 +165,11 @@ def lib():
         # SATOOLS_AMD_CONV_OPTIONS="pair32w=0,lean_balance=2" -> sat_conv_set_option(name, value) at load time
         for item in filter(None, os.environ.get("SATOOLS_AMD_CONV_OPTIONS", "").split(",")):
             name, _, value = item.partition("=")
-            if l.sat_conv_set_option(name.strip().encode(), int(value)) != 0:
+            try:
+                value = int(value)
+            except ValueError:
+                raise SatError(f"SATOOLS_AMD_CONV_OPTIONS: '{item.strip()}' is not of the form name=integer") from None
+            if l.sat_conv_set_option(name.strip().encode(), value) != 0:
                 raise SatError(f"SATOOLS_AMD_CONV_OPTIONS: {l.sat_last_error().decode('utf-8', 'replace')}")
         _lib = l
     return _lib

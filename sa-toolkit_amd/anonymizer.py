@@ -158,40 +158,45 @@ def build(args):
             with torch.no_grad():
                 # ---- bottleneck extractor: compare the projections the VQ decides on, and the decisions
                 cfg = {k: getattr(ext, k) for k in ("precision", "w2v2_precision") if hasattr(ext, k)}
+                bn32 = None
                 if any(v != "f32" for v in cfg.values()):
                     _, (z, idx, _) = ext.extract_bn(wav.clone(), want_aux=True)
-                    for k in cfg:
-                        setattr(ext, k, "f32")
-                    _, (z32, idx32, _) = ext.extract_bn(wav.clone(), want_aux=True)
-                    out["bn_extractor"] = relrms(z, z32)
-                    out["bn_index_agreement"] = float((idx == idx32).float().mean())
-                    if out["bn_extractor"] <= 5 * tol and out["bn_index_agreement"] >= 0.98:
-                        for k, v in cfg.items():
-                            setattr(ext, k, v)
-                    elif fallback:
-                        fell.append("bn_extractor")
-                    else:
-                        for k, v in cfg.items():
-                            setattr(ext, k, v)
-                # ---- generator, teacher-forced on the exact-f32 extractor's features
+                    keep_f32 = False
+                    try:                                   # whatever happens in between (an OOM on the 16x slower exact kernels ...),
+                        for k in cfg:                      # the configuration is restored unless the fall-back was DECIDED
+                            setattr(ext, k, "f32")
+                        _, (z32, idx32, _) = ext.extract_bn(wav.clone(), want_aux=True)
+                        bn32 = self.get_bn(wav)
+                        out["bn_extractor"] = relrms(z, z32)
+                        out["bn_index_agreement"] = float((idx == idx32).float().mean())
+                        if not (out["bn_extractor"] <= 5 * tol and out["bn_index_agreement"] >= 0.98) and fallback:
+                            fell.append("bn_extractor")
+                            keep_f32 = True
+                    finally:
+                        if not keep_f32:
+                            for k, v in cfg.items():
+                                setattr(ext, k, v)
+                # ---- generator, teacher-forced on the exact-f32 extractor's features (computed above while it was configured so)
                 if gen.precision != "f32":
                     f0 = self.get_f0(wav).unsqueeze(0)
-                    bn = self.get_bn(wav)
+                    bn = bn32 if bn32 is not None else self.get_bn(wav)
                     f0n = f0.clone()
                     ops.f0_norm_transform_(f0n)
                     spk = F.one_hot(torch.zeros(wav.shape[0], dtype=torch.long), num_classes=len(self.spk))
                     x = ops.assemble_input(bn, f0n.reshape(wav.shape[0], -1), spk.to(dev, torch.float32).contiguous(), spk.shape[1])
                     keep = gen.precision
-                    y = gen(x)[0]
-                    gen.precision = "f32"
-                    y32 = gen(x)[0]
-                    out["generator"] = relrms(y, y32)
-                    if out["generator"] <= 50 * tol:          # waveform RMS ~0.1: 1e-3 relative = the path's 1e-4 bar
-                        gen.precision = keep
-                    elif fallback:
-                        fell.append("generator")
-                    else:
-                        gen.precision = keep
+                    keep_f32 = False
+                    try:
+                        y = gen(x)[0]
+                        gen.precision = "f32"
+                        y32 = gen(x)[0]
+                        out["generator"] = relrms(y, y32)
+                        if out["generator"] > 50 * tol and fallback:          # waveform RMS ~0.1: 1e-3 relative = the path's 1e-4 bar
+                            fell.append("generator")
+                            keep_f32 = True
+                    finally:
+                        if not keep_f32:
+                            gen.precision = keep
             out["fallback"] = fell
             if fell:
                 warnings.warn(f"satools_amd: {', '.join(fell)} left the range the split-f16 kernels represent on the calibration "

@@ -621,6 +621,12 @@ extern "C" int sat_attention_f16x3(const void* q_split, const void* k_split, con
   SAT_REQUIRE(B > 0 && heads > 0 && T > 0, "attention: empty shape");
   SAT_REQUIRE(head_dim == 64, "attention: head dimension 64 only (got %d)", head_dim);
   SAT_REQUIRE(v_pitch >= T && v_pitch % 4 == 0, "attention: v needs a row pitch >= T that is a multiple of 4 floats (got %d)", v_pitch);
+  // the running maximum is taken on the raw scores and the scale applied afterwards: a positive scale only
+  SAT_REQUIRE(scale > 0.f, "attention: the score scale must be positive (got %g)", (double)scale);
+  // the K planes of an utterance (heads * head_dim channels x T x 4 B) and the V rows of a head (64 x v_pitch x 4 B) sit behind
+  // 32-bit buffer descriptors
+  SAT_REQUIRE((long long)heads * head_dim * T * 16 < (1LL << 31) && (long long)64 * v_pitch * 4 < (1LL << 31),
+              "attention: %d heads x %d frames (v pitch %d) do not fit 31-bit buffer offsets", heads, T, v_pitch);
   const size_t lds_bytes = (size_t)2 * 2 * 64 * AT_VU * 16;  // two regions of a split V image [hi|lo][64][33 units] >= K planes = V f32 rows (64 KB)
   const int nw = T > 128 ? 8 : 4;
   auto kern = nw == 8 ? attention_f16x3_kernel<8> : attention_f16x3_kernel<4>;

@@ -39,6 +39,17 @@ def _enc(x):
     raise TypeError(f"frozen export: cannot store {type(x)}")
 
 
+def _plain(x):
+    """build arguments as plain python (what `torch.load(weights_only=True)` accepts): anything else is stored as its str()"""
+    if x is None or isinstance(x, (bool, int, float, str)):
+        return x
+    if isinstance(x, (list, tuple)):
+        return [_plain(v) for v in x]
+    if isinstance(x, dict):
+        return {str(k): _plain(v) for k, v in x.items()}
+    return str(x)
+
+
 def _dec(x, device, mods=None):
     from .asrbn import _LayerCache
     if isinstance(x, dict):
@@ -85,7 +96,7 @@ def export_frozen(model, path):
     gen._prepare(dev)
     ext._prepare(dev)
     blob = {"format": FORMAT, "kind": "anonymizer",
-            "build_args": dict(model._build_args), "utt2spk": dict(model.utt2spk),
+            "build_args": _plain(dict(model._build_args)), "utt2spk": {str(k): str(v) for k, v in dict(model.utt2spk).items()},
             "generator": {"packed": _enc(gen._packed), "modes": list(gen._packed_modes), "precision": gen.precision},
             "extractor": {"class": type(ext).__name__, "precision": ext.precision, "cache": _enc(ext._cache)}}
     if hasattr(ext, "_prepare_full"):
@@ -105,9 +116,11 @@ def load_frozen(path, device="cuda"):
     """-> the anonymizer `Net`, on `device`, in eval mode, ready for convert(); no parameters inside"""
     from . import anonymizer
     from .asrbn import TDNNFBatchNormParams
-    blob = torch.load(path, weights_only=False, map_location="cpu")
-    if blob.get("format") != FORMAT:
-        raise _lib.SatError(f"{path}: not a {FORMAT} file")
+    # plain containers, numbers, strings and tensors only (_enc refuses anything else at export): the restricted unpickler
+    # is enough, and a file from elsewhere cannot run code at load time
+    blob = torch.load(path, weights_only=True, map_location="cpu")
+    if not isinstance(blob, dict) or blob.get("format") != FORMAT or blob.get("kind") != "anonymizer":
+        raise _lib.SatError(f"{path}: not a {FORMAT} anonymizer file")
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.SatError("load_frozen: the packed weights only exist for the HIP device (no CPU fallback)")
@@ -116,6 +129,8 @@ def load_frozen(path, device="cuda"):
     _strip_parameters(net, device)
     gen, ext = net.hifigan, net.bn_extractor
     gen.precision = blob["generator"]["precision"]
+    if len(blob["generator"]["packed"].get("__l__", [])) != len(blob["generator"]["modes"]):
+        raise _lib.SatError(f"{path}: packed convolutions and modes differ in number")
     gen._install_packed(_dec(blob["generator"]["packed"], device), blob["generator"]["modes"])
     gen.__dict__["_frozen"] = True
     e = blob["extractor"]

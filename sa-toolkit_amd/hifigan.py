@@ -127,10 +127,16 @@ class CoreHifiGan(CoreHifiGanParams):
                                        _lib.int_array(self.resblock_kernel_sizes), _lib.int_array(dil)),
                   "sat_hifigan_create")
             self._handle = h
+        n = l.sat_hifigan_num_convs(self._handle)
+        if len(packed) != n or len(modes) != n:
+            raise _lib.SatError(f"generator: {len(packed)} packed convolutions / {len(modes)} modes for an architecture of {n}")
         for i, ((wp, b), mode) in enumerate(zip(packed, modes)):
             check(l.sat_hifigan_set_conv(self._handle, i, ptr(wp), ptr(b), mode), "sat_hifigan_set_conv")
             if mode == _lib.CONV_F16X3:      # the packed weights' power-of-two layer scale (packing.pack_conv_weight_f16x3)
-                check(l.sat_hifigan_set_conv_descale(self._handle, i, float(getattr(wp, "w_descale", 1.0))), "sat_hifigan_set_conv_descale")
+                if not hasattr(wp, "w_descale"):
+                    raise _lib.SatError(f"generator conv {i}: split-f16 packed weights without .w_descale (lost by .to() / .clone(): "
+                                        "use packing.move_packed, or set it to 1.0 for weights packed with scale=False)")
+                check(l.sat_hifigan_set_conv_descale(self._handle, i, float(wp.w_descale)), "sat_hifigan_set_conv_descale")
         check(l.sat_hifigan_set_option(self._handle, b"split_acts", int(self.split_acts)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"branch_streams", int(self.branch_streams)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"fuse_pair64", int(self.fuse_pair64)), "sat_hifigan_set_option")

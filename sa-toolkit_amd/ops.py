@@ -14,6 +14,19 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _descale(w_packed, mode=1):
+    """power-of-two layer scale of split-f16 packed weights (packing.pack_conv_weight_f16x3 attaches it as `.w_descale`).
+    The attribute does not survive .to() / .clone() / .contiguous() / indexing: a packed tensor WITHOUT it in split-f16 mode is
+    refused instead of being multiplied as if its scale were 1 (every output of the layer would be off by 2^e)."""
+    if int(mode) != 1:
+        return float(getattr(w_packed, "w_descale", 1.0))
+    d = getattr(w_packed, "w_descale", None)
+    if d is None:
+        raise _lib.SatError("split-f16 packed weights without .w_descale: pack on the target device (packing.pack_conv_weight_f16x3), "
+                            "move them with packing.move_packed(), or set w.w_descale = 1.0 for weights packed with scale=False")
+    return float(d)
+
+
 def _strided3(t):
     """[B, C, T] tensor usable by the conv kernel: f32, innermost axis contiguous (views with a row
     pitch are fine: the kernel takes batch / channel strides)"""
@@ -84,7 +97,7 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
     d.B, d.C_in, d.T_in, d.C_out, d.T_q = B, (c_in if c_in_w is None else int(c_in_w)), t_in, c_out, t_q
     d.ksize, d.dilation, d.stride, d.pad_left, d.groups, d.up = ksize, dilation, stride, pad_left, groups, up
     d.mode = int(mode)
-    d.w_descale = float(getattr(w_packed, "w_descale", 1.0))      # power-of-two layer scale of split-f16 packed weights (packing.py)
+    d.w_descale = _descale(w_packed, mode)      # power-of-two layer scale of split-f16 packed weights (packing.py)
     d.in_lrelu = 0 if in_lrelu is None else 1
     d.in_slope = 0.0 if in_lrelu is None else float(in_lrelu)
     d.relu, d.gelu, d.res_after_act = int(relu), int(gelu), int(post_res is not None)
@@ -313,9 +326,9 @@ def resblock_pair(x, w1, b1, w2, b2, ksize, dilation, slope=0.1, out=None, accum
     if planes_residual:
         d.res_split, d.res_split_slope = ptr(x_split), float(slope)
     d.no_y = int(no_y)
-    d.w_descale = float(getattr(w2, "w_descale", 1.0))
+    d.w_descale = _descale(w2)
     check(lib().sat_resblock_pair_scaled_f16x3(C.byref(d), None if planes_residual else ptr(x), ptr(w1), ptr(b1),
-                                               float(getattr(w1, "w_descale", 1.0)), ptr(w2), ptr(out), stream()),
+                                               _descale(w1), ptr(w2), ptr(out), stream()),
           "sat_resblock_pair_scaled_f16x3")
     return out
 
@@ -334,7 +347,7 @@ def resblock_mrf(x_split, B, c, t, branches, slope=0.1, out=None, y_split=None, 
             d.dilation[j][i] = 2 * i + 1
             d.w[j][i][0], d.w[j][i][1] = ptr(w1), ptr(w2)
             d.bias[j][i][0], d.bias[j][i][1] = ptr(b1), ptr(b2)
-            d.w_descale[j][i][0], d.w_descale[j][i][1] = float(getattr(w1, "w_descale", 1.0)), float(getattr(w2, "w_descale", 1.0))
+            d.w_descale[j][i][0], d.w_descale[j][i][1] = _descale(w1), _descale(w2)
             keep += [w1, b1, w2, b2]
     d.slope = float(slope)
     d.x_split = ptr(x_split)
@@ -354,7 +367,7 @@ def upsample2(x_split, w_packed, bias, B, c_in, t, y_split_slope=0.1, y_split=No
     lrelu(y, y_split_slope), [B][c_in / 2][2 t]"""
     if y_split is None:
         y_split = split_like(B, c_in // 2, 2 * t, x_split.device)
-    check(lib().sat_upsample2_f16x3(ptr(x_split), ptr(w_packed), ptr(bias), float(getattr(w_packed, "w_descale", 1.0)), ptr(y_split),
+    check(lib().sat_upsample2_f16x3(ptr(x_split), ptr(w_packed), ptr(bias), _descale(w_packed), ptr(y_split),
                                     float(y_split_slope), B, c_in, t, stream()), "sat_upsample2_f16x3")
     return y_split
 

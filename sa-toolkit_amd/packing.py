@@ -99,6 +99,15 @@ def pack_conv_weight_f16x3(w: torch.Tensor, groups: int = 1, up: int = 1, scale:
     return out
 
 
+def move_packed(w: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+    """`w.to(*args, **kwargs)` for a tensor packed by pack_conv_weight_f16x3, keeping its `.w_descale` (a plain .to() / .clone() /
+    .contiguous() returns a tensor without the attribute, which ops.* refuse in split-f16 mode)"""
+    out = w.to(*args, **kwargs)
+    if hasattr(w, "w_descale"):
+        out.w_descale = w.w_descale
+    return out
+
+
 F8_W_HI_EXP, F8_W_LO_EXP, F8_X_LO_EXP = 6, 16, 10      # power-of-two scales of the e4m3 operands (csrc/conv1d_mfma.hip)
 
 

@@ -393,6 +393,39 @@ def main():
         h.remove()
         np.savez_compressed(os.path.join(GOLD, "fx_w2v2.npz"), **out)
         json.dump(shapes2, open(os.path.join(GOLD, "fx_shapes_w2v2.json"), "w"))
+    if want("w2v2_long"):
+        # the wav2vec2 tag on ONE 20 s utterance (999 frames: attention over more than one 256-key block, the long path of
+        # the GPU tests) through the reference's own Net: VQ indices, the margin of every decision, a channel subsample of the
+        # features, and every 4th sample of convert()'s waveform (F0 by the reference's own get_f0)
+        import torchaudio
+        from oracle import wav2vec2 as ow
+        torchaudio.models.wav2vec2.model._factory = ow.build_wav2vec2
+        name2 = "bn_tdnnf_wav2vec2_vq_48"
+        tag2 = "hifigan_" + name2 + "_v1"
+        net2 = build_reference_model(ref, name2)
+        st2, _ = synthetic.checkpoint(tag2)
+        net2.load_state_dict(st2["base_model_state_dict"], strict=True)
+        net2.eval()
+        n = 20 * 16000
+        seeds = [3 + 7 * j for j in range(4)]            # = tests/test_hip_robust.py: _long_batch([3], n)
+        w = torch.cat([synthetic.harm_batch([sd], 80000)[0] for sd in seeds])[:n].unsqueeze(0)
+        acts = {}
+        h = net2.bn_extractor.tdnnfs[2].bottleneck_func.quant.register_forward_hook(
+            lambda m, i, o: acts.update(idx=o[5].detach(), dist=o[4].detach()))
+        out = {"seeds": np.array(seeds), "n": np.array(n)}
+        with torch.no_grad():
+            bn = net2.get_bn(w)
+            out["idx"] = acts["idx"].reshape(1, -1).numpy()
+            srt = acts["dist"].sort(1)[0]
+            out["d1"] = srt[:, 0].reshape(1, -1).numpy()
+            out["d2"] = srt[:, 1].reshape(1, -1).numpy()
+            out["bn_sub"] = bn[:, :, ::16].numpy()
+            out["w2v2_last_sub"] = net2.bn_extractor.preprocessor.extract_features(w)[0][-1][:, :, ::16].numpy()
+            out["f0"] = net2.get_f0(w).numpy()
+            out["convert_every4"] = net2.convert(w.clone(), target=net2.spk[5]).numpy()[..., ::4]
+        h.remove()
+        np.savez_compressed(os.path.join(GOLD, "fx_w2v2_long.npz"), **out)
+        print("w2v2_long:", {k: v.shape for k, v in out.items()})
     print("fixtures written to", GOLD)
 
 
