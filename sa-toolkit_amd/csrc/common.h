@@ -114,6 +114,21 @@ __device__ __forceinline__ void lds_dma16(const uint4* lds_dst, const i32x4 rs, 
                : "memory");
 #endif
 }
+// the same for lanes 0-31 only (a half-filled piece: 512 bytes)
+__device__ __forceinline__ void lds_dma16_lo32(const uint4* lds_dst, const i32x4 rs, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+  unsigned keep;
+  unsigned long long ex;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xffffffff\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %3, %4, %5 offen lds\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(ex)
+      : "s"(la), "v"(voff), "s"(rs), "s"(soff)
+      : "memory");
+#endif
+}
+
 #endif
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1713,8 +1713,12 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
         SAT_REQUIRE(ring16_supports(a), "conv1d: x_wrap_channels needs the epilogue of the ring GEMM (up 1, split-f16 planes)");
         return launch_f16x3_ring16(a, d->B, s);
       }
-      if (g_k1_gemm >= 2 && a.co_pad % 128 == 0 && c256 * 8 <= c128 * 9)
+      if (g_k1_gemm >= 2 && a.co_pad % 128 == 0 && c256 * 8 <= c128 * 9) {
+        // more tiles than CUs (the 1024 -> 4096 layer: four per CU): the persistent walk of the same ring (gemm_walk16.hip)
+        if (g_k1_gemm >= 3 && gemm_walk_supports(a) && gemm_walk_wanted((long long)ceil_div(a.rows_g, 128) * ceil_div(a.T_q, 256) * d->B))
+          return launch_f16x3_gemm_walk(&a, 1, d->B, s);
         return g_k1_gemm >= 3 && ring16_supports(a) ? launch_f16x3_ring16(a, d->B, s) : launch_f16x3_ring(a, d->B, s);
+      }
       return launch_f16x3_k1(a, d->B, s);
     }
     SAT_REQUIRE(!a.k1_wrap, "conv1d: x_wrap_channels is only served by the 1x1 GEMM path (C_in %% 64 == 0, up 1, 31-bit slabs)");
@@ -1765,6 +1769,14 @@ extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const
       writes_read = writes_read || (wr0 && wr0 == (a[j].no_y ? nullptr : (const void*)a[j].y)) || (wr1 && wr1 == a[j].y16);
     }
   if (ring && n > 1) return launch_f16x3_convring_multi(a, n, !writes_read, d[0].B, (hipStream_t)stream);
+  // 1x1 convs of one shape on split planes (q | k | v of an attention layer): one launch of the persistent ring GEMM
+  bool walk = n > 1 && !writes_read && g_k1_gemm >= 3;
+  for (int j = 0; j < n && walk; ++j) {
+    const long long c256 = (long long)ceil_div(a[j].T_q, 256) * 256, c128 = (long long)ceil_div(a[j].T_q, 128) * 128;
+    walk = d[j].mode == SAT_CONV_F16X3 && d[j].groups == 1 && d[j].B == d[0].B && gemm_walk_supports(a[j]) && gemm_walk_same_shape(a[j], a[0]) &&
+           c256 * 8 <= c128 * 9;
+  }
+  if (walk) return launch_f16x3_gemm_walk(a, n, d[0].B, (hipStream_t)stream);
   for (int j = 0; j < n; ++j) {
     int st = sat_conv1d_f32(&d[j], x[j], w_packed[j], y[j], stream);
     if (st != SAT_OK) return st;
@@ -1879,6 +1891,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "pair32w")) { pair32w_set(value); return SAT_OK; }
   if (!strcmp(name, "pair64w")) { pair64w_set(value); return SAT_OK; }
   if (!strcmp(name, "convring")) { convring_set(value); return SAT_OK; }
+  if (!strcmp(name, "gemm_walk")) { gemm_walk_set(value); return SAT_OK; }
   if (!strcmp(name, "lean_balance")) { lean_set_balance(value); return SAT_OK; }
   if (!strcmp(name, "pair32s_waves")) { pair32s_set_waves(value); return SAT_OK; }
   if (!strcmp(name, "k1_gemm")) { g_k1_gemm = value < 0 ? 0 : value > 3 ? 3 : value; return SAT_OK; }

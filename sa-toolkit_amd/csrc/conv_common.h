@@ -624,6 +624,12 @@ bool convring_supports(const ConvArgs& a, int B);
 void convring_set(int v);
 int convring_debug_stamps(long long* buf);
 bool ring16_supports(const ConvArgs& a);
+// the persistent, multi-job form of that ring for plain Linear layers (gemm_walk16.hip)
+int launch_f16x3_gemm_walk(const ConvArgs* a, int njobs, int B, hipStream_t s);
+bool gemm_walk_supports(const ConvArgs& a);
+bool gemm_walk_same_shape(const ConvArgs& a, const ConvArgs& b);
+void gemm_walk_set(int v);
+bool gemm_walk_wanted(long long tiles);      // a single GEMM: more tiles than CUs (option "gemm_walk" + 2: always)
 
 
 }  // namespace sat

@@ -34,21 +34,6 @@ namespace sat {
 #define SAT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define SAT_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
 
-// lanes 0-31 only (the last, half-filled piece of an X row)
-__device__ __forceinline__ void lds_dma16_lo32(const uint4* lds_dst, const i32x4 rs, unsigned voff, unsigned soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
-  unsigned keep;
-  unsigned long long ex;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xffffffff\n\ts_nop 0\n\t"
-      "buffer_load_dwordx4 %3, %4, %5 offen lds\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep), "=&s"(ex)
-      : "s"(la), "v"(voff), "s"(rs), "s"(soff)
-      : "memory");
-#endif
-}
-
 // diagnostic instantiation (STAMP): waves 0 and 4 of every block record cycle counters (sat_convring_debug_stamps)
 constexpr int CR_STAMPS = 8;
 __device__ __forceinline__ long long cr_clock() {

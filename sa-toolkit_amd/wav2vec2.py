@@ -290,9 +290,11 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
                 # fused attention (csrc/w2v2.hip): Q and K leave their projections as split planes, the scores stay
                 # in registers, the context comes back as planes for the output projection
                 qs, ks = ops.split_like(B, 1024, T, x.device), ops.split_like(B, 1024, T, x.device)
-                ops.conv1d(h, L["q_w"], 1024, 1, bias=L["q_b"], mode=mm, x_split=hs, y_split=qs, y_split_slope=1.0, no_y=True)
-                ops.conv1d(h, L["k_w"], 1024, 1, bias=L["k_b"], mode=mm, x_split=hs, y_split=ks, y_split_slope=1.0, no_y=True)
-                ops.conv1d(h, L["v_w"], 1024, 1, bias=L["v_b"], out=v[:, :, :T], mode=mm, x_split=hs)
+                # q | k | v: three GEMMs of one shape on the same input — one launch of the persistent ring (sat_conv1d_multi_f32)
+                ops.conv1d_multi([
+                    (h, L["q_w"], 1024, 1, dict(bias=L["q_b"], mode=mm, x_split=hs, y_split=qs, y_split_slope=1.0, no_y=True)),
+                    (h, L["k_w"], 1024, 1, dict(bias=L["k_b"], mode=mm, x_split=hs, y_split=ks, y_split_slope=1.0, no_y=True)),
+                    (h, L["v_w"], 1024, 1, dict(bias=L["v_b"], out=v[:, :, :T], mode=mm, x_split=hs))])
                 o, os_ = ops.attention_fused(qs, ks, v, B, heads, hd, T, hd ** -0.5)
                 x = ops.conv1d(o, L["o_w"], 1024, 1, bias=L["o_b"], res=x, mode=mm, x_split=os_)
             else:

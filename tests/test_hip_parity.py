@@ -1344,3 +1344,55 @@ def test_generator_multi_branch_launches_give_the_same_bits(model):
         finally:
             check(lib().sat_hifigan_set_option(g._handle, b"multi_branch", g.multi_branch), "set_option")
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("B,T", [(3, 249), (2, 500), (5, 250)], ids=lambda v: str(v))
+def test_persistent_ring_gemm_gives_the_bits_of_the_ring_gemm(B, T):
+    """gemm_f16x3_walk16_kernel (csrc/gemm_walk16.hip: the Linear layers of the wav2vec2 encoder, reference
+    tdnnf_wav2vec2_vq.py:39-56 through torchaudio) — a block walks several tiles and up to three GEMMs of one shape (q | k | v)
+    with the loop of gemm_f16x3_ring16_kernel: the same bits as that kernel, for every epilogue it carries (bias; GELU + planes;
+    f32 residual; f32 output with a row pitch) and for rows / columns that do not fill a tile"""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    tp = (T + 63) // 64 * 64
+    for cin, cout, kind in ((512, 256, "plain"), (1024, 384, "gelu_planes"), (256, 128, "res"), (512, 256, "qkv"), (1024, 640, "qkv")):
+        x = _rand(B, cin, T, seed=1).to(DEV)
+        xs = ops.act_split(x, 1.0)
+        nj = 3 if kind == "qkv" else 1
+        ws = [packing.pack_conv_weight_f16x3(_rand(cout, cin, 1, seed=10 + j, scale=cin ** -0.5).to(DEV)) for j in range(nj)]
+        bs = [_rand(cout, seed=20 + j).to(DEV) for j in range(nj)]
+        res = _rand(B, cout, T, seed=30).to(DEV)
+
+        def run(multi):
+            if kind == "qkv":
+                qs, ks = ops.split_like(B, cout, T, DEV).zero_(), ops.split_like(B, cout, T, DEV).zero_()
+                v = torch.zeros(B, cout, tp, device=DEV)
+                jobs = [(x, ws[0], cout, 1, dict(bias=bs[0], mode=1, x_split=xs, y_split=qs, y_split_slope=1.0, no_y=True)),
+                        (x, ws[1], cout, 1, dict(bias=bs[1], mode=1, x_split=xs, y_split=ks, y_split_slope=1.0, no_y=True)),
+                        (x, ws[2], cout, 1, dict(bias=bs[2], mode=1, x_split=xs, out=v[:, :, :T]))]
+                if multi:
+                    ops.conv1d_multi(jobs)
+                else:
+                    for (xx, w, c, k, kw) in jobs:
+                        ops.conv1d(xx, w, c, k, **kw)
+                return (qs, ks, v)
+            if kind == "plain":
+                return (ops.conv1d(x, ws[0], cout, 1, bias=bs[0], mode=1, x_split=xs),)
+            if kind == "res":
+                return (ops.conv1d(x, ws[0], cout, 1, bias=bs[0], mode=1, x_split=xs, res=res),)
+            ys = ops.split_like(B, cout, T, DEV).zero_()
+            ops.conv1d(x, ws[0], cout, 1, bias=bs[0], gelu=True, mode=1, x_split=xs, y_split=ys, y_split_slope=1.0, no_y=True)
+            return (ys,)
+
+        with conv_option("gemm_walk", 0, 1):
+            old = run(False)
+            assert "ring16" in _lib.lib().sat_last_dispatch_name().decode()
+        with conv_option("gemm_walk", 3, 1):             # (+ 2: also for a single GEMM with fewer tiles than CUs)
+            new = run(True)
+            name = _lib.lib().sat_last_dispatch_name().decode()
+            assert "walk16" in name, (kind, name)
+        for a, bb in zip(old, new):
+            assert torch.equal(a, bb), (cin, cout, kind)
+        if kind == "plain":
+            ref = F.conv1d(x.double().cpu(), _rand(cout, cin, 1, seed=10, scale=cin ** -0.5).double(), bs[0].double().cpu())
+            assert (new[0].cpu().double() - ref).abs().max().item() < 3e-5

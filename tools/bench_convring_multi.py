@@ -97,3 +97,22 @@ if os.environ.get("STAMPS"):
             print(f"multi C {C} {name}: blocks {len(q)} tiles {q[0, 7]:.0f}  first-operand waits {q[:, 0].median():7.0f}  loops {q[:, 1].median():8.0f}  step-head waits {q[:, 2].median():8.0f}"
                   f"  epilogues {q[:, 3].median():7.0f}  kernel {q[:, 4].median():8.0f} cyc = {q[:, 5].median() / 100:6.1f} us at {clk:4.2f} GHz", flush=True)
     opt(0)
+
+# what the epilogues cost in the three-branch launch (diagnostic bit 4 of the option: no epilogue; results are wrong)
+if os.environ.get("EPI"):
+    for C, T in ((256, 1250), (128, 5000)):
+        x = torch.randn(B, C, T, device=dev)
+        xs = ops.act_split(x, 0.1)
+        ks = (3, 7, 11)
+        ws = [packing.pack_conv_weight_f16x3(torch.randn(C, C, k, device=dev) * (k * C) ** -0.5) for k in ks]
+        bs = [torch.randn(C, device=dev) for k in ks]
+        ys = [ops.split_like(B, C, T, dev) for _ in ks]
+        for kind in ("conv1", "conv2"):
+            jobs = [(x, ws[j], C, k, dict(bias=bs[j], dilation=1, pad_left=(k - 1) // 2, mode=1, x_split=xs, y_split_slope=0.1, y_split=ys[j], no_y=True,
+                                          **(dict(res_split=xs, res_split_slope=0.1) if kind == "conv2" else {}))) for j, k in enumerate(ks)]
+            t = {}
+            for bits, what in ((1, "full"), (5, "no epilogue"), (3, "no K loop")):
+                opt(bits)
+                t[what] = timed(lambda: ops.conv1d_multi(jobs))
+            print(f"C {C} {kind}: full {t['full']:6.1f} us   without the epilogues {t['no epilogue']:6.1f} us   without the K loops {t['no K loop']:6.1f} us", flush=True)
+    opt(1)
