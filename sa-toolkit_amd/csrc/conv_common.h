@@ -553,10 +553,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
       }
-      if (p.gelu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-      }
+      if (p.gelu) gelu_fast4(v);
       if (has_res && p.res_after) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += p.res_scale * rv[r];

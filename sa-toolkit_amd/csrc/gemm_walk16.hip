@@ -66,10 +66,7 @@ __device__ __forceinline__ void walk_epilogue_piece(const WalkJob& e, const Walk
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += e.res_scale * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, roff + r * r_rb, 0, 0));
   }
-  if (e.gelu) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-  }
+  if (e.gelu) gelu_fast4(v);
   if (e.y) {
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(e.y + (long long)b * e.y_bs), 0, (unsigned)(rows_g * e.y_cs * 4), 0x00020000);
     const int y_rb = (int)e.y_cs * 4;

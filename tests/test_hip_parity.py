@@ -643,8 +643,16 @@ def test_full_size_batch_properties(model, fbank_tag_state):
     assert x.shape == (32, 504, 250)
     full = model.hifigan(x)[0].clone()
     assert torch.equal(full.reshape(y.shape), y)
-    for sl in (slice(0, 1), slice(5, 9), slice(29, 32)):
-        assert torch.equal(model.hifigan(x[sl].contiguous())[0], full[sl])
+    # a slice of the batch: the kernels treat utterances independently, so with ONE dispatch the bits are those of the full batch.
+    # By default a batch of a few utterances leaves the thick stages on the register-staged tiles (too few tiles for the one-
+    # block-per-CU ring conv, csrc/conv_ring16.hip): another accumulation order, agreement to f32 rounding
+    with conv_option("convring", 33, 1):                 # (+ 32: the ring conv whatever the number of tiles)
+        full_ring = model.hifigan(x)[0].clone()
+        assert torch.equal(full_ring, full)
+        for sl in (slice(0, 1), slice(5, 9), slice(29, 32)):
+            assert torch.equal(model.hifigan(x[sl].contiguous())[0], full[sl])
+    for sl in (slice(0, 1), slice(5, 9)):
+        assert rms((model.hifigan(x[sl].contiguous())[0] - full[sl]).cpu().numpy()) < 5e-7
     _, gen_sd = oconv.split_state_dict(fbank_tag_state[0]["base_model_state_dict"])
     ref = ohg.generator(gen_sd, x[17:18].cpu())
     err = rms((full[17:18].cpu() - ref).numpy())

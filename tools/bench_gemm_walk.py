@@ -77,3 +77,22 @@ for B, T in ((32, 249), (3, 100), (2, 257)):
         fl = 2.0 * B * T * cin * cout * nj
         print(f"B {B:2d} T {T:3d} {cin:4d} -> {cout:4d} {kind:12s}: {n0[:28]:28s} {t0:7.1f} us ({fl / t0 / 1e6:4.0f} TF/s)   {n1[:28]:28s} {t1:7.1f} us ({fl / t1 / 1e6:4.0f} TF/s)   same bits: {same}", flush=True)
 opt(1)
+
+# what the epilogues cost (diagnostic option bits: + 8 no K loop, + 16 no epilogue; results are wrong)
+if os.environ.get("EPI"):
+    B, T = 32, 249
+    for cin, cout, kind in ((1024, 4096, "gelu_planes"), (1024, 4096, "planes"), (1024, 1024, "qkv")):
+        x = torch.randn(B, cin, T, device=dev)
+        xs = ops.act_split(x, 1.0)
+        nj = 3 if kind == "qkv" else 1
+        ws = [packing.pack_conv_weight_f16x3(torch.randn(cout, cin, 1, device=dev) * cin ** -0.5) for _ in range(nj)]
+        bs = [torch.randn(cout, device=dev) for _ in range(nj)]
+        ys = [ops.split_like(B, cout, T, dev) for _ in range(nj)]
+        jobs = [(x, ws[j], cout, 1, dict(bias=bs[j], mode=1, x_split=xs, y_split=ys[j], y_split_slope=1.0, no_y=True, gelu=(kind == "gelu_planes"))) for j in range(nj)]
+        f = (lambda: ops.conv1d_multi(jobs)) if nj > 1 else (lambda: ops.conv1d(*jobs[0][:4], **jobs[0][4]))
+        t = {}
+        for bits, what in ((3, "full"), (3 + 16, "no epilogue"), (3 + 8, "no K loop")):
+            opt(bits)
+            t[what] = timed(f)
+        print(f"{cin} -> {cout} {kind:12s}: full {t['full']:6.1f} us   without the epilogues {t['no epilogue']:6.1f} us   without the K loops {t['no K loop']:6.1f} us", flush=True)
+    opt(1)
