@@ -377,7 +377,7 @@ def roofline_generator(model, dev, reps):
     peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
     hbm = GEN_BYTES_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
     traffic, note = None, None
-    for name in ("r03_generator_traffic.json", "r02_generator_traffic.json", "r01o_generator_traffic.json"):
+    for name in ("r04_generator_traffic.json", "r03_generator_traffic.json", "r02_generator_traffic.json", "r01o_generator_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))["per_forward"]
@@ -425,13 +425,16 @@ def roofline_w2v2(model, dev, reps):
     model_bytes = W2V2_ACT_BYTES_PER_UTT * BATCH + W2V2_WEIGHT_BYTES
     hbm = model_bytes / (ext_ms * 1e-3) / 1e12
     traffic, note = None, None
-    tpath = os.path.join(ROOT, "profiles", "r03_w2v2_traffic.json")
-    if os.path.exists(tpath):
+    for tname in ("r04_w2v2_traffic.json", "r03_w2v2_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tpath):
+            continue
         tj = json.load(open(tpath))["per_forward"]
         traffic = (tj["fetch_GB_doubled"] + tj["write_GB"]) * 1e9
         note = (f"HBM bytes per get_bn() of a batch of 32, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                f"(profiles/r03_w2v2_traffic.json): fetch {tj['fetch_GB_doubled']} GB (FETCH_SIZE x 2, the gfx950 wide-load "
+                f"(profiles/{tname}): fetch {tj['fetch_GB_doubled']} GB (FETCH_SIZE x 2, the gfx950 wide-load "
                 f"correction) + write {tj['write_GB']} GB; per-layer streaming model {model_bytes / 1e9:.2f} GB")
+        break
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note,
             "hbm_model": {"achieved_TBps": round(hbm, 3), "peak_TBps": PEAK_HBM_TBS, "frac": round(hbm / PEAK_HBM_TBS, 4),

@@ -231,7 +231,15 @@ int sat_upsample2_f16x3(const void* x_split, const void* w_packed, const float* 
  * bits); "pair32s" (default 1), "pair32w" (1), "pair64w" (0) send sat_resblock_pair_scaled_f16x3 at C = 32 with 3 taps,
  * C = 32 with 7 / 11 taps and C = 64 with 3 taps (planes in, residual from the planes, dilation <= 5) through the streaming /
  * wave-specialised kernels of csrc/pair32s.hip (agree with the general fused step to f32 rounding of the accumulation);
- * "pair32s_waves" (8 / 4) picks that file's block shape at 3 taps.  Unknown names return SAT_ERR_INVALID. */
+ * "pair32s_waves" (8 / 4) picks that file's block shape at 3 taps.  Round 4: "convring" (0 / 1 default; + 32: whatever the number
+ * of tiles) sends k-tap convs on split planes with C_out > 64, C_in % 32 == 0, k >= 3 and the generator's ResBlock epilogues (bias,
+ * residual from planes, MRF accumulation; no folded BatchNorm / ReLU / GELU) through the LDS-DMA ring kernel on the 16x16x32 MFMA
+ * shape (csrc/conv_ring16.hip: 256 x 160 / 128 x 320 tiles, one 8-wave block per CU) when they fill three quarters of the CUs —
+ * K = 32 per instruction associates differently from the register-staged tiles: agreement to f32 rounding of the accumulation;
+ * "gemm_walk" (0 / 1 default; + 2: also single GEMMs with no more tiles than CUs) sends 1x1 convs of k1_gemm = 3 with a plain
+ * Linear epilogue (bias, f32 residual, GELU, f32 / plane stores) through the persistent form of that ring (csrc/gemm_walk16.hip)
+ * when a launch holds more tiles than CUs or several GEMMs (sat_conv1d_multi_f32) — the bits of k1_gemm = 3.
+ * Unknown names return SAT_ERR_INVALID. */
 int sat_conv_set_option(const char* name, int value);
 /* f32 [B][C][T] -> split planes of lrelu(x, slope) in `format` (SAT_SPLIT_*); C % 16 == 0 */
 int sat_act_split_f32(const float* x, void* x_split, int B, int C, int T, float slope, int format, void* stream);
@@ -265,7 +273,9 @@ int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, float* y, void
 void sat_hifigan_destroy(sat_hifigan* h);
 /* options: "fuse_pairs" (default 1): run the conv pairs of stages with C <= 32 as one fused kernel; "fuse_pair64" (bit mask,
  * default 3), "fuse_mrf" (default 1: whole MRF block of the C = 16 stage in one launch), "mrf_exact" (default 0),
- * "ups2" (default 1: the two thin upsamplers on sat_upsample2_f16x3), "split_acts", "planes_residual", "branch_streams" */
+ * "ups2" (default 1: the two thin upsamplers on sat_upsample2_f16x3), "multi_branch" (default 1: on the stages with C > 64 the i-th
+ * conv of all MRF branches as ONE sat_conv1d_multi_f32 call — 6 launches per stage instead of 18, same bits), "split_acts",
+ * "planes_residual", "branch_streams" */
 int sat_hifigan_set_option(sat_hifigan* h, const char* name, int value);
 
 /* final stage alone: leaky_relu(0.01) -> ReflectionPad1d((1,0)) -> Conv1d(C,1,7,pad 3) -> tanh

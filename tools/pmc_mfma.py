@@ -34,7 +34,7 @@ def main():
     rows, tot_busy, tot_cyc, tot_ms = [], 0.0, 0.0, 0.0
     for k in sorted(a, key=lambda k: -dur[k]):
         v, w = a[k], b.get(k, {})
-        if not any(s in k[0] for s in ("conv1d_", "resblock_pair", "convpost", "act_split", "gemm_f16x3", "attention", "layernorm", "w2v2_")):
+        if not any(s in k[0] for s in ("conv1d_", "resblock_pair", "convpost", "act_split", "gemm_f16x3", "attention", "layernorm", "w2v2_", "mrf16", "pairw", "pair32s", "ups2")):
             continue
         cyc = v["GRBM_GUI_ACTIVE"] / 8
         wc = max(w.get("SQ_WAVE_CYCLES", 0.0), 1.0)
