@@ -203,8 +203,10 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
 template <int WR, bool STAMP = false>
 __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingArgs A, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-  constexpr int WC = 8 / WR, MT = 4, NT = 5, ROWS = 64 * WR, COLS = 80 * WC;
-  constexpr int XW = WR == 4 ? 224 : 384;               // columns of an X tile (>= COLS + (ksize - 1) * dilation)
+  // WR = 4: 256 x 160, WR = 2: 128 x 320 (wave tile 64 x 80); WR = 1: 64 x 384 (wave tile 64 x 48: the 64-channel stage, whose X
+  // tiles hold BOTH chunk pairs of its K)
+  constexpr int WC = 8 / WR, MT = 4, NT = WR == 1 ? 3 : 5, ROWS = 64 * WR, COLS = 16 * NT * WC;
+  constexpr int XW = WR == 4 ? 224 : WR == 2 ? 384 : 448;       // columns of an X tile (>= COLS + (ksize - 1) * dilation)
   constexpr int XP = (XW + 63) / 64;                     // DMA pieces per X row; the last one half-filled when XW % 64 == 32
   constexpr bool XHALF = XW % 64 != 0;
   constexpr int X_UNITS = 8 * XW, W_UNITS = 8 * ROWS, W0 = 2 * X_UNITS;     // 16-byte units
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wave >> 2, idx = wave & 3;
-  const int wr = WR == 4 ? idx : (idx & 1), wc = WR == 4 ? half : ((idx >> 1) + 2 * half);
+  const int wr = WR == 4 ? idx : WR == 2 ? (idx & 1) : 0, wc = WR == 4 ? half : WR == 2 ? ((idx >> 1) + 2 * half) : (idx + 4 * half);
   const int njobs = A.njobs;
   const int nreg = (A.n_vb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // regions of this block
   const int ntiles = nreg * njobs;
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
 
   // fragment addresses (units): lane (li, lg) reads chunk lg >> 1, half lg & 1; lo planes 2 segments further
   const int a_lane = (lg >> 1) * 4 * ROWS + (lg & 1) * ROWS + wr * 64 + li;
-  const int b_lane = (lg >> 1) * 4 * XW + (lg & 1) * XW + wc * 80 + li;
+  const int b_lane = (lg >> 1) * 4 * XW + (lg & 1) * XW + wc * (16 * NT) + li;
   h8 fa[2][MT][2], fb[2][2];
   auto read_a = [&](h8 (&dst)[2], const uint4* wb, int m) __attribute__((always_inline)) {
     dst[0] = __builtin_bit_cast(h8, wb[m * 16]);
@@ -306,7 +308,8 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
   auto body = [&](auto cur, auto late_c, auto more_c) __attribute__((always_inline)) {
     constexpr int CUR = decltype(cur)::value;
     constexpr bool LATE = decltype(late_c)::value, MORE = decltype(more_c)::value;
-    constexpr int N_HAND = LATE ? 2 : 0;     // the DMA issue stands in front of this column's MFMAs
+    constexpr int N_HAND = LATE ? NT / 2 : 0;     // the DMA issue stands in front of this column's MFMAs
+    constexpr int AR = (MT + NT - 2) / (NT - 1);   // rows of the next step's A fragments read per column (columns 1 .. NT - 1)
     if constexpr (MORE) {
       long long w0 = 0;
       if constexpr (STAMP) w0 = cr_clock();
@@ -339,7 +342,10 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
         if (n + 1 < NT) read_b(fb[(n + 1 + CUR) & 1], xcur, n + 1);
         else if constexpr (MORE) read_b(fb[(NT + CUR) & 1], xnext, 0);
         if constexpr (MORE) {
-          if (n >= 1) read_a(fa[CUR ^ 1][n - 1], wnext, n - 1);
+          if (n >= 1) {
+#pragma unroll
+            for (int m2 = (n - 1) * AR; m2 < n * AR && m2 < MT; ++m2) read_a(fa[CUR ^ 1][m2], wnext, m2);
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -425,7 +431,7 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     mfma16_drain();
     if (!(A.diag & 4)) {
       const RingJob ej = A.job[done.j];
-      ring_epilogue<MT, NT>(ej, A, acc, done.b, done.co_b + wr * 64, done.q_b + wc * 80, li, lg);
+      ring_epilogue<MT, NT>(ej, A, acc, done.b, done.co_b + wr * 64, done.q_b + wc * (16 * NT), li, lg);
     }
     if constexpr (STAMP) st_epi += cr_clock() - p0;
     if (!more) break;
@@ -475,12 +481,15 @@ static int cu_count() {
 bool convring_supports(const ConvArgs& a, int B) {
   if (!(g_convring & 1)) return false;
   if (!(a.x16 && !a.f8 && !a.y16_f8 && !a.poly_planes && !a.k1_wrap && a.fast_epi && a.up == 1 && a.stride == 1)) return false;
+  // (rows <= 64: the kernel has a 64 x 384 layout, WR = 1, whose X tiles hold both chunk pairs of the 64-channel stage — measured SLOWER
+  // than the register-staged tile there, 183-189 against 150 us at 11 taps: 6.6 tiles per block with 112 KB of X each; not dispatched)
   if (!epilogue16_supports(a) || a.ksize < 3 || a.cin_g % 32 != 0 || a.rows_g <= 64) return false;
   // what ring_epilogue carries: bias, residual from planes (scale 1, before the activation), accumulation, f32 / plane stores
   if (a.ch_scale || a.relu || a.gelu || a.res || a.res_after || !a.bias || (a.res16 && a.res_scale != 1.f) || (a.accum && a.no_y)) return false;
   const int halo = (a.ksize - 1) * a.dil;
-  if (a.rows_g > 128 ? halo > 224 - 160 : halo > 384 - 320) return false;
-  const long long tiles = a.rows_g > 128 ? (long long)ceil_div(a.rows_g, 256) * ceil_div(a.T_q, 160) * B : (long long)ceil_div(a.T_q, 320) * B;
+  if (halo > 64) return false;                     // (X tiles: 160 + 64, 320 + 64, 384 + 64 columns)
+  const long long tiles = a.rows_g > 128 ? (long long)ceil_div(a.rows_g, 256) * ceil_div(a.T_q, 160) * B
+                          : a.rows_g > 64 ? (long long)ceil_div(a.T_q, 320) * B : (long long)ceil_div(a.T_q, 384) * B;
   return (g_convring & 32) || tiles * 4 >= (long long)cu_count() * 3;
 }
 
@@ -492,7 +501,7 @@ bool convring_same_shape(const ConvArgs& a, const ConvArgs& b) {
 
 template <int WR>
 static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s) {
-  constexpr int WC = 8 / WR, ROWS = 64 * WR, COLS = 80 * WC, XW = WR == 4 ? 224 : 384;
+  constexpr int WC = 8 / WR, NT = WR == 1 ? 3 : 5, ROWS = 64 * WR, COLS = 16 * NT * WC, XW = WR == 4 ? 224 : WR == 2 ? 384 : 448;
   RingArgs A{};
   for (int j = 0; j < njobs; ++j) {
     RingJob& r = A.job[j];
