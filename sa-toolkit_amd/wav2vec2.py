@@ -159,6 +159,8 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
     #: product; with it also the fused attention kernel and the positional conv as chained 11-tap pieces) or "f32"
     #: (exact f32 MFMA everywhere, attention as scores GEMM + softmax + apply GEMM).
     w2v2_precision = os.environ.get("SATOOLS_AMD_W2V2_PRECISION", "f16x3")
+    #: the transformer's residual stream on a row pitch of round_up(T, 64) frames instead of T (same values; aligned 128-byte rows)
+    residual_pitch = int(os.environ.get("SATOOLS_AMD_W2V2_PITCH", "1"))
     #: the feature extractor's stride-2 3-tap convs as one wrapped 1x1 product on the ring GEMM (0: two-tap polyphase conv)
     fe_wrapped_gemm = int(os.environ.get("SATOOLS_AMD_W2V2_FE_WRAPPED_GEMM", "1"))
 
@@ -283,6 +285,15 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         # stage): 182 -> ~60 us per layer
         sp = (lambda t: ops.act_split(t, 1.0)) if planes else (lambda t: None)
         ln = (lambda t, p: ops.layernorm_ch(t, *p, planes=True, want_f32=False)) if planes else (lambda t, p: (ops.layernorm_ch(t, *p), None))
+        # The residual stream x lives in two buffers of row pitch tp (a multiple of 64 frames: 249 -> 256), written alternately by the
+        # two residual GEMMs of a layer: with the natural pitch of 249 floats no row starts on a 128-byte line, and every 128-byte
+        # piece the LayerNorm and the GEMM epilogues read or write straddles two (SATOOLS_AMD_W2V2_PITCH=0: the contiguous form)
+        pitched = planes and self.residual_pitch
+        if pitched:
+            xbuf = [torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device) for _ in range(2)]
+            xbuf[0][:, :, :T].copy_(x)
+            x = xbuf[0][:, :, :T]
+        nb = 1
         for L in W["layers"]:
             h, hs = ln(x, L["ln1"])
             v = torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device)
@@ -296,7 +307,8 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
                     (h, L["k_w"], 1024, 1, dict(bias=L["k_b"], mode=mm, x_split=hs, y_split=ks, y_split_slope=1.0, no_y=True)),
                     (h, L["v_w"], 1024, 1, dict(bias=L["v_b"], out=v[:, :, :T], mode=mm, x_split=hs))])
                 o, os_ = ops.attention_fused(qs, ks, v, B, heads, hd, T, hd ** -0.5)
-                x = ops.conv1d(o, L["o_w"], 1024, 1, bias=L["o_b"], res=x, mode=mm, x_split=os_)
+                x = ops.conv1d(o, L["o_w"], 1024, 1, bias=L["o_b"], res=x, mode=mm, x_split=os_, out=xbuf[nb][:, :, :T] if pitched else None)
+                nb ^= 1
             else:
                 q = torch.empty(B, 1024, tp, dtype=torch.float32, device=x.device)
                 k = torch.empty_like(q)
@@ -315,7 +327,8 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
                 fs = ops.split_like(B, 4096, T, x.device)
                 f = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True, mode=mm, x_split=hs, y_split=fs,
                                y_split_slope=1.0, no_y=True)                        # f: shape carrier only
-                x = ops.conv1d(f, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm, x_split=fs)
+                x = ops.conv1d(f, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm, x_split=fs, out=xbuf[nb][:, :, :T] if pitched else None)
+                nb ^= 1
             else:
                 h = ops.conv1d(h, L["f1_w"], 4096, 1, bias=L["f1_b"], gelu=True, mode=mm)
                 x = ops.conv1d(h, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm)

@@ -32,6 +32,18 @@ if len(sys.argv) > 1 and sys.argv[1] == "ab":
     for opt in (1, 2, 3):
         print(f"k1_gemm={opt}: get_bn ms per batch, five rounds: " + " ".join(f"{v:.2f}" for v in res[opt]) + f"   median {sorted(res[opt])[2]:.2f}")
     _lib.check(_lib.lib().sat_conv_set_option(b"k1_gemm", 3), "set_option")
+elif len(sys.argv) > 1 and sys.argv[1] == "pitch":
+    # interleaved A/B of the residual-stream pitch (wav2vec2.py: residual_pitch)
+    res, outs = {0: [], 1: []}, {}
+    ext = model.bn_extractor
+    for rnd in range(5):
+        for v in (0, 1):
+            ext.residual_pitch = v
+            res[v].append(run(5))
+            outs[v] = model.get_bn(wav).clone()
+    for v in (0, 1):
+        print(f"residual_pitch={v}: get_bn ms per batch, five rounds: " + " ".join(f"{t:.2f}" for t in res[v]) + f"   median {sorted(res[v])[2]:.2f}")
+    print("outputs bit-identical:", bool(torch.equal(outs[0], outs[1])))
 elif len(sys.argv) > 2 and sys.argv[1] == "opt":
     # interleaved A/B of a sat_conv_set_option switch: python tools/w2v2_only.py opt <name> <value_a> <value_b>
     name, va, vb = sys.argv[2].encode(), int(sys.argv[3]), int(sys.argv[4])
