@@ -157,7 +157,22 @@ typedef struct {
                               largest |w| sits near 2^10: lo = f16(w - hi) is then a NORMAL f16 for every weight within
                               2^-13 of the largest, i.e. hi + lo carries 22 significand bits whatever the layer's scale) and
                               the accumulator is multiplied by w_descale = 2^-e before the bias — exact.  0 means 1 */
+  int32_t up_grouped;      /* up = 4, SAT_CONV_F16X3, planes in and planes out (x_split, y_split, no_y): the rows of the polyphase weight
+                              are ordered (16-channel group, phase, channel) — row (c / 16 * 4 + r) * 16 + c % 16 produces phase r of
+                              channel c — instead of c * up + r (packing.convtranspose_as_phase_conv(..., grouped=True)): the four
+                              16-row strips of a wave tile of the LDS-DMA ring (conv_ring16.hip) are then the four output phases of
+                              one channel group and go to the planes without a transposition.  C_out % 16 == 0, C_out * 4 > 128,
+                              C_in % 64 == 0, three tap slots (sat_upsample_grouped_supported); served by that kernel only */
+  uint32_t up_zero_taps;   /* with up_grouped: bit (slot * 4 + r) set = the weights of tap slot `slot` are all zero for phase r
+                              (sat_convtranspose_zero_taps: a k = 8, stride-4 layer has 2 taps per phase in 3 slots, mask 0x30c — the
+                              pattern the kernel has an instantiation without those products for).  A promise about the WEIGHTS: a
+                              mask naming non-zero weights gives wrong results.  0 (or another pattern) = multiply everything */
 } sat_conv1d_desc;
+
+/* the shapes sat_conv1d_desc.up_grouped serves (1 / 0), and the zero (tap slot, phase) pairs of ConvTranspose1d(k, stride u, padding
+ * pad) seen as a polyphase conv (satools/satools/hifigan/archi.py:47-59) as the mask sat_conv1d_desc.up_zero_taps takes (u <= 4) */
+int sat_upsample_grouped_supported(int C_in, int C_out, int ksize, int stride, int padding);
+uint32_t sat_convtranspose_zero_taps(int ksize, int stride, int padding);
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
                    void* stream);

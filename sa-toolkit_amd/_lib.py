@@ -41,6 +41,7 @@ class ConvDesc(C.Structure):
         ("relu_first", C.c_int32),
         ("x_wrap_channels", C.c_int32),
         ("w_descale", C.c_float),
+        ("up_grouped", C.c_int32), ("up_zero_taps", C.c_uint32),
     ]
 
 
@@ -65,6 +66,8 @@ _PROTOS = {
     "sat_conv1d_multi_f32": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "sat_conv1d_packed_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sat_convtranspose_phase_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sat_upsample_grouped_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sat_convtranspose_zero_taps": (C.c_uint32, [C.c_int, C.c_int, C.c_int]),
     "sat_hifigan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sat_hifigan_num_convs": (C.c_int, [C.c_void_p]),

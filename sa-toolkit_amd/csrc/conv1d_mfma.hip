@@ -1590,6 +1590,36 @@ extern "C" int sat_conv1d_packed_dims(int C_in, int C_out, int up, int groups, i
   return SAT_OK;
 }
 
+extern "C" int sat_upsample_grouped_supported(int C_in, int C_out, int ksize, int stride, int padding) {
+  if (stride != 4 || C_in <= 0 || C_out <= 0 || ksize < stride || padding < 0) return 0;
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int r = 0; r < stride; ++r)
+    for (int dl = -ksize; dl <= ksize; ++dl) {
+      const int j = r + padding - stride * dl;
+      if (j >= 0 && j < ksize) lo = std::min(lo, dl), hi = std::max(hi, dl);
+    }
+  const int slots = hi - lo + 1;
+  return C_in % 64 == 0 && C_out % 16 == 0 && C_out * 4 > 128 && slots == 3;
+}
+
+extern "C" uint32_t sat_convtranspose_zero_taps(int ksize, int stride, int padding) {
+  if (stride < 1 || stride > 4 || ksize < 1 || padding < 0) return 0;
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int r = 0; r < stride; ++r)
+    for (int dl = -ksize; dl <= ksize; ++dl) {
+      const int j = r + padding - stride * dl;
+      if (j >= 0 && j < ksize) lo = std::min(lo, dl), hi = std::max(hi, dl);
+    }
+  if (hi - lo + 1 > 8) return 0;
+  uint32_t mask = 0;
+  for (int slot = 0; slot <= hi - lo; ++slot)
+    for (int r = 0; r < stride; ++r) {
+      const int j = r + padding - stride * (slot + lo);
+      if (j < 0 || j >= ksize) mask |= 1u << (slot * 4 + r);
+    }
+  return mask;
+}
+
 // descriptor -> launch arguments (every check of sat_conv1d_f32 but the choice of the kernel)
 static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y, ConvArgs& a) {
   SAT_REQUIRE(d && w_packed && (x || d->x_split) && (y || (d->no_y && d->y_split)), "conv1d: null pointer");
@@ -1598,6 +1628,7 @@ static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* 
               "conv1d: bad ksize/dilation/stride/up/groups");
   SAT_REQUIRE(d->C_in % d->groups == 0 && d->C_out % d->groups == 0, "conv1d: groups must divide channels");
   SAT_REQUIRE(d->up == 1 || d->stride == 1, "conv1d: polyphase output requires stride 1");
+  SAT_REQUIRE(!d->up_grouped || (d->mode == SAT_CONV_F16X3 && d->up == 4), "conv1d: up_grouped is a SAT_CONV_F16X3 layout of up = 4");
   a = ConvArgs{};
   a.x = x;
   a.w = (const float*)w_packed;
@@ -1674,7 +1705,16 @@ static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* 
       a.res16 = d->res_split;
       a.res16_inv = 1.0f / d->res_split_slope;
     }
-    if (d->up > 1 && (a.y16 || a.no_y)) {
+    if (d->up_grouped) {
+      // polyphase upsampler of stride 4 with its rows grouped by phase: the LDS-DMA ring writes the planes itself
+      a.up_grouped = 1;
+      a.up_zero_taps = d->up_zero_taps;
+      a.y = (float*)a.y16;
+      SAT_REQUIRE(d->mode == SAT_CONV_F16X3 && d->groups == 1 && !d->res && !d->res_split && !d->accum && !d->relu && !d->gelu && !d->ch_scale &&
+                      (long long)a.rows_g * a.T_q * 4 < (1LL << 31) && convring_ups_supports(a),
+                  "conv1d(f16x3): up_grouped needs up 4, split planes in and out with no_y, C_in %% 64 == 0, C_out %% 16 == 0, C_out * 4 > 128, "
+                  "3 tap slots, a bias and a plain epilogue");
+    } else if (d->up > 1 && (a.y16 || a.no_y)) {
       // polyphase upsampler straight to planes (LDS-transposed epilogue)
       const int co_b = a.rows_g > 32 ? 64 : 32;
       SAT_REQUIRE(a.x16 && a.y16 && a.no_y && !a.f8 && !a.y16_f8 && d->groups == 1 && co_b % (8 * d->up) == 0 && a.cout_g % 16 == 0 &&
@@ -1722,6 +1762,7 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
       return launch_f16x3_k1(a, d->B, s);
     }
     SAT_REQUIRE(!a.k1_wrap, "conv1d: x_wrap_channels is only served by the 1x1 GEMM path (C_in %% 64 == 0, up 1, 31-bit slabs)");
+    if (a.up_grouped) return launch_f16x3_convring_ups(a, d->B, s);
     // the generator's resblock convs at C >= 128: the LDS-DMA ring on the 16x16x32 shape (conv_ring16.hip)
     if (d->groups == 1 && convring_supports(a, d->B)) return launch_f16x3_convring(a, d->B, s);
     // few blocks (TDNNF linearB: 128 rows x 250 frames x 32 utterances = 64 tiles of 64 x 256 on 256 CUs): half-width

@@ -58,6 +58,8 @@ struct ConvArgs {
   float res16_inv;       // 1 / slope
   int f8;                // planes kernels: cross terms hi*lo + lo*hi on the block-scaled e4m3 MFMA
   int poly_planes;       // up > 1, planes only: the LDS-transposed polyphase epilogue
+  int up_grouped;        // up = 4, rows (16-channel group, phase, channel): conv_ring16.hip's upsampler form
+  unsigned up_zero_taps; // its all-zero (tap slot, phase) pairs, bit slot * 4 + phase
   int y16_f8;            // output planes carry (hi f16 | e4m3(hi) | e4m3(lo * 2^10)) instead of (hi f16 | lo f16)
   int k1_wrap;           // ring16 GEMM: K chunks >= k1_wrap read plane chunk (c - k1_wrap) one position later; 0 = none
   int pp_tiles_t, pp_total, pp_per_xcd, pp_nslots;   // persistent pair kernel: tiles per utterance / in all / per XCD, blocks per XCD
@@ -615,6 +617,8 @@ bool lean_supports(const ConvArgs& a);
 int launch_f16x3_ring16(const ConvArgs& a, int B, hipStream_t s);   // the same ring on v_mfma_f32_16x16x32_f16
 // k-tap convs at C >= 128 as an LDS-DMA ring on the 16x16x32 shape, 256 x 160 / 128 x 320 tiles (conv_ring16.hip)
 int launch_f16x3_convring(const ConvArgs& a, int B, hipStream_t s);
+int launch_f16x3_convring_ups(const ConvArgs& a, int B, hipStream_t s);      // ConvTranspose1d(stride 4), rows grouped by phase
+bool convring_ups_supports(const ConvArgs& a);
 int launch_f16x3_convring_multi(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s);   // up to three convs of one shape in one launch
 bool convring_same_shape(const ConvArgs& a, const ConvArgs& b);
 bool convring_supports(const ConvArgs& a, int B);

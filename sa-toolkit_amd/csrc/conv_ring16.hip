@@ -195,16 +195,93 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
   }
 }
 
+// ---- the upsampler form: a ConvTranspose1d of stride 4 as a polyphase conv whose rows are ordered (16-channel group, phase, channel) —
+// the four 16-row strips of a wave's 64 rows are the four output phases of ONE channel group, strip m belongs at the output times
+// 4 q + m.  Planes only (bias, leaky-relu, hi / lo split as in ring_epilogue), no residual, no accumulation.
+// A lane holds column q = q_w + 16 n + li of every strip: stored as they are, the 16-byte units of one instruction would lie 64 bytes
+// apart (measured: the epilogue alone 44 us for 82 MB).  The four strips are TRANSPOSED inside every quad of lanes first (two
+// butterfly stages of v_cndmask with a DPP quad_perm source per dword): store j of lane l then carries phase l & 3 of column
+// (l & ~3) + j — the four lanes of a quad write 64 contiguous bytes.
+template <int NT>
+__device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingArgs& A, f32x4 (&acc)[4][NT], int b, int co_w, int q_w, int li, int lg) {
+  const unsigned OOB = 0x80000000u;
+  const int rows_g = A.rows_g, T_q = A.T_q;
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)e.bias, 0, (unsigned)(rows_g), 0x00020000);      // rows_g / 4 channels
+  const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc((char*)e.y16 + (long long)b * rows_g * T_q * 4, 0, (unsigned)(rows_g * T_q * 4), 0x00020000);
+  const float descale = e.w_descale, slope = e.y16_slope;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  float bi[4];                                          // channel (co_w / 64) * 16 + 4 lg + r, whatever the phase
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, ((co_w >> 2) + 4 * lg + r) * 4, 0, 0));
+  if (co_w >= rows_g) return;                           // wave-uniform: padding rows of the block's tile
+  const bool l0 = li & 1, l1 = li & 2;
+  // unit index of (channel group, plane of this lane after the hi / lo exchange) at output time 0
+  const int plane_base = ((co_w >> 6) * 4 + (lg >> 1) + 2 * (lg & 1)) * (4 * T_q);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    u32x4 un[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float u[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = __builtin_fmaf(acc[m][n][r], descale, bi[r]);
+        u[r] = v > 0.f ? v : v * slope;
+      }
+      const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
+      const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
+      const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
+      const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+      // (ring_epilogue: after swap(hi, lo) per word the lanes of even lg hold the whole hi unit, their partners lg ^ 1 the whole lo unit)
+      const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, l01), false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, l23), false, false);
+      un[m] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+    }
+    // 4 x 4 transposition (strip m, lane l of the quad) -> (store j, lane l): first strip bit 0 against lane bit 0, then bit 1 against bit 1
+    u32x4 p[4], t[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned ev = un[2 * h][w], od = un[2 * h + 1][w];
+        const unsigned ev_x = (unsigned)__builtin_amdgcn_mov_dpp((int)ev, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]: lane ^ 1
+        const unsigned od_x = (unsigned)__builtin_amdgcn_mov_dpp((int)od, 0xB1, 0xF, 0xF, true);
+        p[2 * h][w] = l0 ? od_x : ev;
+        p[2 * h + 1][w] = l0 ? od : ev_x;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned lo_ = p[h][w], hi_ = p[h + 2][w];
+        const unsigned lo_x = (unsigned)__builtin_amdgcn_mov_dpp((int)lo_, 0x4E, 0xF, 0xF, true);     // quad_perm [2, 3, 0, 1]: lane ^ 2
+        const unsigned hi_x = (unsigned)__builtin_amdgcn_mov_dpp((int)hi_, 0x4E, 0xF, 0xF, true);
+        t[h][w] = l1 ? hi_x : lo_;
+        t[h + 2][w] = l1 ? hi_ : lo_x;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = q_w + n * 16 + (li & ~3) + j;
+      const unsigned off = q < T_q ? (unsigned)((plane_base + 4 * q + (li & 3)) * 16) : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(t[j], y16rs, off, 0, 0);
+    }
+  }
+}
+
 // A block walks the tiles (region, job) of its regions vb = blockIdx.x, + gridDim.x, ...: the next tile's first X tile and
 // W slots are requested BEFORE the epilogue of the current one (the rings are free behind the barrier that ends a K
 // loop), and with `rotate` neighbouring blocks take the jobs in different orders, so that their epilogues — 164 KB of
 // output per tile — do not reach HBM as one burst of every CU at once (measured on the one-tile-per-launch form: the
 // epilogue of 256 blocks finishing together ran at the HBM write rate, 7.5 us for 42 MB).
-template <int WR, bool STAMP = false>
+// UMASK >= 0: the upsampler form (ring_epilogue<UPS>), three tap slots, bit (slot * 4 + phase) of UMASK = the weights of that slot are all
+// zero for that phase: those products (and the reads of their A fragments) are left out AT COMPILE TIME — the loop is unrolled over the
+// three slots (x two fragment parities).  (Skipping by a run-time mask put scalar branches around the inline-asm MFMAs: hipcc then spilled
+// 124 registers, some of them accumulators stored right behind the MFMA that writes them, which it cannot see inside the asm: wrong values.)
+template <int WR, bool STAMP = false, int UMASK = -1>
 __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingArgs A, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   // WR = 4: 256 x 160, WR = 2: 128 x 320 (wave tile 64 x 80); WR = 1: 64 x 384 (wave tile 64 x 48: the 64-channel stage, whose X
   // tiles hold BOTH chunk pairs of its K)
+  constexpr bool UPS = UMASK >= 0;
   constexpr int WC = 8 / WR, MT = 4, NT = WR == 1 ? 3 : 5, ROWS = 64 * WR, COLS = 16 * NT * WC;
   constexpr int XW = WR == 4 ? 224 : WR == 2 ? 384 : 448;       // columns of an X tile (>= COLS + (ksize - 1) * dilation)
   constexpr int XP = (XW + 63) / 64;                     // DMA pieces per X row; the last one half-filled when XW % 64 == 32
@@ -305,8 +382,11 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
 
   int s = 0, pp = 0, t = 0, ws = 0;          // current step, its pair, tap, W slot
   int p3 = 0, t3 = 0;                        // pair and tap of step s + 3
-  auto body = [&](auto cur, auto late_c, auto more_c) __attribute__((always_inline)) {
+  auto body = [&](auto cur, auto late_c, auto more_c, auto tap_c) __attribute__((always_inline)) {
     constexpr int CUR = decltype(cur)::value;
+    constexpr int TC = decltype(tap_c)::value;         // UPS: the tap slot of this step, known at compile time (else -1)
+    // strips (= phases) whose weights are zero at this slot / at the next step's
+    constexpr unsigned SK = TC >= 0 ? ((unsigned)UMASK >> (4 * TC)) & 15u : 0u, SK1 = TC >= 0 ? ((unsigned)UMASK >> (4 * ((TC + 1) % 3))) & 15u : 0u;
     constexpr bool LATE = decltype(late_c)::value, MORE = decltype(more_c)::value;
     constexpr int N_HAND = LATE ? NT / 2 : 0;     // the DMA issue stands in front of this column's MFMAs
     constexpr int AR = (MT + NT - 2) / (NT - 1);   // rows of the next step's A fragments read per column (columns 1 .. NT - 1)
@@ -344,13 +424,17 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
         if constexpr (MORE) {
           if (n >= 1) {
 #pragma unroll
-            for (int m2 = (n - 1) * AR; m2 < n * AR && m2 < MT; ++m2) read_a(fa[CUR ^ 1][m2], wnext, m2);
+            for (int m2 = (n - 1) * AR; m2 < n * AR && m2 < MT; ++m2) {
+              if ((SK1 >> m2) & 1u) continue;
+              read_a(fa[CUR ^ 1][m2], wnext, m2);
+            }
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
+        if ((SK >> m) & 1u) continue;
         mfma16_acc(acc[m][n], fa[CUR][m][1], fb[(n + CUR) & 1][0]);
         mfma16_acc(acc[m][n], fa[CUR][m][0], fb[(n + CUR) & 1][1]);
         mfma16_acc(acc[m][n], fa[CUR][m][0], fb[(n + CUR) & 1][0]);
@@ -362,17 +446,33 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using NOT = std::integral_constant<int, -1>;
   auto loop = [&](auto late_c) __attribute__((always_inline)) {
     using L = decltype(late_c);
-    while (s + 2 < NS) {
-      body(I0{}, L{}, std::true_type{});
-      body(I1{}, L{}, std::true_type{});
-    }
-    if (s + 1 < NS) {
-      body(I0{}, L{}, std::true_type{});
-      body(I1{}, L{}, std::false_type{});
+    if constexpr (UPS) {
+      // three slots x two fragment parities: NS = 3 NP steps, NP even
+      auto six = [&](auto more_last) __attribute__((always_inline)) {
+        body(I0{}, L{}, std::true_type{}, I0{});
+        body(I1{}, L{}, std::true_type{}, I1{});
+        body(I0{}, L{}, std::true_type{}, I2{});
+        body(I1{}, L{}, std::true_type{}, I0{});
+        body(I0{}, L{}, std::true_type{}, I1{});
+        body(I1{}, L{}, more_last, I2{});
+      };
+      while (s + 6 < NS) six(std::true_type{});
+      six(std::false_type{});
     } else {
-      body(I0{}, L{}, std::false_type{});
+      while (s + 2 < NS) {
+        body(I0{}, L{}, std::true_type{}, NOT{});
+        body(I1{}, L{}, std::true_type{}, NOT{});
+      }
+      if (s + 1 < NS) {
+        body(I0{}, L{}, std::true_type{}, NOT{});
+        body(I1{}, L{}, std::false_type{}, NOT{});
+      } else {
+        body(I0{}, L{}, std::false_type{}, NOT{});
+      }
     }
   };
 
@@ -431,7 +531,8 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     mfma16_drain();
     if (!(A.diag & 4)) {
       const RingJob ej = A.job[done.j];
-      ring_epilogue<MT, NT>(ej, A, acc, done.b, done.co_b + wr * 64, done.q_b + wc * (16 * NT), li, lg);
+      if constexpr (UPS) ring_epilogue_ups<NT>(ej, A, acc, done.b, done.co_b + wr * 64, done.q_b + wc * (16 * NT), li, lg);
+      else ring_epilogue<MT, NT>(ej, A, acc, done.b, done.co_b + wr * 64, done.q_b + wc * (16 * NT), li, lg);
     }
     if constexpr (STAMP) st_epi += cr_clock() - p0;
     if (!more) break;
@@ -499,7 +600,16 @@ bool convring_same_shape(const ConvArgs& a, const ConvArgs& b) {
          (a.no_y || b.no_y || (a.y_bs == b.y_bs && a.y_cs == b.y_cs));
 }
 
-template <int WR>
+// ConvTranspose1d(stride 4) as a polyphase conv whose rows are ordered (16-channel group, phase, channel) — sat_conv1d_desc.up_grouped:
+// only this kernel reads that order (256-row tiles: rows > 128), whatever the number of tiles
+bool convring_ups_supports(const ConvArgs& a) {
+  if (!(a.x16 && a.y16 && a.no_y && !a.f8 && !a.y16_f8 && !a.k1_wrap && a.up == 4 && a.stride == 1)) return false;
+  if (a.ksize != 3 || a.cin_g % 64 != 0 || a.cin_pad != a.cin_g || a.rows_g <= 128 || a.rows_g % 64 != 0 || !a.bias) return false;
+  if (a.ch_scale || a.relu || a.gelu || a.res || a.res16 || a.res_after || a.accum) return false;
+  return (a.ksize - 1) * a.dil <= 64;
+}
+
+template <int WR, int UMASK = -1>
 static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s) {
   constexpr int WC = 8 / WR, NT = WR == 1 ? 3 : 5, ROWS = 64 * WR, COLS = 16 * NT * WC, XW = WR == 4 ? 224 : WR == 2 ? 384 : 448;
   RingArgs A{};
@@ -524,8 +634,8 @@ static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipS
   const size_t lds_bytes = ((size_t)2 * 8 * XW + (size_t)3 * 8 * ROWS) * 16;
   // one block per CU (the LDS of a block is most of a CU's): a block walks regions blockIdx.x, + gridDim.x, ...
   const int grid = std::min(A.n_vb, std::max(8, cu_count() / 8 * 8));
-  auto kern = conv1d_f16x3_ring16_kernel<WR, false>;
-  auto kern_st = conv1d_f16x3_ring16_kernel<WR, true>;
+  auto kern = conv1d_f16x3_ring16_kernel<WR, false, UMASK>;
+  auto kern_st = conv1d_f16x3_ring16_kernel<WR, UMASK < 0, UMASK>;      // (no stamped build of the upsampler form)
   static std::atomic<uint64_t> attr_done{0};      // per device
   int dev;
   if (attr_needed_on_current_device(attr_done, &dev)) {
@@ -544,5 +654,12 @@ int launch_f16x3_convring_multi(const ConvArgs* a, int njobs, int rotate, int B,
 }
 
 int launch_f16x3_convring(const ConvArgs& a, int B, hipStream_t s) { return launch_f16x3_convring_multi(&a, 1, 0, B, s); }
+
+// the zero pattern of ConvTranspose1d(k 8, stride 4, padding 2) — phases 0, 1: slots 0, 1; phases 2, 3: slots 1, 2 — has its own instantiation;
+// any other pattern multiplies everything (the zero weights are in the packed tensor)
+constexpr unsigned UPS_MASK_K8 = 0x30cu;
+int launch_f16x3_convring_ups(const ConvArgs& a, int B, hipStream_t s) {
+  return a.up_zero_taps == UPS_MASK_K8 ? launch_convring<4, (int)UPS_MASK_K8>(&a, 1, 0, B, s) : launch_convring<4, 0>(&a, 1, 0, B, s);
+}
 
 }  // namespace sat

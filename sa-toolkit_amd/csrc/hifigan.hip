@@ -137,6 +137,7 @@ struct sat_hifigan {
                              // 11 taps measured slower fused (its recomputed halo and short blocks cost more than the traffic saved)
   int mrf_exact = 0;         // fused MRF block: 0 = residuals of steps 2 / 3 rebuilt from the 22-bit planes like the launch-by-launch path (bit-identical
                              // to it, and measured 5 % faster: fewer live registers); 1 = kept in f32 registers
+  int ups_ring = 0;          // the stride-4 upsamplers' packed rows are grouped by phase (sat_conv1d_desc.up_grouped): set by the packer's side
   int ups2 = 1;              // the thin upsamplers (C_in = 64, 32; k 4, stride 2) on the streaming kernel of ups2.hip
   int multi_branch = 1;      // thick stages (C > 64): the i-th conv of all MRF branches as one sat_conv1d_multi_f32 call (one launch where the ring kernel serves them)
   int fuse_mrf = 1;          // a whole MRF block (all branches, all steps, the mean) as one launch where mrf.hip supports the stage (C = 16)
@@ -272,6 +273,7 @@ extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int valu
   if (std::string(name) == "multi_branch") { h->multi_branch = value; return SAT_OK; }
   if (std::string(name) == "mrf_exact") { h->mrf_exact = value; return SAT_OK; }
   if (std::string(name) == "ups2") { h->ups2 = value; return SAT_OK; }
+  if (std::string(name) == "ups_ring") { h->ups_ring = value; return SAT_OK; }
   if (std::string(name) == "split_acts") { h->split_acts = value; return SAT_OK; }
   if (std::string(name) == "planes_residual") { h->planes_residual = value; return SAT_OK; }
   if (std::string(name) == "branch_streams") { h->branch_streams = value; return SAT_OK; }
@@ -390,6 +392,19 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         int s;
         if (h->ups2 && cmode == SAT_CONV_F16X3 && h->planes_residual && sat_upsample2_supported(C, k, u, (k - u) / 2)) {
           s = sat_upsample2_f16x3(XS, h->convs[h->id_up(i)].w, h->convs[h->id_up(i)].bias, h->convs[h->id_up(i)].descale, Hs, 0.1f, B, C, Tc, stream);
+          if (s != SAT_OK) return s;
+        } else if (h->ups_ring && sat_upsample_grouped_supported(C, Cn, k, u, (k - u) / 2)) {
+          // rows grouped by phase (the packer consulted the same rule): the LDS-DMA ring, zero tap slots skipped (conv_ring16.hip)
+          if (!(cmode == SAT_CONV_F16X3 && h->planes_residual)) {
+            set_error("hifigan: option ups_ring (packed rows of the stride-4 upsamplers grouped by phase) needs split-f16 weights and the split-plane pipeline");
+            return SAT_ERR_INVALID;
+          }
+          d.y_split = Hs;
+          d.y_split_slope = 0.1f;
+          d.no_y = 1;
+          d.up_grouped = 1;
+          d.up_zero_taps = sat_convtranspose_zero_taps(k, u, (k - u) / 2);
+          s = sat_conv1d_f32(&d, nullptr, h->convs[h->id_up(i)].w, nullptr, stream);
           if (s != SAT_OK) return s;
         } else if (direct) {
           d.y_split = Hs;
@@ -637,6 +652,10 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
     {
       int lo, hi;
       phase_window(k, u, (k - u) / 2, &lo, &hi);
+      if (h->ups_ring && sat_upsample_grouped_supported(C, Cn, k, u, (k - u) / 2)) {
+        set_error("hifigan: option ups_ring (packed rows of the stride-4 upsamplers grouped by phase) needs the split-plane pipeline (split_acts)");
+        return SAT_ERR_INVALID;
+      }
       sat_conv1d_desc d = base_desc(C, Cn, Tc, Tc, u);
       d.ksize = hi - lo + 1;
       d.pad_left = -lo;

@@ -97,7 +97,9 @@ def export_frozen(model, path):
     ext._prepare(dev)
     blob = {"format": FORMAT, "kind": "anonymizer",
             "build_args": _plain(dict(model._build_args)), "utt2spk": {str(k): str(v) for k, v in dict(model.utt2spk).items()},
-            "generator": {"packed": _enc(gen._packed), "modes": list(gen._packed_modes), "precision": gen.precision},
+            "generator": {"packed": _enc(gen._packed), "modes": list(gen._packed_modes), "precision": gen.precision,
+                          # row order of the stride-4 upsamplers' packed weights (hifigan.py: ups_ring); absent in older files = 0
+                          "ups_grouped": int(bool(gen.__dict__.get("_packed_ups_grouped", False)))},
             "extractor": {"class": type(ext).__name__, "precision": ext.precision, "cache": _enc(ext._cache)}}
     if hasattr(ext, "_prepare_full"):
         full = ext._prepare_full(dev)
@@ -131,7 +133,8 @@ def load_frozen(path, device="cuda"):
     gen.precision = blob["generator"]["precision"]
     if len(blob["generator"]["packed"].get("__l__", [])) != len(blob["generator"]["modes"]):
         raise _lib.SatError(f"{path}: packed convolutions and modes differ in number")
-    gen._install_packed(_dec(blob["generator"]["packed"], device), blob["generator"]["modes"])
+    gen._install_packed(_dec(blob["generator"]["packed"], device), blob["generator"]["modes"],
+                        ups_grouped=bool(blob["generator"].get("ups_grouped", 0)))
     gen.__dict__["_frozen"] = True
     e = blob["extractor"]
     if type(ext).__name__ != e["class"]:

@@ -41,6 +41,11 @@ class CoreHifiGan(CoreHifiGanParams):
     #: the two thin upsamplers (64 -> 32 and 32 -> 16 channels) on the streaming kernel of csrc/ups2.hip
     ups2 = int(os.environ.get("SATOOLS_AMD_GEN_UPS2", "1"))
 
+    #: the stride-4 upsamplers (256 -> 128 and 128 -> 64 channels) on the LDS-DMA ring of csrc/conv_ring16.hip: their polyphase rows
+    #: are PACKED grouped by phase (sat_conv1d_desc.up_grouped) and the all-zero tap slots of a phase are skipped (2 of 3 slots carry
+    #: weights at k = 8).  Needs the split-f16 generator on the split-plane pipeline (precision "f16x3", split_acts)
+    ups_ring = int(os.environ.get("SATOOLS_AMD_GEN_UPS_RING", "1"))
+
     #: per-stream workspaces kept (3.3 GB each at 32 x 5 s: 26 GB at the default); beyond it the least recently used one is
     #: dropped.  One per convert() job in flight on the GPU (the reference's jobs_per_compute_device, bench.py --jobs) is
     #: what is needed; raise SATOOLS_AMD_GEN_MAX_WORKSPACES for more concurrent streams
@@ -60,7 +65,7 @@ class CoreHifiGan(CoreHifiGanParams):
         ps = self.__dict__.get("_flat_params")
         if ps is None:
             ps = self.__dict__["_flat_params"] = list(self.parameters())
-        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf, self.ups2, self.multi_branch) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf, self.ups2, self.multi_branch, self.ups_ring) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def invalidate(self):
         self._packed_key = None
@@ -104,7 +109,8 @@ class CoreHifiGan(CoreHifiGanParams):
                 mode = _lib.CONV_F32
             elif 1 <= i <= n_ups:
                 u, k = self.upsample_rates[i - 1], self.upsample_kernel_sizes[i - 1]
-                wc, _, _ = packing.convtranspose_as_phase_conv(w, u, (k - u) // 2)
+                grouped = self._ups_grouped() and packing.upsample_grouped_supported(w.shape[0], w.shape[1], k, u, (k - u) // 2)
+                wc, _, _ = packing.convtranspose_as_phase_conv(w, u, (k - u) // 2, grouped=grouped)
                 wp = pack(wc, up=u)
             else:
                 wp = pack(w)
@@ -114,7 +120,11 @@ class CoreHifiGan(CoreHifiGanParams):
         self._packed_key = key
         _lib.cache_rebuild_end(device)
 
-    def _install_packed(self, packed, modes):
+    def _ups_grouped(self):
+        """whether the stride-4 upsamplers' rows are packed grouped by phase (what the C handle is told as option ups_ring)"""
+        return bool(self.ups_ring) and self.precision == "f16x3" and bool(self.split_acts)
+
+    def _install_packed(self, packed, modes, ups_grouped=None):
         """hand the kernel-ready weights [(packed weight, bias)] of every conv to the C handle (also the entry point of
         frozen.load_frozen, which brings them from a file instead of folding and packing parameters)"""
         l = lib()
@@ -143,6 +153,9 @@ class CoreHifiGan(CoreHifiGanParams):
         check(l.sat_hifigan_set_option(self._handle, b"fuse_mrf", int(self.fuse_mrf)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"multi_branch", int(self.multi_branch)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"ups2", int(self.ups2)), "sat_hifigan_set_option")
+        # (a frozen model brings the row order its weights were packed in)
+        self._packed_ups_grouped = self._ups_grouped() if ups_grouped is None else bool(ups_grouped)
+        check(l.sat_hifigan_set_option(self._handle, b"ups_ring", int(self._packed_ups_grouped)), "sat_hifigan_set_option")
         self._packed = packed  # keeps the device buffers alive
         self._packed_modes = list(modes)
 

@@ -64,7 +64,7 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
                  up=1, in_lrelu=None, res=None, res_scale=1.0, res_toff=0, res_tstride=1, ch_scale=None, ch_shift=None,
                  relu=False, gelu=False, post_res=None, out=None, accum=False, accum_div=0.0, mode=0, t_out=None,
                  x_split=None, y_split=None, y_split_slope=1.0, no_y=False, y_split_format=0, res_split=None,
-                 res_split_slope=1.0, relu_first=False, x_wrap_channels=0, c_in=None):
+                 res_split_slope=1.0, relu_first=False, x_wrap_channels=0, c_in=None, up_grouped=False, up_zero_taps=0):
     """Descriptor of a fused conv (see include/satools_hip.h sat_conv1d_f32).  `pad_right` defaults to the
     'same'-style value implied by pad_left for stride 1; T_q is derived like torch does:
     T_q = (T_in + pad_left + pad_right - dilation*(ksize-1) - 1)//stride + 1 (`t_out` caps it).
@@ -74,7 +74,9 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
     `no_y` skips the f32 store; `res_split` takes the residual from SPLIT_F16 planes of lrelu(r, res_split_slope).
     `x_wrap_channels` = Cw (1x1 conv on split planes): the planes hold Cw channels and the weight's input channels
     c >= Cw read channel c - Cw one position later (sat_conv1d_desc.x_wrap_channels); `x` gives [B, Cw, T] and
-    `c_in` the weight's input channels."""
+    `c_in` the weight's input channels.  `up_grouped` (up = 4, planes in and out): the polyphase weight's rows are ordered (16-channel
+    group, phase, channel) — packing.convtranspose_as_phase_conv(..., grouped=True) — and `up_zero_taps` names its all-zero (tap slot,
+    phase) pairs (packing.convtranspose_zero_taps), sat_conv1d_desc.up_grouped / up_zero_taps."""
     x = _strided3(x)
     c_in_w = c_in
     B, c_in, t_in = x.shape
@@ -118,6 +120,7 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
     d.res_split, d.res_split_slope = ptr(res_split), float(res_split_slope)
     d.relu_first = int(relu_first)
     d.x_wrap_channels = int(x_wrap_channels)
+    d.up_grouped, d.up_zero_taps = int(bool(up_grouped)), int(up_zero_taps)
     return d, x, out, res      # (res: the possibly re-laid-out residual must outlive the launch)
 
 

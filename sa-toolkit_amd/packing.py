@@ -36,10 +36,21 @@ def pack_conv_weight(w: torch.Tensor, groups: int = 1, up: int = 1) -> torch.Ten
     return out.contiguous()
 
 
-def convtranspose_as_phase_conv(w: torch.Tensor, stride: int, padding: int):
+def upsample_grouped_supported(c_in, c_out, k, stride, padding):
+    """the shapes whose polyphase rows may be ordered (16-channel group, phase, channel): sat_conv1d_desc.up_grouped"""
+    return bool(_lib.lib().sat_upsample_grouped_supported(int(c_in), int(c_out), int(k), int(stride), int(padding)))
+
+
+def convtranspose_zero_taps(k, stride, padding):
+    """bit (slot * 4 + phase) set: that tap slot of the polyphase conv is all zero for that phase (sat_conv1d_desc.up_zero_taps)"""
+    return int(_lib.lib().sat_convtranspose_zero_taps(int(k), int(stride), int(padding)))
+
+
+def convtranspose_as_phase_conv(w: torch.Tensor, stride: int, padding: int, grouped: bool = False):
     """ConvTranspose1d weight [C_in, C_out, K] -> equivalent conv weight [C_out*u, C_in, K'] whose
     row co*u + r produces output phase r (t = q*u + r), plus (K', pad_left).
-    Output t reads input s = q + delta through tap j = r + padding - u*delta."""
+    Output t reads input s = q + delta through tap j = r + padding - u*delta.
+    `grouped`: row (co // 16 * u + r) * 16 + co % 16 instead (sat_conv1d_desc.up_grouped; C_out % 16 == 0)."""
     c_in, c_out, k = w.shape
     u = stride
     kp, pad_left = phase_dims(k, u, padding)
@@ -50,6 +61,9 @@ def convtranspose_as_phase_conv(w: torch.Tensor, stride: int, padding: int):
             j = r + padding - u * delta
             if 0 <= j < k:
                 wc[r::u, :, jp] = w[:, :, j].t()
+    if grouped:
+        assert c_out % 16 == 0
+        wc = wc.reshape(c_out // 16, 16, u, c_in, kp).permute(0, 2, 1, 3, 4).reshape(c_out * u, c_in, kp).contiguous()
     return wc, kp, pad_left
 
 

@@ -194,6 +194,58 @@ def test_polyphase_conv_writes_split_planes(cfg):
     assert torch.equal(ys, ops.act_split(y, 0.1))
 
 
+@pytest.mark.parametrize("cfg", [(256, 128, 133, 2), (128, 64, 700, 3), (256, 128, 161, 1), (128, 64, 5000, 2)])
+def test_stride4_upsampler_on_the_ring_with_rows_grouped_by_phase(cfg):
+    """ConvTranspose1d(k 8, stride 4, padding 2) planes to planes on the LDS-DMA ring (conv_ring16.hip, sat_conv1d_desc.up_grouped):
+    rows ordered (16-channel group, phase, channel), the plane units transposed inside the quads of lanes before the stores, the
+    all-zero (tap slot, phase) products left out.  Against float64, against the LDS-transposed epilogue of the 64 x 256 tile
+    (another accumulation order: f32 rounding), and the instantiation without the zero products against the one that multiplies
+    everything (the same bits)."""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    cin, cout, T, B = cfg
+    k, u = 8, 4
+    pad = (k - u) // 2
+    assert packing.upsample_grouped_supported(cin, cout, k, u, pad) and not packing.upsample_grouped_supported(cin, cout, 4, 2, 1)
+    assert not packing.upsample_grouped_supported(64, 32, k, u, pad) and not packing.upsample_grouped_supported(96, 64, k, u, pad)
+    zt = packing.convtranspose_zero_taps(k, u, pad)
+    assert zt == 0x30c            # phases 0, 1: slots 0, 1; phases 2, 3: slots 1, 2
+    x = _rand(B, cin, T, seed=1).to(DEV)
+    w = _rand(cin, cout, k, seed=2, scale=1.0 / np.sqrt(cin * k / u)).to(DEV)
+    b = _rand(cout, seed=3).to(DEV)
+    xs = ops.act_split(x, 0.1)
+    wc, kp, pl = packing.convtranspose_as_phase_conv(w, u, pad)
+    wg, kp2, pl2 = packing.convtranspose_as_phase_conv(w, u, pad, grouped=True)
+    assert (kp, pl) == (kp2, pl2) == (3, 1)
+    # the mask names exactly the zero (slot, phase) pairs of the polyphase weight
+    for slot in range(kp):
+        for r in range(u):
+            assert bool((wc[r::u, :, slot] == 0).all()) == bool(zt >> (slot * 4 + r) & 1)
+    y_tile = ops.split_like(B, cout, T * u, DEV)
+    ops.conv1d(x, packing.pack_conv_weight_f16x3(wc, up=u), cout, kp, bias=b, pad_left=pl, up=u, mode=1, x_split=xs, y_split=y_tile,
+               y_split_slope=0.1, no_y=True)
+    wpg = packing.pack_conv_weight_f16x3(wg, up=u)
+    outs = []
+    for mask in (zt, 0, 0x1):     # (0x1 is not the pattern with an instantiation of its own: everything is multiplied)
+        ys = torch.full((B, cout // 16, 2, 2, T * u, 8), 7.0, dtype=torch.float16, device=DEV)
+        guard = torch.full((B, cout, T * u), 7.0, device=DEV)
+        ops.conv1d(x, wpg, cout, kp, bias=b, pad_left=pl, up=u, mode=1, x_split=xs, y_split=ys, y_split_slope=0.1, no_y=True, out=guard,
+                   up_grouped=True, up_zero_taps=mask)
+        assert "UMASK = %d" % (zt if mask == zt else 0) in _lib.lib().sat_last_dispatch_name().decode()
+        assert (guard == 7.0).all()
+        outs.append(ys)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = F.leaky_relu(F.conv_transpose1d(F.leaky_relu(x.double().cpu(), 0.1), w.double().cpu(), b.double().cpu(), stride=u, padding=pad), 0.1)
+    got = ops.unsplit(outs[0]).double().cpu()
+    assert (got - ref).abs().max() < 4e-6
+    assert (got - ops.unsplit(y_tile).double().cpu()).abs().max() < 4e-6
+    # what the layout needs is said, not guessed
+    with pytest.raises(_lib.SatError):
+        ops.conv1d(x, wpg, cout, kp, bias=b, pad_left=pl, up=u, mode=1, x_split=xs, up_grouped=True)                    # f32 output
+    with pytest.raises(_lib.SatError):
+        ops.conv1d(x, wpg, cout, kp, bias=b, pad_left=pl, up=u, mode=0, up_grouped=True)                               # exact-f32 mode
+
+
 def test_convpost_matches_oracle():
     ops, _ = _ops()
     x, w, b = _rand(2, 16, 2500, seed=1), _rand(1, 16, 7, seed=2, scale=0.1), _rand(1, seed=3, scale=0.1)
@@ -444,9 +496,15 @@ def test_generator_split_plane_pipeline_equals_f32_handover(model, gold):
     x = torch.randn(2, g.imput_dim, 25, generator=torch.Generator().manual_seed(3)).to(DEV)
     with conv_option("convring", 33, 1):
         y_ring = g(x)[0].clone()             # the thick stages on the LDS-DMA ring conv (16x16x32 MFMA shape; + 32: also for this small batch)
-    with conv_option("convring", 0, 1):      # the register-staged tiles below accumulate in ONE order whatever the staging
-        _split_plane_pipeline_equals_f32_handover(g, x, lib, check)
-        y_lean = g(x)[0]
+    keep_ups = g.ups_ring
+    try:
+        # (the f32-handover pipeline reads the upsamplers' rows in the (channel, phase) order: ups_ring off for the comparison)
+        g.ups_ring = 0
+        with conv_option("convring", 0, 1):      # the register-staged tiles below accumulate in ONE order whatever the staging
+            _split_plane_pipeline_equals_f32_handover(g, x, lib, check)
+            y_lean = g(x)[0].clone()
+    finally:
+        g.ups_ring = keep_ups
     # K = 32 per instruction associates differently: agreement to f32 rounding of the accumulation
     assert rms((y_ring - y_lean).cpu().numpy()) < 5e-7
 
@@ -1352,6 +1410,39 @@ def test_generator_multi_branch_launches_give_the_same_bits(model):
         finally:
             check(lib().sat_hifigan_set_option(g._handle, b"multi_branch", g.multi_branch), "set_option")
     assert torch.equal(y0, y1)
+
+
+def test_generator_stride4_upsamplers_on_the_ring(model):
+    """generator attribute `ups_ring`: the two stride-4 upsamplers packed with their rows grouped by phase and run by the LDS-DMA ring
+    (another accumulation order than the 64 x 256 tile: f32 rounding), the row order kept by the frozen export, and the pipelines that
+    cannot read that order refusing it"""
+    from satools_amd._lib import lib, check, SatError
+    g = model.hifigan
+    if g.precision != "f16x3" or not g.split_acts:
+        pytest.skip("the grouped rows belong to the split-f16 generator on the split-plane pipeline")
+    x = torch.randn(2, g.imput_dim, 41, generator=torch.Generator().manual_seed(6)).to(DEV)
+    keep = g.ups_ring
+    try:
+        g.ups_ring = 1
+        y1 = g(x)[0].clone()
+        assert g._packed_ups_grouped
+        check(lib().sat_hifigan_set_option(g._handle, b"planes_residual", 0), "set_option")
+        try:
+            with pytest.raises(SatError):
+                g(x)
+            check(lib().sat_hifigan_set_option(g._handle, b"split_acts", 0), "set_option")
+            with pytest.raises(SatError):
+                g(x)
+        finally:
+            check(lib().sat_hifigan_set_option(g._handle, b"split_acts", 1), "set_option")
+            check(lib().sat_hifigan_set_option(g._handle, b"planes_residual", 1), "set_option")
+        assert torch.equal(y1, g(x)[0])
+        g.ups_ring = 0
+        y0 = g(x)[0].clone()
+        assert not g._packed_ups_grouped
+    finally:
+        g.ups_ring = keep
+    assert rms((y1 - y0).cpu().numpy()) < 5e-7
 
 
 @pytest.mark.parametrize("B,T", [(3, 249), (2, 500), (5, 250)], ids=lambda v: str(v))

@@ -1,4 +1,5 @@
-"""A/B of a sat_conv_set_option switch (or, with the prefix `gen:`, a sat_hifigan_set_option switch) on the generator forward
+"""A/B of a sat_conv_set_option switch (or, with the prefix `gen:`, a sat_hifigan_set_option switch; with `attr:`, an attribute of the
+Python generator object, which repacks the weights where they depend on it) on the generator forward
 (batch 32 x 250 frames), interleaved rounds in one process: python tools/ab_option.py <option> <value_a> <value_b>"""
 import os
 import sys
@@ -8,8 +9,8 @@ import satools_amd
 from satools_amd import _lib
 
 name, va, vb = sys.argv[1].encode(), int(sys.argv[2]), int(sys.argv[3])
-GEN = name.startswith(b"gen:")
-name = name[4:] if GEN else name
+GEN, ATTR = name.startswith(b"gen:"), name.startswith(b"attr:")
+name = name[4:] if GEN else name[5:] if ATTR else name
 model = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1")
 model.to("cuda")
 g = model.hifigan
@@ -17,7 +18,9 @@ x = torch.randn(32, g.imput_dim, 250, device="cuda")
 
 
 def setopt(v):
-    if GEN:
+    if ATTR:
+        setattr(g, name.decode(), v)
+    elif GEN:
         g(x[:1])                             # (the handle exists after the first forward)
         _lib.check(_lib.lib().sat_hifigan_set_option(g._handle, name, v), "set_option")
     else:
