@@ -25,6 +25,7 @@ static int g_k1_gemm = 3;
 // sat_conv_set_option("lean3" | "lean7" | "lean11", v): 3- / 7- / 11-tap convs on split planes (no folded BatchNorm) through
 // the three-blocks-per-CU form of the tile (1, conv_lean.hip) or the two-block form (0)
 static int g_lean3 = 1, g_lean7 = 1, g_lean11 = 1;
+static int g_trim_halo = 1; // the fused pair kernels load only the columns of their staged window that conv1 reads (window + halo of the dilation)
 static int g_pair32s = 1;   // the 3-tap fused step at C = 32 on the streaming kernel (pair32s.hip)
 
 template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1, int XWI>
@@ -1347,7 +1348,8 @@ __global__ void __launch_bounds__(256, 3) resblock_pair32_kernel(const ConvArgs 
 #pragma unroll
     for (int it = 0; it < XWI; ++it) {
       const int xi = xi0 + lane + 64 * it;
-      const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((pl * p.T_in + xi) * 16) : 0x80000000u;
+      // (p.xw: the columns conv1 reads — its W1-column window plus the halo of the dilated taps; the rest of the 320 is never multiplied)
+      const unsigned voff = (xi >= 0 && xi < p.T_in && lane + 64 * it < p.xw) ? (unsigned)((pl * p.T_in + xi) * 16) : 0x80000000u;
       xst[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, chunk * 4 * p.T_in * 16, 0));
     }
   };
@@ -1472,6 +1474,7 @@ static int launch_pair32(const ConvArgs& a, int B, hipStream_t s) {
     return SAT_ERR_INVALID;
   }
   const size_t lds_bytes = ((size_t)KS * 4 * 32 + (size_t)2 * 4 * (KS == 11 ? 236 : FP_W1)) * 16;   // weights + t1 (over the input chunk)
+  p.xw = g_trim_halo ? (KS == 11 ? 236 : FP_W1) + (p.ksize - 1) * p.dil : 320;
   auto kern = resblock_pair32_kernel<KS>;
   if (lds_bytes > 64 * 1024)
     SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1893,6 +1896,7 @@ extern "C" int sat_resblock_pair_scaled_f16x3(const sat_conv1d_desc* d, const fl
   if (a.cin_g == 64 && g_pair32s && pair32s_supports(a)) return launch_pair32s(a, d->B, s);
   if (a.cin_g == 64) {
     SAT_REQUIRE(pair64_supports(a), "resblock_pair(C = 64): split planes in, residual from planes, (ksize - 1) * dilation <= 64");
+    a.xw = g_trim_halo ? 128 + (a.ksize - 1) * a.dil : 192;      // staged columns conv1 reads (pair64.hip)
     return launch_pair64(a, d->B, s);
   }
   if (a.cin_g == 32 && a.x16 && a.res16) {
@@ -1929,6 +1933,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "lean7")) { g_lean7 = value != 0; return SAT_OK; }
   if (!strcmp(name, "lean11")) { g_lean11 = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32s")) { g_pair32s = value != 0; return SAT_OK; }
+  if (!strcmp(name, "trim_halo")) { g_trim_halo = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32w")) { pair32w_set(value); return SAT_OK; }
   if (!strcmp(name, "pair64w")) { pair64w_set(value); return SAT_OK; }
   if (!strcmp(name, "convring")) { convring_set(value); return SAT_OK; }

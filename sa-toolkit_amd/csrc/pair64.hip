@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs 
 #pragma unroll
       for (int it = 0; it < XWI; ++it) {
         const int xi = xi0 + lane + 64 * it;
-        const unsigned voff = (xi >= 0 && xi < p.T_in) ? (unsigned)((wave * p.T_in + xi) * 16) : 0x80000000u;
+        // (p.xw: the 128-column window of conv1 plus the halo of its dilated taps — the rest of the 192 staged columns is never multiplied)
+        const unsigned voff = (xi >= 0 && xi < p.T_in && lane + 64 * it < p.xw) ? (unsigned)((wave * p.T_in + xi) * 16) : 0x80000000u;
         xst[set][it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, ch * 4 * p.T_in * 16, 0));
       }
     }

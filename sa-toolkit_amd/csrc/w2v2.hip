@@ -50,6 +50,8 @@ constexpr int LN_FR = 32;          // frames per block: a wave's load covers two
 // CONV0: the input is not read but computed — the wav2vec2 feature extractor's first conv (1 -> C channels, ck <= 12
 // taps, stride cstride) of the waveform x [B][cn], weights in LDS as rows of 12 floats: y = LN(conv0(wav)) without the
 // [B][512][16k] f32 tensor ever reaching HBM.  Same accumulation order as w2v2_conv0_kernel, so the same bits.
+// (Tried: 64 frames per block, a wave = one channel slice, the weights as SGPR operands from scalar loads instead of 96 broadcast
+// ds_read_b128 per thread — 517 -> 745 us; channel pairs in packed f32 FMAs — hipcc spilled 3 000 registers.)
 template <int SLICES, int MAXPT, bool CONV0 = false>
 __global__ void __launch_bounds__(LN_FR * SLICES) layernorm_ch_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
@@ -150,9 +152,13 @@ __global__ void __launch_bounds__(LN_FR * SLICES) layernorm_ch_kernel(
       }
     }
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      o[jj] = (v[8 * g8 + jj] - mean) * rstd * gm[jj] + bt[jj];
-      if (gelu) o[jj] = gelu_erf(o[jj]);
+    for (int jj = 0; jj < 8; ++jj) o[jj] = (v[8 * g8 + jj] - mean) * rstd * gm[jj] + bt[jj];
+    if (gelu) {                                  // packed f32 arithmetic, two values per instruction (common.h)
+      float o0[4] = {o[0], o[1], o[2], o[3]}, o1[4] = {o[4], o[5], o[6], o[7]};
+      gelu_fast4(o0);
+      gelu_fast4(o1);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) o[jj] = o0[jj], o[4 + jj] = o1[jj];
     }
     if (yf) {
 #pragma unroll

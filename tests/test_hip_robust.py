@@ -341,17 +341,24 @@ def test_sharded_job_runs_on_rccl_in_a_child_process():
     re-executed): the ranks RCCL saw, the gathered job = the shard, both tags, float and PCM16 gathers"""
     env = dict(os.environ, SAT_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0",
                WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for extra in ([], ["--gather", "pcm16"]):
+    # (--headline-only: the fbank tag of configs[1]; without it the wav2vec2 tag of BASELINE configs[4] runs first through the same
+    # code and its line goes to stderr as CONFIG_LINE)
+    for extra in (["--headline-only"], ["--gather", "pcm16"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                            "--headline-only", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                            "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
-        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        cfg = line["config"]
-        assert cfg["ranks_seen_by_rccl"] == [0], cfg
-        assert cfg["all_gather_ms"] > 0.0
-        assert cfg["gathered_equals_shard"] is True, cfg
-        assert cfg["gather_dtype"] == ("int16" if extra else "float32")
-        assert line["n_gpus"] == 1 and line["value"] > 0
+        lines = [json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])]
+        lines += [json.loads(l[len("CONFIG_LINE "):]) for l in r.stderr.splitlines() if l.startswith("CONFIG_LINE ")]
+        assert len(lines) == (1 if "--headline-only" in extra else 2)
+        for line in lines:
+            cfg = line["config"]
+            assert cfg["ranks_seen_by_rccl"] == [0], cfg
+            assert cfg["all_gather_ms"] > 0.0
+            assert cfg["gathered_equals_shard"] is True, cfg
+            assert cfg["gather_dtype"] == ("int16" if "pcm16" in extra else "float32")
+            assert cfg["utterances"] == 64 and line["n_gpus"] == 1 and line["value"] > 0
+        if len(lines) == 2:
+            assert "wav2vec2" in lines[1]["config"]["workload"] and "wav2vec2" not in lines[0]["config"]["workload"]
 
 
 @pytest.mark.parametrize("tag", [FBANK_TAG, W2V2_TAG])
