@@ -112,6 +112,30 @@ def test_packing_layout_and_polyphase_equivalence():
         assert torch.allclose(y, ref, atol=1e-5)
 
 
+def test_grouped_polyphase_rows_and_their_zero_tap_mask():
+    """sat_conv1d_desc.up_grouped / up_zero_taps (host side): the row order (16-channel group, phase, channel) is a permutation of
+    the (channel, phase) order, the mask names exactly the all-zero (tap slot, phase) pairs of ConvTranspose1d(k, stride u, padding)
+    seen as a polyphase conv (reference hifigan/archi.py:47-59), and the rule that admits a layer is the launcher's"""
+    for k, u in ((8, 4), (4, 2), (16, 4), (6, 3)):
+        pad = (k - u) // 2
+        wt = torch.randn(8, 32, k)
+        wc, kp, pl = packing.convtranspose_as_phase_conv(wt, u, pad)
+        wg, kp2, pl2 = packing.convtranspose_as_phase_conv(wt, u, pad, grouped=True)
+        assert (kp, pl) == (kp2, pl2) and wg.shape == wc.shape
+        for c in (0, 5, 17, 31):
+            for r in range(u):
+                assert torch.equal(wg[(c // 16 * u + r) * 16 + c % 16], wc[c * u + r])
+        mask = packing.convtranspose_zero_taps(k, u, pad)
+        if kp <= 8:
+            for slot in range(kp):
+                for r in range(u):
+                    assert bool((wc[r::u, :, slot] == 0).all()) == bool(mask >> (slot * 4 + r) & 1), (k, u, slot, r)
+    assert packing.convtranspose_zero_taps(8, 4, 2) == 0x30c and packing.convtranspose_zero_taps(11, 5, 3) == 0        # (stride 5: no 4-bit phase field)
+    ok = packing.upsample_grouped_supported
+    assert ok(256, 128, 8, 4, 2) and ok(128, 64, 8, 4, 2)
+    assert not ok(512, 256, 11, 5, 3) and not ok(64, 32, 4, 2, 1) and not ok(64, 32, 8, 4, 2) and not ok(96, 64, 8, 4, 2) and not ok(128, 72, 8, 4, 2)
+
+
 def test_yaapt_plan_matches_the_oracle_plan():
     from oracle import yaapt as oy
     opts = {"frame_length": 35.0, "frame_space": 20.0, "nccf_thresh1": 0.25, "tda_frame_length": 25.0}
