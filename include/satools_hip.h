@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 3
+#define SAT_ABI_VERSION 4
 
 typedef enum {
   SAT_OK = 0,

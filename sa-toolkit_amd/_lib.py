@@ -149,6 +149,11 @@ def exported_symbols():
     return sorted(_PROTOS)
 
 
+def library_path():
+    """where the in-tree shared library lives (built by sa-toolkit_amd/build.py)"""
+    return LIB_PATH
+
+
 def lib():
     """load (once) and return the ctypes library; raises if it has not been built"""
     global _lib
@@ -162,7 +167,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.sat_abi_version() != 3:
+        if l.sat_abi_version() != 4:       # 4: sat_conv1d_desc grew up_grouped / up_zero_taps
             raise SatError("libsatools_hip.so ABI version mismatch")
         # A/B switches of the conv dispatch for whole-program measurements (bench.py under different kernels):
         # SATOOLS_AMD_CONV_OPTIONS="pair32w=0,lean_balance=2" -> sat_conv_set_option(name, value) at load time
