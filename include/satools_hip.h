@@ -253,7 +253,8 @@ int sat_upsample2_f16x3(const void* x_split, const void* w_packed, const float* 
  * K = 32 per instruction associates differently from the register-staged tiles: agreement to f32 rounding of the accumulation;
  * "gemm_walk" (0 / 1 default; + 2: also single GEMMs with no more tiles than CUs) sends 1x1 convs of k1_gemm = 3 with a plain
  * Linear epilogue (bias, f32 residual, GELU, f32 / plane stores) through the persistent form of that ring (csrc/gemm_walk16.hip)
- * when a launch holds more tiles than CUs or several GEMMs (sat_conv1d_multi_f32) — the bits of k1_gemm = 3; "trim_halo" (0 / 1
+ * when a launch holds more tiles than CUs or several GEMMs (sat_conv1d_multi_f32) — the bits of k1_gemm = 3; "convring_blocks" (0 default = one block per CU; else the
+ * blocks of a ring-conv launch, a multiple of 8: CUs left to the kernels of other streams, an A/B switch); "trim_halo" (0 / 1
  * default): the fused ResBlock steps at C = 64 / 32 load only the columns of their staged input window that conv1 reads (same bits).
  * Unknown names return SAT_ERR_INVALID. */
 int sat_conv_set_option(const char* name, int value);

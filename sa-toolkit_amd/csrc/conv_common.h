@@ -623,6 +623,7 @@ int launch_f16x3_convring_multi(const ConvArgs* a, int njobs, int rotate, int B,
 bool convring_same_shape(const ConvArgs& a, const ConvArgs& b);
 bool convring_supports(const ConvArgs& a, int B);
 void convring_set(int v);
+void convring_set_blocks(int v);
 int convring_debug_stamps(long long* buf);
 bool ring16_supports(const ConvArgs& a);
 // the persistent, multi-job form of that ring for plain Linear layers (gemm_walk16.hip)

@@ -557,6 +557,8 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
 
 static int g_convring = 1;
 void convring_set(int v) { g_convring = v; }
+static int g_convring_blocks = 0;     // option "convring_blocks": blocks of a launch (0 = one per CU); fewer leave CUs to the kernels of other streams
+void convring_set_blocks(int v) { g_convring_blocks = v < 0 ? 0 : v / 8 * 8; }
 static long long* g_convring_dbg = nullptr;
 int convring_debug_stamps(long long* buf) {
   g_convring_dbg = buf;
@@ -633,7 +635,7 @@ static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipS
   A.n_vb = 8 * A.n_rt * ceil_div(A.total, 8);
   const size_t lds_bytes = ((size_t)2 * 8 * XW + (size_t)3 * 8 * ROWS) * 16;
   // one block per CU (the LDS of a block is most of a CU's): a block walks regions blockIdx.x, + gridDim.x, ...
-  const int grid = std::min(A.n_vb, std::max(8, cu_count() / 8 * 8));
+  const int grid = std::min(A.n_vb, std::max(8, (g_convring_blocks ? std::min(g_convring_blocks, cu_count()) : cu_count()) / 8 * 8));
   auto kern = conv1d_f16x3_ring16_kernel<WR, false, UMASK>;
   auto kern_st = conv1d_f16x3_ring16_kernel<WR, UMASK < 0, UMASK>;      // (no stamped build of the upsampler form)
   static std::atomic<uint64_t> attr_done{0};      // per device
