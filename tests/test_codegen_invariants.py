@@ -26,7 +26,7 @@ def code_objects(tmp_path_factory):
     objdump, readelf = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
     if not (os.path.exists(objdump) and os.path.exists(readelf)):
         pytest.skip("llvm-objdump / llvm-readelf of ROCm not found")
-    _lib.lib()                                             # builds the library if it is not there yet
+    _lib.lib()                                             # (raises with the build command if the library is missing)
     d = tmp_path_factory.mktemp("co")
     so = shutil.copy(_lib.library_path(), d)
     subprocess.run([objdump, "--offloading", so], check=True, capture_output=True, cwd=d)
