@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 4
+#define SAT_ABI_VERSION 5
 
 typedef enum {
   SAT_OK = 0,
@@ -106,6 +106,21 @@ int sat_convring_debug_stamps(int64_t* buf);
  *                  w[g][cin_pad/16][ksize][4][co_pad][16 B], segments hi f16 ch 0-7 | hi f16 ch 8-15 |
  *                  e4m3(lo * 2^16) 16 ch | e4m3(hi * 2^6) 16 ch. */
 #define SAT_CONV_F16F8 2
+/*   SAT_CONV_F16F8R (round 5) the same decomposition inside the LDS-DMA ring kernel (csrc/conv_ring16.hip; k-tap convs with
+ *                  C_out > 64, C_in % 32 == 0, the generator's ResBlock epilogues): hi*hi on v_mfma_f32_16x16x32_f16, both cross
+ *                  terms of a PAIR of taps in one block-scaled e4m3 v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 = 2 terms x 2 taps
+ *                  x 32 channels) — 2 MFMA units per product instead of 3.  The main planes stay SAT_SPLIT_F16 (the residual is
+ *                  still rebuilt from hi + lo: 22 bits); the e4m3 operands travel in a SIDECAR next to them,
+ *                    S8[b][c/16][2 units][t][16 B] = e4m3(hi) of 16 channels | e4m3(lo * 2^10) of 16 channels
+ *                  (hi, lo = the f16 values of the main planes, round to nearest even, saturating at 448: a pure function
+ *                  of the planes), read through x_split8 and written by the producer's epilogue through y_split8
+ *                  (or by sat_planes_f8_sidecar).  Weights: packing.pack_conv_weight_f16f8r,
+ *                    w[C_in/32][2 ceil(k/2) steps][8 planes][co_pad][16 B]; per pair of taps an f16 step (planes = (tap of the
+ *                    pair, chunk of the channel pair, channel half): hi f16 of 8 channels) and an e4m3 step (planes = (tap of the
+ *                    pair, term, chunk): term 0 e4m3(lo * 2^9), term 1 e4m3(hi * 2^-2) of 16 channels), hi / lo of w * 2^e with
+ *                    the SAT_CONV_F16X3 layer scale (largest |w| * 2^e in [2^9, 2^10)); an odd k is padded with a zero tap.
+ *                  Served by that kernel only (sat_conv1d_f8r_supported), at every batch size. */
+#define SAT_CONV_F16F8R 3
 /* split-plane formats: per 16-channel chunk and position four 16-byte units
  *   SAT_SPLIT_F16: hi f16 ch 0-7 | hi f16 ch 8-15 | lo f16 ch 0-7 | lo f16 ch 8-15
  *   SAT_SPLIT_F8 : hi f16 ch 0-7 | hi f16 ch 8-15 | e4m3(hi) 16 ch | e4m3(lo * 2^10) 16 ch */
@@ -167,7 +182,16 @@ typedef struct {
                               (sat_convtranspose_zero_taps: a k = 8, stride-4 layer has 2 taps per phase in 3 slots, mask 0x30c — the
                               pattern the kernel has an instantiation without those products for).  A promise about the WEIGHTS: a
                               mask naming non-zero weights gives wrong results.  0 (or another pattern) = multiply everything */
+  const void* x_split8;    /* SAT_CONV_F16F8R: the e4m3 sidecar of x_split (see the mode) */
+  void* y_split8;          /* also write the e4m3 sidecar of y_split (k-tap convs and up_grouped upsamplers served by the LDS-DMA ring
+                              kernel, SAT_CONV_F16X3 or SAT_CONV_F16F8R), or NULL */
+  int32_t y_split_hi_only; /* with y_split8: do not store the lo units of y_split (a tensor that is only ever an F16F8R operand) */
 } sat_conv1d_desc;
+
+/* 1 when sat_conv1d_f32 / sat_conv1d_multi_f32 serve this SAT_CONV_F16F8R descriptor (the LDS-DMA ring kernel's shapes and epilogues), else 0 */
+int sat_conv1d_f8r_supported(const sat_conv1d_desc* d);
+/* the e4m3 sidecar of SAT_SPLIT_F16 planes [B][C][T] (C % 16 == 0): x_split8[b][c/16][2][t][16 B] = e4m3(hi) | e4m3(lo * 2^10) */
+int sat_planes_f8_sidecar(const void* x_split, void* x_split8, int B, int C, int T, void* stream);
 
 /* the shapes sat_conv1d_desc.up_grouped serves (1 / 0), and the zero (tap slot, phase) pairs of ConvTranspose1d(k, stride u, padding
  * pad) seen as a polyphase conv (satools/satools/hifigan/archi.py:47-59) as the mask sat_conv1d_desc.up_zero_taps takes (u <= 4) */
@@ -283,6 +307,10 @@ int sat_hifigan_num_convs(const sat_hifigan* h);
 int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const void* w_packed, const float* bias, int mode);
 /* power-of-two descale of a conv's packed weights (sat_conv1d_desc.w_descale); 1 after sat_hifigan_set_conv */
 int sat_hifigan_set_conv_descale(sat_hifigan* h, int conv_id, float w_descale);
+/* a second packing of a ResBlock conv for SAT_CONV_F16F8R (packing.pack_conv_weight_f16f8r; same layer scale w_descale as its
+ * SAT_CONV_F16X3 packing): used by the stages option "f8_stages" names when the ring kernel serves the batch, else the
+ * SAT_CONV_F16X3 packing of sat_hifigan_set_conv is (small batches).  NULL removes it. */
+int sat_hifigan_set_conv_f8r(sat_hifigan* h, int conv_id, const void* w_packed_f8r);
 size_t sat_hifigan_workspace_bytes(const sat_hifigan* h, int B, int T);
 /* x [B][in_channels][T] -> y [B][1][T*prod(up_rates)+1]  (tanh output, archi.py:87-90) */
 int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, float* y, void* workspace,
@@ -292,7 +320,8 @@ void sat_hifigan_destroy(sat_hifigan* h);
  * default 3), "fuse_mrf" (default 1: whole MRF block of the C = 16 stage in one launch), "mrf_exact" (default 0),
  * "ups2" (default 1: the two thin upsamplers on sat_upsample2_f16x3), "multi_branch" (default 1: on the stages with C > 64 the i-th
  * conv of all MRF branches as ONE sat_conv1d_multi_f32 call — 6 launches per stage instead of 18, same bits), "split_acts",
- * "planes_residual", "branch_streams" */
+ * "planes_residual", "branch_streams"; "f8_stages" (round 5, default 0): bit i set = the ResBlock convs of stage i run as
+ * SAT_CONV_F16F8R where sat_hifigan_set_conv_f8r installed their packing and the ring kernel serves the batch */
 int sat_hifigan_set_option(sat_hifigan* h, const char* name, int value);
 
 /* final stage alone: leaky_relu(0.01) -> ReflectionPad1d((1,0)) -> Conv1d(C,1,7,pad 3) -> tanh

@@ -17,7 +17,7 @@ class SatError(RuntimeError):
     pass
 
 
-CONV_F32, CONV_F16X3, CONV_F16F8 = 0, 1, 2
+CONV_F32, CONV_F16X3, CONV_F16F8, CONV_F16F8R = 0, 1, 2, 3
 SPLIT_F16, SPLIT_F8 = 0, 1
 
 
@@ -42,6 +42,7 @@ class ConvDesc(C.Structure):
         ("x_wrap_channels", C.c_int32),
         ("w_descale", C.c_float),
         ("up_grouped", C.c_int32), ("up_zero_taps", C.c_uint32),
+        ("x_split8", C.c_void_p), ("y_split8", C.c_void_p), ("y_split_hi_only", C.c_int32),
     ]
 
 
@@ -89,6 +90,9 @@ _PROTOS = {
     "sat_resblock_pair_scaled_f16x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                                  C.c_void_p, C.c_void_p]),
     "sat_hifigan_set_conv_descale": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "sat_hifigan_set_conv_f8r": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "sat_conv1d_f8r_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "sat_planes_f8_sidecar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sat_upsample2_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sat_upsample2_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p]),
@@ -167,7 +171,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.sat_abi_version() != 4:       # 4: sat_conv1d_desc grew up_grouped / up_zero_taps
+        if l.sat_abi_version() != 5:       # 5: SAT_CONV_F16F8R; sat_conv1d_desc grew x_split8 / y_split8 / y_split_hi_only
             raise SatError("libsatools_hip.so ABI version mismatch")
         # A/B switches of the conv dispatch for whole-program measurements (bench.py under different kernels):
         # SATOOLS_AMD_CONV_OPTIONS="pair32w=0,lean_balance=2" -> sat_conv_set_option(name, value) at load time

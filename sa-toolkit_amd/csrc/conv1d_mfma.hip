@@ -1680,9 +1680,17 @@ static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* 
     a.fast_epi = d->up == 1 && ylim < (1LL << 31) && rlim < (1LL << 31) && ylim > 0;
   }
   SAT_REQUIRE(d->mode != SAT_CONV_F32 || (!d->x_split && !d->y_split && !d->no_y), "conv1d: split planes need a split-f16 mode");
-  if (d->mode == SAT_CONV_F16X3 || d->mode == SAT_CONV_F16F8) {
+  if (d->mode == SAT_CONV_F16X3 || d->mode == SAT_CONV_F16F8 || d->mode == SAT_CONV_F16F8R) {
     a.f8 = d->mode == SAT_CONV_F16F8;
+    a.f8r = d->mode == SAT_CONV_F16F8R;
     SAT_REQUIRE(!a.f8 || d->x_split, "conv1d(f16f8): the input must be split planes (SAT_SPLIT_F8)");
+    SAT_REQUIRE(!a.f8r || (d->x_split && d->x_split8 && d->y_split_format <= 1 && d->ksize >= 2 && !d->up_grouped && d->up == 1),
+                "conv1d(f16f8r): needs x_split (SAT_SPLIT_F16 planes) with its e4m3 sidecar x_split8, SAT_SPLIT_F16 output planes, ksize >= 2, up 1");
+    SAT_REQUIRE(!d->y_split8 || (d->y_split && d->mode != SAT_CONV_F16F8 && d->y_split_format <= 1), "conv1d: y_split8 is the sidecar of SAT_SPLIT_F16 planes y_split");
+    SAT_REQUIRE(!d->y_split_hi_only || d->y_split8, "conv1d: y_split_hi_only goes with y_split8");
+    a.x8 = d->x_split8;
+    a.y8 = d->y_split8;
+    a.y16_hi_only = d->y_split_hi_only;
     SAT_REQUIRE(d->y_split_format >= 0 && d->y_split_format <= 2, "conv1d: unknown y_split_format");
     a.y16_f8 = d->y_split_format == 0 ? a.f8 : d->y_split_format == 2;
     SAT_REQUIRE(d->stride == 1, "conv1d(f16x3): stride 1 only");
@@ -1733,6 +1741,8 @@ static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* 
       SAT_REQUIRE(!(d->no_y && d->accum), "conv1d: no_y with accum");
     }
     a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;   // bytes per group
+    // (SAT_CONV_F16F8R packing: [C_in / 32][2 ceil(k / 2) steps][8 planes][co_pad][16 B])
+    if (a.f8r) a.w_gs = (long long)(a.cin_pad / (2 * CI_CHUNK)) * (2 * ((a.ksize + 1) / 2)) * 8 * a.co_pad * 16;
     return SAT_OK;
   }
   SAT_REQUIRE(d->mode == SAT_CONV_F32, "conv1d: unknown mode %d", d->mode);
@@ -1745,7 +1755,16 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
   int st = conv1d_prepare(d, x, w_packed, y, a);
   if (st != SAT_OK) return st;
   hipStream_t s = (hipStream_t)stream;
+  if (d->mode == SAT_CONV_F16F8R) {
+    SAT_REQUIRE(d->groups == 1 && convring_supports(a, d->B),
+                "conv1d(f16f8r): served by the LDS-DMA ring kernel only (C_out > 64, C_in %% 32 == 0, ksize >= 3, halo <= 64, bias, plain / "
+                "ResBlock epilogue: sat_conv1d_f8r_supported)");
+    return launch_f16x3_convring(a, d->B, s);
+  }
   if (d->mode == SAT_CONV_F16X3 || d->mode == SAT_CONV_F16F8) {
+    // an e4m3 sidecar of the output is written by the epilogues of conv_ring16.hip only
+    SAT_REQUIRE(!a.y8 || a.up_grouped || (d->groups == 1 && convring_supports(a, d->B)),
+                "conv1d: y_split8 needs a shape the LDS-DMA ring kernel serves (or sat_planes_f8_sidecar after the launch)");
     // 1x1 on split planes with enough rows: the GEMM kernel (activation fragments straight from the planes)
     if (a.x16 && a.ksize == 1 && !a.f8 && !a.poly_planes && a.fast_epi && d->groups == 1 && a.rows_g >= 128 &&
         (a.cin_pad / CI_CHUNK) % 4 == 0 && g_k1_gemm) {
@@ -1799,7 +1818,7 @@ extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const
   for (int j = 0; j < n; ++j) {
     int st = conv1d_prepare(&d[j], x[j], w_packed[j], y[j], a[j]);
     if (st != SAT_OK) return st;
-    ring = ring && (d[j].mode == SAT_CONV_F16X3) && d[j].groups == 1 && d[j].B == d[0].B && convring_supports(a[j], d[j].B) && convring_same_shape(a[j], a[0]);
+    ring = ring && (d[j].mode == SAT_CONV_F16X3 || d[j].mode == SAT_CONV_F16F8R) && d[j].groups == 1 && d[j].B == d[0].B && convring_supports(a[j], d[j].B) && convring_same_shape(a[j], a[0]);
   }
   // the order of the jobs may rotate from block to block unless a job reads (accumulates into, takes its residual or
   // input from) what another one writes
@@ -1808,9 +1827,10 @@ extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const
       if (i == j) continue;
       const void* wr0 = a[i].no_y ? nullptr : (const void*)a[i].y;
       const void* wr1 = a[i].y16;
-      const void* rd[5] = {a[j].accum ? (const void*)a[j].y : nullptr, a[j].res, a[j].res16, a[j].x16, a[j].x};
-      for (const void* r : rd) writes_read = writes_read || (r && (r == wr0 || r == wr1));
-      writes_read = writes_read || (wr0 && wr0 == (a[j].no_y ? nullptr : (const void*)a[j].y)) || (wr1 && wr1 == a[j].y16);
+      const void* wr2 = a[i].y8;
+      const void* rd[6] = {a[j].accum ? (const void*)a[j].y : nullptr, a[j].res, a[j].res16, a[j].x16, a[j].x, a[j].x8};
+      for (const void* r : rd) writes_read = writes_read || (r && (r == wr0 || r == wr1 || r == wr2));
+      writes_read = writes_read || (wr0 && wr0 == (a[j].no_y ? nullptr : (const void*)a[j].y)) || (wr1 && wr1 == a[j].y16) || (wr2 && wr2 == a[j].y8);
     }
   if (ring && n > 1) return launch_f16x3_convring_multi(a, n, !writes_read, d[0].B, (hipStream_t)stream);
   // 1x1 convs of one shape on split planes (q | k | v of an attention layer): one launch of the persistent ring GEMM
@@ -1912,6 +1932,48 @@ extern "C" int sat_resblock_pair_scaled_f16x3(const sat_conv1d_desc* d, const fl
     case 7: return launch_pair<7>(a, d->B, s);
     default: return launch_pair<11>(a, d->B, s);
   }
+}
+
+extern "C" int sat_conv1d_f8r_supported(const sat_conv1d_desc* d) {
+  if (!d || d->mode != SAT_CONV_F16F8R || !d->x_split || !d->x_split8 || d->groups != 1) return 0;
+  ConvArgs a;
+  float dummy;
+  if (conv1d_prepare(d, nullptr, &dummy, d->no_y ? nullptr : &dummy, a) != SAT_OK) return 0;
+  return convring_supports(a, d->B) ? 1 : 0;
+}
+
+// e4m3 sidecar of SAT_SPLIT_F16 planes: thread = (utterance, chunk, position); reads the chunk's four 16-byte units at t, writes
+// e4m3(hi) and e4m3(lo * 2^10) of its 16 channels as two 16-byte units (HBM-streaming)
+__global__ void __launch_bounds__(256) planes_f8_sidecar_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int chunk = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const uint4* xb = x + ((long long)b * (C / 16) + chunk) * 4 * T + t;
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  const h8v h0 = __builtin_bit_cast(h8v, xb[0]), h1 = __builtin_bit_cast(h8v, xb[T]);
+  const h8v l0 = __builtin_bit_cast(h8v, xb[2LL * T]), l1 = __builtin_bit_cast(h8v, xb[3LL * T]);
+  uint4 oh, ol;
+  oh.x = pack_e4m3x4((float)h0[0], (float)h0[1], (float)h0[2], (float)h0[3]);
+  oh.y = pack_e4m3x4((float)h0[4], (float)h0[5], (float)h0[6], (float)h0[7]);
+  oh.z = pack_e4m3x4((float)h1[0], (float)h1[1], (float)h1[2], (float)h1[3]);
+  oh.w = pack_e4m3x4((float)h1[4], (float)h1[5], (float)h1[6], (float)h1[7]);
+  const float k = F8_XLO_SCALE;
+  ol.x = pack_e4m3x4((float)l0[0] * k, (float)l0[1] * k, (float)l0[2] * k, (float)l0[3] * k);
+  ol.y = pack_e4m3x4((float)l0[4] * k, (float)l0[5] * k, (float)l0[6] * k, (float)l0[7] * k);
+  ol.z = pack_e4m3x4((float)l1[0] * k, (float)l1[1] * k, (float)l1[2] * k, (float)l1[3] * k);
+  ol.w = pack_e4m3x4((float)l1[4] * k, (float)l1[5] * k, (float)l1[6] * k, (float)l1[7] * k);
+  uint4* yb = y + ((long long)b * (C / 16) + chunk) * 2 * T + t;
+  yb[0] = oh;
+  yb[T] = ol;
+}
+
+extern "C" int sat_planes_f8_sidecar(const void* x_split, void* x_split8, int B, int C, int T, void* stream) {
+  SAT_REQUIRE(x_split && x_split8, "planes_f8_sidecar: null pointer");
+  SAT_REQUIRE(B > 0 && C > 0 && T > 0 && C % 16 == 0 && B < 65536 && C / 16 < 65536, "planes_f8_sidecar: unsupported shape B=%d C=%d T=%d", B, C, T);
+  dim3 grid(ceil_div(T, 256), C / 16, B);
+  hipLaunchKernelGGL(planes_f8_sidecar_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)x_split, (uint4*)x_split8, C, T);
+  SAT_LAUNCH_CHECK("planes_f8_sidecar_kernel");
+  return SAT_OK;
 }
 
 extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, int T, float slope, int format, void* stream) {

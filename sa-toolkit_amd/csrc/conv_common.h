@@ -16,13 +16,16 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // "W_lo8 . x_hi8", lanes 32-63 the block "W_hi8 . x_lo8"
 constexpr float F8_XLO_SCALE = 1024.f;
 constexpr int F8_E_XHI = 127, F8_E_XLO = 127 - 10, F8_E_WHI = 127 - 6, F8_E_WLO = 127 - 16;
+// SAT_CONV_F16F8R (conv_ring16.hip): the weights carry the SAT_CONV_F16X3 layer scale (largest |w'| in [2^9, 2^10)), so
+// e4m3(W_hi * 2^-2) stays below 448 and e4m3(W_lo * 2^9) (|W_lo| < 2^-1) below 256
+constexpr int F8R_E_WHI = 127 + 2, F8R_E_WLO = 127 - 9;
 
 __device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
-  // OCP e4m3 saturates at 448; clamp first so an out-of-range activation degrades gracefully
-  a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
-  b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
-  c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f);
-  d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
+  // OCP e4m3 saturates at 448; clamp first so an out-of-range activation degrades gracefully (v_med3_f32: one instruction)
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
   int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
   return (unsigned)w;
@@ -67,6 +70,10 @@ struct ConvArgs {
                          // into the middle of the f16 range, so that lo = f16(w - hi) is a normal number for every weight
                          // that matters); the accumulator is multiplied by its inverse before the bias — exact
   float w_descale1;      // fused pair: the same for the first conv
+  int f8r;               // SAT_CONV_F16F8R (conv_ring16.hip): hi*hi on the f16 MFMA, the cross terms of a pair of taps on the e4m3 MFMA
+  const void* x8;        // its e4m3 sidecar of x16
+  void* y8;              // e4m3 sidecar of y16 to write, or null
+  int y16_hi_only;       // with y8: the lo units of y16 are not stored
 #ifdef SAT_STAMPS
   long long* dbg;        // diagnostic build (tools/stamp_conv.hip): per-block, per-chunk phase time stamps
 #endif
@@ -408,6 +415,12 @@ __device__ __forceinline__ void mfma16_acc(f32x4& acc, const h8& a, const h8& b)
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 #endif
 }
+// the same for the block-scaled e4m3 product of K = 128 (scale operands: one E8M0 byte per lane = its 32-byte K block)
+__device__ __forceinline__ void mfma8_acc(f32x4& acc, const i32x8& a, const i32x8& b, int scale_a, int scale_b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(scale_a), "v"(scale_b));
+#endif
+}
 __device__ __forceinline__ void mfma16_drain() {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -622,6 +635,7 @@ bool convring_ups_supports(const ConvArgs& a);
 int launch_f16x3_convring_multi(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s);   // up to three convs of one shape in one launch
 bool convring_same_shape(const ConvArgs& a, const ConvArgs& b);
 bool convring_supports(const ConvArgs& a, int B);
+bool convring_wanted(int rows_g, int T_q, int B);
 void convring_set(int v);
 void convring_set_blocks(int v);
 int convring_debug_stamps(long long* buf);

@@ -29,6 +29,16 @@ namespace sat {
 // The SIMD partners (waves k and k + 4) issue their DMA pieces at different points of a step (gemm_ring.hip).
 // Per accumulator: pairs of chunks ascending, taps ascending, lo*hi, hi*lo, hi*hi — K = 32 inside one instruction
 // associates differently from the 32x32x16 tile: agreement to f32 rounding of the accumulation, not bit for bit.
+//
+// F8 (round 5, SAT_CONV_F16F8R): 2 MFMA units per product instead of 3.  hi * hi stays on the f16 MFMA; the two cross terms
+// (2^-11 of the product) of a PAIR of taps go through ONE block-scaled e4m3 v_mfma_scale_f32_16x16x128_f8f6f4: K = 128 = lane
+// group lg -> (term lg >> 1, chunk lg & 1 of the pair) x 32 bytes = 16 channels of the first tap | 16 channels of the second.
+// The rings do not change shape.  A step is still 8 planes of ROWS 16-byte units from the W ring and reads the same X tile:
+//   E step (even): W planes (tap of the pair, chunk, half) = hi f16: 40 f16 MFMAs per wave (both taps)
+//   O step (odd):  W planes (tap of the pair, term, chunk): e4m3(W_lo * 2^9) | e4m3(W_hi * 2^-2): 20 e4m3 MFMAs — the same
+//                  640 matrix cycles; the per-lane E8M0 scales undo the powers of two exactly
+//   X tile:        [chunk][hi0 hi1 | e4m3(hi) e4m3(lo * 2^10)][XW]: units 0, 1 from the main planes, 2, 3 from the sidecar
+// An odd kernel size is padded with a zero tap (the packed weights hold it; its B operand re-reads the last tap's columns).
 // ------------------------------------------------------------------------------------------------
 
 #define SAT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -57,14 +67,18 @@ struct RingJob {
   float* y;              // f32 output (and MRF accumulator), or null
   void* y16;             // output planes of lrelu(y, y16_slope), or null
   const void* res16;     // residual as planes of lrelu(r, 1 / res16_inv), or null
+  const void* x8;        // F8: e4m3 sidecar of x16
+  void* y8;              // e4m3 sidecar of y16 to write, or null
+  long long y_bs, y_cs;  // f32 output strides (elements) — per job: a job may store into a pitched view of its own
   float w_descale, y16_slope, res16_inv, accum_div;
   int ksize, dil, pad_left, accum;
   unsigned w_bytes;
+  int nstep;             // steps per chunk pair: ksize, F8: 2 * ceil(ksize / 2)
+  int hi_only;           // the lo units of y16 are not stored
   int pad_;
 };
 struct RingArgs {
   RingJob job[3];
-  long long y_bs, y_cs;   // f32 output strides (elements)
   int cin_g, cin_pad, rows_g, co_pad, T_in, T_q;
   int njobs;        // 1..3
   int rotate;       // the order of the jobs rotates with the region (no job reads what another one writes)
@@ -83,15 +97,19 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
   const unsigned OOB = 0x80000000u;
   const int rows_g = A.rows_g, T_q = A.T_q;
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(e.y ? e.y + (long long)b * A.y_bs : (float*)e.y16), 0, e.y ? (unsigned)(rows_g * A.y_cs * 4) : 0u, 0x00020000);
+      (void*)(e.y ? e.y + (long long)b * e.y_bs : (float*)e.y16), 0, e.y ? (unsigned)(rows_g * e.y_cs * 4) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)e.bias, 0, (unsigned)(rows_g * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(e.y16 ? (char*)e.y16 + (long long)b * rows_g * T_q * 4 : (char*)e.y), 0, e.y16 ? (unsigned)(rows_g * T_q * 4) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(e.res16 ? (const char*)e.res16 + (long long)b * rows_g * T_q * 4 : (const char*)e.bias), 0,
       e.res16 ? (unsigned)(rows_g * T_q * 4) : 0u, 0x00020000);
-  const int y_rb = (int)A.y_cs * 4;
+  // e4m3 sidecar of the output planes: [chunk][e4m3(hi) | e4m3(lo * 2^10)][T_q] x 16 bytes (one byte per channel)
+  const __amdgpu_buffer_rsrc_t y8rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(e.y8 ? (char*)e.y8 + (long long)b * rows_g * T_q * 2 : (char*)e.bias), 0, e.y8 ? (unsigned)(rows_g * T_q * 2) : 0u, 0x00020000);
+  const int y_rb = (int)e.y_cs * 4;
   const bool has_y = e.y != nullptr, has_y16 = e.y16 != nullptr, has_res = e.res16 != nullptr, accum = e.accum != 0;
+  const bool has_y8 = e.y8 != nullptr, hi_only = e.hi_only != 0;
   const float descale = e.w_descale, slope = e.y16_slope, inv = e.res16_inv, div = e.accum_div;
   float bi[MT][4];
 #pragma unroll
@@ -188,8 +206,17 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
         const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, l01), false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, l23), false, false);
         const u32x4 unit = {s0[0], s1[0], s0[1], s1[1]};
-        const unsigned off = qok ? (unsigned)(((chunk * 4 + (lg >> 1) + 2 * (lg & 1)) * T_q + q) * 16) : OOB;
+        const unsigned off = (qok && !(hi_only && (lg & 1))) ? (unsigned)(((chunk * 4 + (lg >> 1) + 2 * (lg & 1)) * T_q + q) * 16) : OOB;
         __builtin_amdgcn_raw_buffer_store_b128(unit, y16rs, off, 0, 0);
+        if (has_y8) {
+          // a function of the plane values (hi, lo as f16): four channels = bytes 4 lg .. 4 lg + 3 of the chunk's unit at q
+          const unsigned x8h = pack_e4m3x4((float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]);
+          const unsigned x8l = pack_e4m3x4((float)l01[0] * F8_XLO_SCALE, (float)l01[1] * F8_XLO_SCALE, (float)l23[0] * F8_XLO_SCALE,
+                                           (float)l23[1] * F8_XLO_SCALE);
+          const unsigned off8 = qok ? (unsigned)(((chunk * 2) * T_q + q) * 16 + 4 * lg) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(x8h, y8rs, off8, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(x8l, y8rs, off8, T_q * 16, 0);
+        }
       }
     }
   }
@@ -208,6 +235,9 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
   const int rows_g = A.rows_g, T_q = A.T_q;
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)e.bias, 0, (unsigned)(rows_g), 0x00020000);      // rows_g / 4 channels
   const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc((char*)e.y16 + (long long)b * rows_g * T_q * 4, 0, (unsigned)(rows_g * T_q * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y8rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(e.y8 ? (char*)e.y8 + (long long)b * rows_g * T_q * 2 : (char*)e.bias), 0, e.y8 ? (unsigned)(rows_g * T_q * 2) : 0u, 0x00020000);
+  const bool has_y8 = e.y8 != nullptr;
   const float descale = e.w_descale, slope = e.y16_slope;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   float bi[4];                                          // channel (co_w / 64) * 16 + 4 lg + r, whatever the phase
@@ -220,6 +250,7 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     u32x4 un[4];
+    unsigned x8[2][4];                                  // e4m3 sidecar: [e4m3(hi) | e4m3(lo * 2^10)][strip], this lane's four channels
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       float u[4];
@@ -236,6 +267,10 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
       const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, l01), false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, l23), false, false);
       un[m] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      if (has_y8) {
+        x8[0][m] = pack_e4m3x4((float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]);
+        x8[1][m] = pack_e4m3x4((float)l01[0] * F8_XLO_SCALE, (float)l01[1] * F8_XLO_SCALE, (float)l23[0] * F8_XLO_SCALE, (float)l23[1] * F8_XLO_SCALE);
+      }
     }
     // 4 x 4 transposition (strip m, lane l of the quad) -> (store j, lane l): first strip bit 0 against lane bit 0, then bit 1 against bit 1
     u32x4 p[4], t[4];
@@ -264,6 +299,36 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
       const unsigned off = q < T_q ? (unsigned)((plane_base + 4 * q + (li & 3)) * 16) : OOB;
       __builtin_amdgcn_raw_buffer_store_b128(t[j], y16rs, off, 0, 0);
     }
+    if (has_y8) {
+      // the sidecar dwords through the same 4 x 4 transposition: store j of lane l = phase l & 3 of column (l & ~3) + j, bytes 4 lg ..
+#pragma unroll
+      for (int term = 0; term < 2; ++term) {
+        unsigned p8[4], t8[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned ev = x8[term][2 * h], od = x8[term][2 * h + 1];
+          const unsigned ev_x = (unsigned)__builtin_amdgcn_mov_dpp((int)ev, 0xB1, 0xF, 0xF, true);
+          const unsigned od_x = (unsigned)__builtin_amdgcn_mov_dpp((int)od, 0xB1, 0xF, 0xF, true);
+          p8[2 * h] = l0 ? od_x : ev;
+          p8[2 * h + 1] = l0 ? od : ev_x;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned lo_ = p8[h], hi_ = p8[h + 2];
+          const unsigned lo_x = (unsigned)__builtin_amdgcn_mov_dpp((int)lo_, 0x4E, 0xF, 0xF, true);
+          const unsigned hi_x = (unsigned)__builtin_amdgcn_mov_dpp((int)hi_, 0x4E, 0xF, 0xF, true);
+          t8[h] = l1 ? hi_x : lo_;
+          t8[h + 2] = l1 ? hi_ : lo_x;
+        }
+        const int base8 = ((co_w >> 6) * 2 + term) * (4 * T_q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = q_w + n * 16 + (li & ~3) + j;
+          const unsigned off8 = q < T_q ? (unsigned)((base8 + 4 * q + (li & 3)) * 16 + 4 * lg) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(t8[j], y8rs, off8, 0, 0);
+        }
+      }
+    }
   }
 }
 
@@ -276,9 +341,10 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
 // zero for that phase: those products (and the reads of their A fragments) are left out AT COMPILE TIME — the loop is unrolled over the
 // three slots (x two fragment parities).  (Skipping by a run-time mask put scalar branches around the inline-asm MFMAs: hipcc then spilled
 // 124 registers, some of them accumulators stored right behind the MFMA that writes them, which it cannot see inside the asm: wrong values.)
-template <int WR, bool STAMP = false, int UMASK = -1>
+template <int WR, bool STAMP = false, int UMASK = -1, bool F8 = false>
 __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingArgs A, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  static_assert(!(F8 && UMASK >= 0) && !(F8 && WR == 1), "F8: the plain 256 x 160 / 128 x 320 forms only");
   // WR = 4: 256 x 160, WR = 2: 128 x 320 (wave tile 64 x 80); WR = 1: 64 x 384 (wave tile 64 x 48: the 64-channel stage, whose X
   // tiles hold BOTH chunk pairs of its K)
   constexpr bool UPS = UMASK >= 0;
@@ -317,18 +383,25 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
 
   // ---- DMA state of the tile whose operands are being requested
   i32x4 xrs, wrs;
-  int KS = 1, dil = 1, NP = 1, NS = 1, seg_bytes = 0, x_chunk_bytes = 0;
+  int KS = 1, dil = 1, NP = 1, NS = 1, seg_bytes = 0, x_chunk_bytes = 0;      // (KS: steps per chunk pair — the taps, F8: 2 * ceil(taps / 2))
+  int ktaps = 1;                                                                // F8: the taps
   int d_co = 0, d_q0 = 0, d_copad = 0, d_tin = 0;      // row / first input position of the tile, padded rows, input length
   // this wave's DMA pieces: of every W slot the (chunk of the pair = wave >> 2, segment = wave & 3) row, of every X tile the
   // (chunk of the pair, plane = wave & 3) row
   const int my_w_unit = half * 4 * ROWS + idx * ROWS, my_x_unit = half * 4 * XW + idx * XW;
   auto setup = [&](const Tile& t) __attribute__((always_inline)) {
     const RingJob p = A.job[t.j];
-    KS = p.ksize, dil = p.dil;
+    KS = F8 ? p.nstep : p.ksize, dil = p.dil, ktaps = p.ksize;
     NP = A.cin_pad / (2 * CI_CHUNK), NS = NP * KS;
     seg_bytes = A.co_pad * 16;
-    x_chunk_bytes = 4 * A.T_in * 16;
-    xrs = dma_rsrc((const char*)p.x16 + (long long)t.b * A.cin_g * A.T_in * 4, (unsigned)(A.cin_g * A.T_in * 4));
+    if (F8 && idx >= 2) {
+      // this wave's X rows are the sidecar's: units (e4m3(hi), e4m3(lo * 2^10)) of its chunk
+      x_chunk_bytes = 2 * A.T_in * 16;
+      xrs = dma_rsrc((const char*)p.x8 + (long long)t.b * A.cin_g * A.T_in * 2, (unsigned)(A.cin_g * A.T_in * 2));
+    } else {
+      x_chunk_bytes = 4 * A.T_in * 16;
+      xrs = dma_rsrc((const char*)p.x16 + (long long)t.b * A.cin_g * A.T_in * 4, (unsigned)(A.cin_g * A.T_in * 4));
+    }
     wrs = dma_rsrc(p.w, p.w_bytes);
     d_co = t.co_b, d_q0 = t.q_b - p.pad_left, d_copad = A.co_pad, d_tin = A.T_in;
   };
@@ -336,15 +409,16 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
   // registers across the K loop they were what the allocator spilled INTO the loop)
   auto voff_w = [&](int j) __attribute__((always_inline)) {
     const int row = d_co + j * 64 + lane;
-    return row < d_copad ? (unsigned)(row * 16 + idx * seg_bytes) : 0x80000000u;
+    return row < d_copad ? (unsigned)(row * 16 + (F8 ? 0 : idx * seg_bytes)) : 0x80000000u;
   };
   auto voff_x = [&](int k) __attribute__((always_inline)) {
     const int xi = d_q0 + k * 64 + lane;
-    return (xi >= 0 && xi < d_tin) ? (unsigned)((idx * d_tin + xi) * 16) : 0x80000000u;
+    return (xi >= 0 && xi < d_tin) ? (unsigned)(((F8 ? (idx & 1) : idx) * d_tin + xi) * 16) : 0x80000000u;
   };
   auto issue_w = [&](int pp, int t, int slot) __attribute__((always_inline)) {
     const uint4* dst = lds4 + W0 + slot * W_UNITS + my_w_unit;
-    const unsigned soff = (unsigned)((((2 * pp + half) * KS + t) * 4) * seg_bytes);
+    // F8: packed [pair][step][plane = wave][row]; else [chunk][tap][plane][row]
+    const unsigned soff = F8 ? (unsigned)(((pp * KS + t) * 8 + wave) * seg_bytes) : (unsigned)((((2 * pp + half) * KS + t) * 4) * seg_bytes);
 #pragma unroll
     for (int j = 0; j < PW; ++j) lds_dma16(dst + j * 64, wrs, voff_w(j), soff);
   };
@@ -367,12 +441,25 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
   };
 
   // fragment addresses (units): lane (li, lg) reads chunk lg >> 1, half lg & 1; lo planes 2 segments further
-  const int a_lane = (lg >> 1) * 4 * ROWS + (lg & 1) * ROWS + wr * 64 + li;
+  // (F8: W plane = 4 (tap of the pair) + lg in both kinds of step; the e4m3 B unit of lane group lg = plane 2 + term of chunk lg & 1)
+  const int a_lane = F8 ? lg * ROWS + wr * 64 + li : (lg >> 1) * 4 * ROWS + (lg & 1) * ROWS + wr * 64 + li;
   const int b_lane = (lg >> 1) * 4 * XW + (lg & 1) * XW + wc * (16 * NT) + li;
+  const int b_lane8 = (lg & 1) * 4 * XW + (2 + (lg >> 1)) * XW + wc * (16 * NT) + li;
+  // E8M0 scales (term 0: W_lo8 . x_hi8, term 1: W_hi8 . x_lo8).  The instruction numbers k = 16 g + j for bytes 0-15 of lane group g and
+  // 64 + 16 g + j for bytes 16-31, and takes the scale of its 32-wide block b from lane group b (measured: tools/scratch/probe_mfma_scale.hip):
+  // block 0 = first halves of groups 0, 1 (term 0, first tap), block 1 = first halves of groups 2, 3 (term 1), blocks 2, 3 the second tap's
+  const int sc_a = (lg & 1) ? F8R_E_WHI : F8R_E_WLO, sc_b = (lg & 1) ? F8_E_XLO : F8_E_XHI;
   h8 fa[2][MT][2], fb[2][2];
+  // F8: E steps use fa[0] / fb (taps 0, 1 of the pair), O steps the 32-byte forms
+  i32x8 fa8[MT], fb8[2];
+  typedef int i32x4v __attribute__((ext_vector_type(4)));
+  auto read8 = [&](i32x8& dst, const uint4* p0, const uint4* p1) __attribute__((always_inline)) {
+    const i32x4v lo = __builtin_bit_cast(i32x4v, *p0), hi = __builtin_bit_cast(i32x4v, *p1);
+    dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
   auto read_a = [&](h8 (&dst)[2], const uint4* wb, int m) __attribute__((always_inline)) {
     dst[0] = __builtin_bit_cast(h8, wb[m * 16]);
-    dst[1] = __builtin_bit_cast(h8, wb[m * 16 + 2 * ROWS]);
+    dst[1] = __builtin_bit_cast(h8, wb[m * 16 + (F8 ? 4 : 2) * ROWS]);
   };
   auto read_b = [&](h8 (&dst)[2], const uint4* xb, int n) __attribute__((always_inline)) {
     dst[0] = __builtin_bit_cast(h8, xb[n * 16]);
@@ -444,13 +531,96 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     ++s, pp = p1, t = t1, ws = ws1;
     if (++t3 == KS) t3 = 0, ++p3;
   };
+  // ---- F8: CUR = 0 the E step of a pair of taps (hi * hi of both taps on the f16 MFMA: 40 per wave), CUR = 1 its O step (both
+  // cross terms of both taps in one e4m3 MFMA of K = 128: 20 per wave, the same matrix cycles).  Same rings, same waits.
+  auto body8 = [&](auto cur, auto late_c, auto more_c) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(cur)::value;
+    constexpr bool LATE = decltype(late_c)::value, MORE = decltype(more_c)::value;
+    constexpr int N_HAND = LATE ? NT / 2 : 0;
+    static_assert(MT == NT - 1 || !F8, "one A row of the next step per column 1 .. NT - 1");
+    if constexpr (MORE) {
+      long long w0 = 0;
+      if constexpr (STAMP) w0 = cr_clock();
+      if (s + 2 < NS) {
+        if (t == 1 && pp >= 1 && pp + 1 < NP) SAT_WAIT_VM_LGKM0(PW + PX);
+        else SAT_WAIT_VM_LGKM0(PW);
+      } else {
+        SAT_WAIT_VM_LGKM0(0);
+      }
+      asm volatile("s_barrier" ::: "memory");
+      if constexpr (STAMP) st_wait += cr_clock() - w0;
+    }
+    int t1 = t + 1, p1 = pp;
+    if (t1 == KS) t1 = 0, p1 = pp + 1;
+    const int ws1 = ws == 2 ? 0 : ws + 1;
+    const uint4* wnext = lds4 + W0 + ws1 * W_UNITS + a_lane;
+    // columns of the two taps of this step's pair (the zero tap that pads an odd kernel re-reads the last tap's columns: finite
+    // values against zero weights)
+    const int tp = t & ~1;
+    const int sh0 = tp * dil, sh1 = (tp + 1 < ktaps ? tp + 1 : tp) * dil;
+    const uint4* x16 = lds4 + (pp & 1) * X_UNITS + b_lane;
+    const uint4* x8 = lds4 + (pp & 1) * X_UNITS + b_lane8;
+    // (O step: the next step is the E step of pair (p1, taps t1, t1 + 1))
+    const int nh0 = t1 * dil, nh1 = (t1 + 1 < ktaps ? t1 + 1 : t1) * dil;
+    const uint4* xn16 = lds4 + (p1 & 1) * X_UNITS + b_lane;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (n == N_HAND && !(STAMP && (A.diag & 8))) {
+        if (t == 0 && pp >= 1 && pp + 1 < NP) issue_x(pp + 1);
+        if (s + 3 < NS) issue_w(p3, t3, ws);
+      }
+      if (!(STAMP && (A.diag & 16))) {
+        if constexpr (CUR == 0) {
+          if (n + 1 < NT) {
+            fb[(n + 1) & 1][0] = __builtin_bit_cast(h8, x16[(n + 1) * 16 + sh0]);
+            fb[(n + 1) & 1][1] = __builtin_bit_cast(h8, x16[(n + 1) * 16 + sh1]);
+          } else {
+            read8(fb8[0], x8 + sh0, x8 + sh1);          // column 0 of the O step that always follows
+          }
+          if (n >= 1) read8(fa8[n - 1], wnext + (n - 1) * 16, wnext + (n - 1) * 16 + 4 * ROWS);
+        } else {
+          if (n + 1 < NT) {
+            read8(fb8[(n + 1) & 1], x8 + (n + 1) * 16 + sh0, x8 + (n + 1) * 16 + sh1);
+          } else if constexpr (MORE) {
+            fb[0][0] = __builtin_bit_cast(h8, xn16[nh0]);
+            fb[0][1] = __builtin_bit_cast(h8, xn16[nh1]);
+          }
+          if constexpr (MORE) {
+            if (n >= 1) read_a(fa[0][n - 1], wnext, n - 1);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if constexpr (CUR == 0) {
+          mfma16_acc(acc[m][n], fa[0][m][0], fb[n & 1][0]);
+          mfma16_acc(acc[m][n], fa[0][m][1], fb[n & 1][1]);
+        } else {
+          mfma8_acc(acc[m][n], fa8[m], fb8[n & 1], sc_a, sc_b);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ++s, pp = p1, t = t1, ws = ws1;
+    if (++t3 == KS) t3 = 0, ++p3;
+  };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
   using NOT = std::integral_constant<int, -1>;
   auto loop = [&](auto late_c) __attribute__((always_inline)) {
     using L = decltype(late_c);
-    if constexpr (UPS) {
+    if constexpr (F8) {
+      // NS = NP x 2 ceil(taps / 2): E and O steps alternate, the last step is an O step
+      while (s + 2 < NS) {
+        body8(I0{}, L{}, std::true_type{});
+        body8(I1{}, L{}, std::true_type{});
+      }
+      body8(I0{}, L{}, std::true_type{});
+      body8(I1{}, L{}, std::false_type{});
+    } else if constexpr (UPS) {
       // three slots x two fragment parities: NS = 3 NP steps, NP even
       auto six = [&](auto more_last) __attribute__((always_inline)) {
         body(I0{}, L{}, std::true_type{}, I0{});
@@ -492,7 +662,12 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     asm volatile("s_barrier" ::: "memory");
 #pragma unroll
     for (int m = 0; m < MT; ++m) read_a(fa[0][m], lds4 + W0 + a_lane, m);
-    read_b(fb[0], lds4 + b_lane, 0);
+    if constexpr (F8) {
+      fb[0][0] = __builtin_bit_cast(h8, lds4[b_lane]);                             // taps 0 and 1 of pair 0, column 0
+      fb[0][1] = __builtin_bit_cast(h8, lds4[b_lane + (ktaps > 1 ? dil : 0)]);
+    } else {
+      read_b(fb[0], lds4 + b_lane, 0);
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -582,8 +757,10 @@ static int cu_count() {
 // tiles for three quarters of the CUs (one 8-wave block per CU: a batch of a few utterances is better served by the small
 // tiles of conv_lean.hip).  Option "convring": 0 = off, 1 = on (default), + 32 = whatever the number of tiles
 bool convring_supports(const ConvArgs& a, int B) {
-  if (!(g_convring & 1)) return false;
+  if (!(g_convring & 1) && !a.f8r) return false;
   if (!(a.x16 && !a.f8 && !a.y16_f8 && !a.poly_planes && !a.k1_wrap && a.fast_epi && a.up == 1 && a.stride == 1)) return false;
+  if (a.f8r && !a.x8) return false;
+  if (a.y8 && !a.y16) return false;
   // (rows <= 64: the kernel has a 64 x 384 layout, WR = 1, whose X tiles hold both chunk pairs of the 64-channel stage — measured SLOWER
   // than the register-staged tile there, 183-189 against 150 us at 11 taps: 6.6 tiles per block with 112 KB of X each; not dispatched)
   if (!epilogue16_supports(a) || a.ksize < 3 || a.cin_g % 32 != 0 || a.rows_g <= 64) return false;
@@ -593,25 +770,34 @@ bool convring_supports(const ConvArgs& a, int B) {
   if (halo > 64) return false;                     // (X tiles: 160 + 64, 320 + 64, 384 + 64 columns)
   const long long tiles = a.rows_g > 128 ? (long long)ceil_div(a.rows_g, 256) * ceil_div(a.T_q, 160) * B
                           : a.rows_g > 64 ? (long long)ceil_div(a.T_q, 320) * B : (long long)ceil_div(a.T_q, 384) * B;
+  // (SAT_CONV_F16F8R weights are packed for this kernel alone: at every number of tiles)
+  return a.f8r || (g_convring & 32) || tiles * 4 >= (long long)cu_count() * 3;
+}
+
+// what hifigan.hip asks before it picks the SAT_CONV_F16F8R packing of a stage: would the f16x3 conv of this shape run on the ring?
+bool convring_wanted(int rows_g, int T_q, int B) {
+  if (!(g_convring & 1) || rows_g <= 64) return false;
+  const long long tiles = rows_g > 128 ? (long long)ceil_div(rows_g, 256) * ceil_div(T_q, 160) * B : (long long)ceil_div(T_q, 320) * B;
   return (g_convring & 32) || tiles * 4 >= (long long)cu_count() * 3;
 }
 
 // jobs of one shape (channels, lengths, batch): what one launch can walk
+// (the f32 output strides are per job: RingJob.y_bs / y_cs)
 bool convring_same_shape(const ConvArgs& a, const ConvArgs& b) {
   return a.cin_g == b.cin_g && a.cin_pad == b.cin_pad && a.rows_g == b.rows_g && a.co_pad == b.co_pad && a.T_in == b.T_in && a.T_q == b.T_q &&
-         (a.no_y || b.no_y || (a.y_bs == b.y_bs && a.y_cs == b.y_cs));
+         a.f8r == b.f8r;
 }
 
 // ConvTranspose1d(stride 4) as a polyphase conv whose rows are ordered (16-channel group, phase, channel) — sat_conv1d_desc.up_grouped:
 // only this kernel reads that order (256-row tiles: rows > 128), whatever the number of tiles
 bool convring_ups_supports(const ConvArgs& a) {
-  if (!(a.x16 && a.y16 && a.no_y && !a.f8 && !a.y16_f8 && !a.k1_wrap && a.up == 4 && a.stride == 1)) return false;
+  if (!(a.x16 && a.y16 && a.no_y && !a.f8 && !a.f8r && !a.y16_f8 && !a.k1_wrap && a.up == 4 && a.stride == 1)) return false;
   if (a.ksize != 3 || a.cin_g % 64 != 0 || a.cin_pad != a.cin_g || a.rows_g <= 128 || a.rows_g % 64 != 0 || !a.bias) return false;
   if (a.ch_scale || a.relu || a.gelu || a.res || a.res16 || a.res_after || a.accum) return false;
   return (a.ksize - 1) * a.dil <= 64;
 }
 
-template <int WR, int UMASK = -1>
+template <int WR, int UMASK = -1, bool F8 = false>
 static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s) {
   constexpr int WC = 8 / WR, NT = WR == 1 ? 3 : 5, ROWS = 64 * WR, COLS = 16 * NT * WC, XW = WR == 4 ? 224 : WR == 2 ? 384 : 448;
   RingArgs A{};
@@ -623,8 +809,10 @@ static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipS
     r.w_descale = a[j].w_descale, r.y16_slope = a[j].y16_slope, r.res16_inv = a[j].res16_inv, r.accum_div = a[j].accum_div;
     r.ksize = a[j].ksize, r.dil = a[j].dil, r.pad_left = a[j].pad_left, r.accum = a[j].accum;
     r.w_bytes = (unsigned)a[j].w_gs;
+    r.y_bs = a[j].y_bs, r.y_cs = a[j].y_cs;
+    r.x8 = a[j].x8, r.y8 = a[j].y8, r.hi_only = a[j].y16_hi_only && a[j].y8;
+    r.nstep = F8 ? 2 * ((a[j].ksize + 1) / 2) : a[j].ksize;
   }
-  A.y_bs = a[0].y_bs, A.y_cs = a[0].y_cs;
   A.cin_g = a[0].cin_g, A.cin_pad = a[0].cin_pad, A.rows_g = a[0].rows_g, A.co_pad = a[0].co_pad, A.T_in = a[0].T_in, A.T_q = a[0].T_q;
   A.njobs = njobs;
   A.rotate = rotate && njobs > 1;
@@ -636,8 +824,8 @@ static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipS
   const size_t lds_bytes = ((size_t)2 * 8 * XW + (size_t)3 * 8 * ROWS) * 16;
   // one block per CU (the LDS of a block is most of a CU's): a block walks regions blockIdx.x, + gridDim.x, ...
   const int grid = std::min(A.n_vb, std::max(8, (g_convring_blocks ? std::min(g_convring_blocks, cu_count()) : cu_count()) / 8 * 8));
-  auto kern = conv1d_f16x3_ring16_kernel<WR, false, UMASK>;
-  auto kern_st = conv1d_f16x3_ring16_kernel<WR, UMASK < 0, UMASK>;      // (no stamped build of the upsampler form)
+  auto kern = conv1d_f16x3_ring16_kernel<WR, false, UMASK, F8>;
+  auto kern_st = conv1d_f16x3_ring16_kernel<WR, UMASK < 0, UMASK, F8>;      // (no stamped build of the upsampler form)
   static std::atomic<uint64_t> attr_done{0};      // per device
   int dev;
   if (attr_needed_on_current_device(attr_done, &dev)) {
@@ -647,11 +835,12 @@ static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipS
   }
   if (g_convring_dbg) hipLaunchKernelGGL(kern_st, dim3(grid), dim3(512), lds_bytes, s, A, g_convring_dbg);
   else hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, s, A, (long long*)nullptr);
-  SAT_LAUNCH_CHECK("conv1d_f16x3_ring16_kernel");
+  SAT_LAUNCH_CHECK(F8 ? "conv1d_f16x3_ring16_kernel (F8: e4m3 cross terms)" : "conv1d_f16x3_ring16_kernel");
   return SAT_OK;
 }
 
 int launch_f16x3_convring_multi(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s) {
+  if (a[0].f8r) return a[0].rows_g > 128 ? launch_convring<4, -1, true>(a, njobs, rotate, B, s) : launch_convring<2, -1, true>(a, njobs, rotate, B, s);
   return a[0].rows_g > 128 ? launch_convring<4>(a, njobs, rotate, B, s) : launch_convring<2>(a, njobs, rotate, B, s);
 }
 

@@ -10,6 +10,8 @@
 
 namespace sat {
 
+bool convring_wanted(int rows_g, int T_q, int B);      // conv_ring16.hip: would a k-tap conv of this shape run on the LDS-DMA ring?
+
 // polyphase view of ConvTranspose1d(k, stride u, padding pad): output t = q*u + r reads input
 // positions s = q + delta with tap j = r + pad - u*delta, 0 <= j < k.  Returns the tap window
 // [dmin, dmax] over all phases.
@@ -130,6 +132,7 @@ struct sat_hifigan {
     const float* bias = nullptr;
     int mode = SAT_CONV_F32;
     float descale = 1.f;      // power-of-two descale of the packed weights (sat_conv1d_desc.w_descale)
+    const void* w8 = nullptr; // second packing for SAT_CONV_F16F8R (same layer scale), or null
   };
   std::vector<Conv> convs;
   int fuse_pairs = 1;
@@ -139,6 +142,8 @@ struct sat_hifigan {
                              // to it, and measured 5 % faster: fewer live registers); 1 = kept in f32 registers
   int ups_ring = 0;          // the stride-4 upsamplers' packed rows are grouped by phase (sat_conv1d_desc.up_grouped): set by the packer's side
   int ups2 = 1;              // the thin upsamplers (C_in = 64, 32; k 4, stride 2) on the streaming kernel of ups2.hip
+  int f8_stages = 0;         // bit i: the ResBlock convs of stage i as SAT_CONV_F16F8R (e4m3 cross terms on the ring kernel) where their second packing is
+                             // installed and the ring kernel serves the batch
   int multi_branch = 1;      // thick stages (C > 64): the i-th conv of all MRF branches as one sat_conv1d_multi_f32 call (one launch where the ring kernel serves them)
   int fuse_mrf = 1;          // a whole MRF block (all branches, all steps, the mean) as one launch where mrf.hip supports the stage (C = 16)
   int split_acts = 1;
@@ -197,6 +202,14 @@ extern "C" int sat_hifigan_set_conv(sat_hifigan* h, int conv_id, const void* w_p
   h->convs[conv_id].bias = bias;
   h->convs[conv_id].mode = mode;
   h->convs[conv_id].descale = 1.f;
+  h->convs[conv_id].w8 = nullptr;
+  return SAT_OK;
+}
+
+extern "C" int sat_hifigan_set_conv_f8r(sat_hifigan* h, int conv_id, const void* w_packed_f8r) {
+  SAT_REQUIRE(h && conv_id > h->n_ups() && conv_id < h->id_post(), "hifigan_set_conv_f8r: only the ResBlock convs carry a SAT_CONV_F16F8R packing");
+  SAT_REQUIRE(!w_packed_f8r || h->convs[conv_id].mode == SAT_CONV_F16X3, "hifigan_set_conv_f8r: next to a SAT_CONV_F16X3 packing only");
+  h->convs[conv_id].w8 = w_packed_f8r;
   return SAT_OK;
 }
 
@@ -271,6 +284,7 @@ extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int valu
   if (std::string(name) == "fuse_pair64") { h->fuse_pair64 = value; return SAT_OK; }
   if (std::string(name) == "fuse_mrf") { h->fuse_mrf = value; return SAT_OK; }
   if (std::string(name) == "multi_branch") { h->multi_branch = value; return SAT_OK; }
+  if (std::string(name) == "f8_stages") { h->f8_stages = value; return SAT_OK; }
   if (std::string(name) == "mrf_exact") { h->mrf_exact = value; return SAT_OK; }
   if (std::string(name) == "ups2") { h->ups2 = value; return SAT_OK; }
   if (std::string(name) == "ups_ring") { h->ups_ring = value; return SAT_OK; }
@@ -375,6 +389,17 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
       const int u = h->up_rates[i], k = h->up_kernels[i];
       const int Cn = C / 2, Tn = Tc * u;
       const bool last_stage = i == h->n_ups() - 1;
+      // this stage's ResBlock convs with e4m3 cross terms (SAT_CONV_F16F8R): the one-launch-per-conv path of the thick stages, every
+      // conv's second packing installed, and a batch the ring kernel would serve anyway (small batches keep the f16x3 tiles)
+      bool use_f8 = ((h->f8_stages >> i) & 1) && h->multi_branch && planes_res_all && !(side && i < h->branch_streams) && nk >= 2 && nk <= 3 &&
+                    Cn > 64 && Cn % 32 == 0 && convring_wanted(Cn, Tn, B);
+      for (int j = 0; j < nk && use_f8; ++j)
+        for (int pair = 0; pair < 3; ++pair)
+          use_f8 = use_f8 && h->convs[h->id_rb(i, j, pair, 0)].w8 && h->convs[h->id_rb(i, j, pair, 1)].w8 &&
+                   (h->rb_kernels[j] - 1) * h->rb_dil[j * 3 + pair] <= 64 && h->rb_kernels[j] >= 3;
+      // e4m3 sidecars (half a slot each: 2 bytes per element) in the slots of the f32 twins this pipeline does not write
+      void* Hs8 = ws + 0 * slot;
+      auto br8 = [&](int j, int which) { return ws + (size_t)(5 + j * 5 + (which < 2 ? 1 : 3)) * slot + (which == 1 ? slot / 2 : 0); };   // 0 T1, 1 RA, 2 RB
       {
         int lo, hi;
         phase_window(k, u, (k - u) / 2, &lo, &hi);
@@ -404,6 +429,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
           d.no_y = 1;
           d.up_grouped = 1;
           d.up_zero_taps = sat_convtranspose_zero_taps(k, u, (k - u) / 2);
+          if (use_f8) d.y_split8 = Hs8;        // the ring's upsampler epilogue writes the sidecar next to the planes
           s = sat_conv1d_f32(&d, nullptr, h->convs[h->id_up(i)].w, nullptr, stream);
           if (s != SAT_OK) return s;
         } else if (direct) {
@@ -416,6 +442,10 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
           s = sat_conv1d_f32(&d, nullptr, h->convs[h->id_up(i)].w, Hf, stream);
           if (s != SAT_OK) return s;
           s = sat_act_split_f32(Hf, Hs, B, Cn, Tn, 0.1f, cmode == SAT_CONV_F16F8 ? SAT_SPLIT_F8 : SAT_SPLIT_F16, stream);
+          if (s != SAT_OK) return s;
+        }
+        if (use_f8 && !d.y_split8) {
+          s = sat_planes_f8_sidecar(Hs, Hs8, B, Cn, Tn, stream);      // (Hf is dead behind the split pass)
           if (s != SAT_OK) return s;
         }
       }
@@ -463,6 +493,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         if (h->multi_branch && planes_res && !fan && nk >= 2 && nk <= 3 && Cn > 64) {
           const float* xnull[3] = {nullptr, nullptr, nullptr};
           const void* rs[3] = {Hs, Hs, Hs};
+          const void* rs8[3] = {Hs8, Hs8, Hs8};
           for (int pair = 0; pair < 3; ++pair) {
             sat_conv1d_desc d1[3], d2[3];
             const void* w1[3];
@@ -470,6 +501,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             float* y1[3] = {nullptr, nullptr, nullptr};
             float* y2[3];
             void* dst_s[3];
+            void* dst8[3] = {nullptr, nullptr, nullptr};
             for (int j = 0; j < nk; ++j) {
               const int rk = h->rb_kernels[j], dil = h->rb_dil[j * 3 + pair];
               const auto& cv1 = h->convs[h->id_rb(i, j, pair, 0)];
@@ -489,6 +521,13 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
               d1[j].y_split_slope = 0.1f;
               d1[j].no_y = 1;
               w1[j] = cv1.w;
+              if (use_f8) {
+                d1[j].mode = SAT_CONV_F16F8R;
+                d1[j].x_split8 = rs8[j];
+                d1[j].y_split8 = br8(j, 0);
+                d1[j].y_split_hi_only = 1;          // the inner activation is only ever a matrix operand
+                w1[j] = cv1.w8;
+              }
               d2[j] = base_desc(Cn, Cn, Tn, Tn, 1);
               d2[j].ksize = rk;
               d2[j].dilation = 1;
@@ -515,12 +554,18 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
               }
               d2[j].y_split = dst_s[j];
               w2[j] = cv2.w;
+              if (use_f8) {
+                d2[j].mode = SAT_CONV_F16F8R;
+                d2[j].x_split8 = br8(j, 0);
+                if (pair < 2) dst8[j] = (rs8[j] == br8(j, 1)) ? br8(j, 2) : br8(j, 1), d2[j].y_split8 = dst8[j];
+                w2[j] = cv2.w8;
+              }
             }
             int s = sat_conv1d_multi_f32(d1, xnull, w1, y1, nk, stream);
             if (s != SAT_OK) return s;
             s = sat_conv1d_multi_f32(d2, xnull, w2, y2, nk, stream);
             if (s != SAT_OK) return s;
-            for (int j = 0; j < nk; ++j) rs[j] = dst_s[j];
+            for (int j = 0; j < nk; ++j) rs[j] = dst_s[j], rs8[j] = dst8[j];
           }
           void* t = XS;
           XS = XSn;

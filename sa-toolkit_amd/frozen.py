@@ -15,7 +15,8 @@ import torch.nn as nn
 
 from . import _lib
 
-FORMAT = "satools_amd.frozen/1"
+FORMAT = "satools_amd.frozen/2"      # 2: plain build arguments only, SAT_CONV_F16F8R second packings
+OLD_FORMATS = ("satools_amd.frozen/1",)
 
 
 def _enc(x):
@@ -40,14 +41,18 @@ def _enc(x):
 
 
 def _plain(x):
-    """build arguments as plain python (what `torch.load(weights_only=True)` accepts): anything else is stored as its str()"""
+    """build arguments as plain python (what `torch.load(weights_only=True)` accepts).  Anything else is REFUSED at export time:
+    a value stored as its str() would come back with another type into `anonymizer.build` (a lossy export nobody notices)."""
     if x is None or isinstance(x, (bool, int, float, str)):
         return x
     if isinstance(x, (list, tuple)):
         return [_plain(v) for v in x]
     if isinstance(x, dict):
         return {str(k): _plain(v) for k, v in x.items()}
-    return str(x)
+    import pathlib
+    if isinstance(x, pathlib.PurePath):             # (a path is its string: `build` only ever formats / opens it)
+        return str(x)
+    raise _lib.SatError(f"export_frozen: build argument of type {type(x).__name__} cannot be stored as plain data ({x!r})")
 
 
 def _dec(x, device, mods=None):
@@ -99,7 +104,10 @@ def export_frozen(model, path):
             "build_args": _plain(dict(model._build_args)), "utt2spk": {str(k): str(v) for k, v in dict(model.utt2spk).items()},
             "generator": {"packed": _enc(gen._packed), "modes": list(gen._packed_modes), "precision": gen.precision,
                           # row order of the stride-4 upsamplers' packed weights (hifigan.py: ups_ring); absent in older files = 0
-                          "ups_grouped": int(bool(gen.__dict__.get("_packed_ups_grouped", False)))},
+                          "ups_grouped": int(bool(gen.__dict__.get("_packed_ups_grouped", False))),
+                          # second packings of the thick stages' ResBlock convs for SAT_CONV_F16F8R ("f16f8r"), {conv id: tensor}
+                          "packed8": _enc({str(k): v for k, v in (gen.__dict__.get("_packed8") or {}).items()}),
+                          "f8_stages": int(gen.f8_stages)},
             "extractor": {"class": type(ext).__name__, "precision": ext.precision, "cache": _enc(ext._cache)}}
     if hasattr(ext, "_prepare_full"):
         full = ext._prepare_full(dev)
@@ -120,7 +128,13 @@ def load_frozen(path, device="cuda"):
     from .asrbn import TDNNFBatchNormParams
     # plain containers, numbers, strings and tensors only (_enc refuses anything else at export): the restricted unpickler
     # is enough, and a file from elsewhere cannot run code at load time
-    blob = torch.load(path, weights_only=True, map_location="cpu")
+    try:
+        blob = torch.load(path, weights_only=True, map_location="cpu")
+    except Exception as e:                          # a file of an older export may hold objects the restricted unpickler refuses
+        raise _lib.SatError(f"{path}: cannot be read as a {FORMAT} file ({type(e).__name__}: {e}); re-export it with this version "
+                            "(export_frozen)") from e
+    if isinstance(blob, dict) and blob.get("format") in OLD_FORMATS:
+        raise _lib.SatError(f"{path}: written as {blob.get('format')}; re-export it with this version (export_frozen writes {FORMAT})")
     if not isinstance(blob, dict) or blob.get("format") != FORMAT or blob.get("kind") != "anonymizer":
         raise _lib.SatError(f"{path}: not a {FORMAT} anonymizer file")
     device = torch.device(device)
@@ -133,8 +147,10 @@ def load_frozen(path, device="cuda"):
     gen.precision = blob["generator"]["precision"]
     if len(blob["generator"]["packed"].get("__l__", [])) != len(blob["generator"]["modes"]):
         raise _lib.SatError(f"{path}: packed convolutions and modes differ in number")
+    gen.f8_stages = int(blob["generator"].get("f8_stages", gen.f8_stages))
+    p8 = _dec(blob["generator"].get("packed8"), device) or {}
     gen._install_packed(_dec(blob["generator"]["packed"], device), blob["generator"]["modes"],
-                        ups_grouped=bool(blob["generator"].get("ups_grouped", 0)))
+                        ups_grouped=bool(blob["generator"].get("ups_grouped", 0)), packed8={int(k): v for k, v in p8.items()})
     gen.__dict__["_frozen"] = True
     e = blob["extractor"]
     if type(ext).__name__ != e["class"]:

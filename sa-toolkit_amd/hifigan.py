@@ -16,10 +16,14 @@ from .params import CoreHifiGanParams
 
 class CoreHifiGan(CoreHifiGanParams):
     #: matrix-product arithmetic of the generator convs: "f16x3" (split-f16 on the f16 matrix cores,
-    #: ~2^-21 relative per product), "f16f8" (hi*hi in f16, the cross terms on the block-scaled e4m3
-    #: MFMA, ~2^-15 per product: 3e-6 RMS on the waveform against 1.5e-7) or "f32" (exact f32 MFMA).
+    #: ~2^-21 relative per product), "f16f8r" (round 5: "f16x3" with the ResBlock convs of the THICK stages — C >= 128, the
+    #: LDS-DMA ring kernel — computing hi*hi in f16 and both cross terms on the block-scaled e4m3 MFMA: 2 MFMA units per
+    #: product instead of 3, ~2^-15 per product on those layers; batches too small for the ring kernel run "f16x3"),
+    #: "f16f8" (round 1: every conv that way on the register-staged tile, slower than "f16x3") or "f32" (exact f32 MFMA).
     #: The output stage is always f32.
     precision = os.environ.get("SATOOLS_AMD_GEN_PRECISION", "f16x3")
+    #: "f16f8r": bit i = stage i may run its ResBlock convs with e4m3 cross terms (default: every stage the ring kernel serves)
+    f8_stages = int(os.environ.get("SATOOLS_AMD_GEN_F8_STAGES", "255"))
     #: hand activations between layers as split planes (csrc/hifigan.hip); 0 = f32 tensors
     split_acts = int(os.environ.get("SATOOLS_AMD_GEN_SPLIT_ACTS", "1"))
     #: number of leading generator stages whose three resblock branches run on separate HIP streams: -2 % for a
@@ -65,7 +69,7 @@ class CoreHifiGan(CoreHifiGanParams):
         ps = self.__dict__.get("_flat_params")
         if ps is None:
             ps = self.__dict__["_flat_params"] = list(self.parameters())
-        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf, self.ups2, self.multi_branch, self.ups_ring) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf, self.ups2, self.multi_branch, self.ups_ring, self.f8_stages) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def invalidate(self):
         self._packed_key = None
@@ -91,13 +95,13 @@ class CoreHifiGan(CoreHifiGanParams):
         if self._packed_key == key and self._handle is not None:
             return
         _lib.cache_rebuild_begin(device, self._packed is not None)
-        packed, modes = [], []
+        packed, modes, packed8 = [], [], {}
         mods = self._conv_modules()
         n_ups = len(self.ups)
         for i, m in enumerate(mods):
             w = m.folded_weight().to(device=device, dtype=torch.float32)
             b = m.bias.detach().to(device=device, dtype=torch.float32).contiguous()
-            if self.precision not in ("f16x3", "f16f8", "f32"):
+            if self.precision not in ("f16x3", "f16f8", "f16f8r", "f32"):
                 raise _lib.SatError(f"unknown generator precision {self.precision!r}")
             split = self.precision != "f32"
             mode = _lib.CONV_F16X3 if split else _lib.CONV_F32
@@ -114,17 +118,22 @@ class CoreHifiGan(CoreHifiGanParams):
                 wp = pack(wc, up=u)
             else:
                 wp = pack(w)
+                # ResBlock convs of the thick stages (C >= 128: what csrc/conv_ring16.hip serves): a second packing with e4m3 cross terms
+                stage = (i - 1 - n_ups) // (6 * len(self.resblock_kernel_sizes))
+                if (i > n_ups and self.precision == "f16f8r" and bool(self.split_acts) and (self.f8_stages >> stage) & 1 and w.shape[0] >= 128
+                        and w.shape[1] % 32 == 0 and w.shape[2] >= 3):
+                    packed8[i] = packing.pack_conv_weight_f16f8r(w)
             packed.append((wp, b))
             modes.append(mode)
-        self._install_packed(packed, modes)
+        self._install_packed(packed, modes, packed8=packed8)
         self._packed_key = key
         _lib.cache_rebuild_end(device)
 
     def _ups_grouped(self):
         """whether the stride-4 upsamplers' rows are packed grouped by phase (what the C handle is told as option ups_ring)"""
-        return bool(self.ups_ring) and self.precision == "f16x3" and bool(self.split_acts)
+        return bool(self.ups_ring) and self.precision in ("f16x3", "f16f8r") and bool(self.split_acts)
 
-    def _install_packed(self, packed, modes, ups_grouped=None):
+    def _install_packed(self, packed, modes, ups_grouped=None, packed8=None):
         """hand the kernel-ready weights [(packed weight, bias)] of every conv to the C handle (also the entry point of
         frozen.load_frozen, which brings them from a file instead of folding and packing parameters)"""
         l = lib()
@@ -156,6 +165,15 @@ class CoreHifiGan(CoreHifiGanParams):
         # (a frozen model brings the row order its weights were packed in)
         self._packed_ups_grouped = self._ups_grouped() if ups_grouped is None else bool(ups_grouped)
         check(l.sat_hifigan_set_option(self._handle, b"ups_ring", int(self._packed_ups_grouped)), "sat_hifigan_set_option")
+        # second packings (SAT_CONV_F16F8R) of the thick stages' ResBlock convs: {conv id: packed tensor}
+        packed8 = dict(packed8 or {})
+        stages = 0
+        n_ups, nk = len(self.upsample_rates), len(self.resblock_kernel_sizes)
+        for i, w8 in packed8.items():
+            check(l.sat_hifigan_set_conv_f8r(self._handle, int(i), ptr(w8)), "sat_hifigan_set_conv_f8r")
+            stages |= 1 << ((int(i) - 1 - n_ups) // (6 * nk))
+        check(l.sat_hifigan_set_option(self._handle, b"f8_stages", stages & int(self.f8_stages)), "sat_hifigan_set_option")
+        self._packed8 = packed8
         self._packed = packed  # keeps the device buffers alive
         self._packed_modes = list(modes)
 

@@ -18,7 +18,7 @@ def _descale(w_packed, mode=1):
     """power-of-two layer scale of split-f16 packed weights (packing.pack_conv_weight_f16x3 attaches it as `.w_descale`).
     The attribute does not survive .to() / .clone() / .contiguous() / indexing: a packed tensor WITHOUT it in split-f16 mode is
     refused instead of being multiplied as if its scale were 1 (every output of the layer would be off by 2^e)."""
-    if int(mode) != 1:
+    if int(mode) not in (1, 3):
         return float(getattr(w_packed, "w_descale", 1.0))
     d = getattr(w_packed, "w_descale", None)
     if d is None:
@@ -64,7 +64,8 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
                  up=1, in_lrelu=None, res=None, res_scale=1.0, res_toff=0, res_tstride=1, ch_scale=None, ch_shift=None,
                  relu=False, gelu=False, post_res=None, out=None, accum=False, accum_div=0.0, mode=0, t_out=None,
                  x_split=None, y_split=None, y_split_slope=1.0, no_y=False, y_split_format=0, res_split=None,
-                 res_split_slope=1.0, relu_first=False, x_wrap_channels=0, c_in=None, up_grouped=False, up_zero_taps=0):
+                 res_split_slope=1.0, relu_first=False, x_wrap_channels=0, c_in=None, up_grouped=False, up_zero_taps=0,
+                 x_split8=None, y_split8=None, y_split_hi_only=False):
     """Descriptor of a fused conv (see include/satools_hip.h sat_conv1d_f32).  `pad_right` defaults to the
     'same'-style value implied by pad_left for stride 1; T_q is derived like torch does:
     T_q = (T_in + pad_left + pad_right - dilation*(ksize-1) - 1)//stride + 1 (`t_out` caps it).
@@ -76,7 +77,10 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
     c >= Cw read channel c - Cw one position later (sat_conv1d_desc.x_wrap_channels); `x` gives [B, Cw, T] and
     `c_in` the weight's input channels.  `up_grouped` (up = 4, planes in and out): the polyphase weight's rows are ordered (16-channel
     group, phase, channel) — packing.convtranspose_as_phase_conv(..., grouped=True) — and `up_zero_taps` names its all-zero (tap slot,
-    phase) pairs (packing.convtranspose_zero_taps), sat_conv1d_desc.up_grouped / up_zero_taps."""
+    phase) pairs (packing.convtranspose_zero_taps), sat_conv1d_desc.up_grouped / up_zero_taps.
+    mode=CONV_F16F8R (the LDS-DMA ring kernel with e4m3 cross terms; weights from packing.pack_conv_weight_f16f8r): `x_split8` = the
+    e4m3 sidecar of x_split (planes_f8_sidecar, or a producer's `y_split8`); `y_split8` (a sidecar_like buffer) receives the sidecar of
+    y_split; `y_split_hi_only` leaves the lo units of y_split unwritten."""
     x = _strided3(x)
     c_in_w = c_in
     B, c_in, t_in = x.shape
@@ -121,6 +125,7 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
     d.relu_first = int(relu_first)
     d.x_wrap_channels = int(x_wrap_channels)
     d.up_grouped, d.up_zero_taps = int(bool(up_grouped)), int(up_zero_taps)
+    d.x_split8, d.y_split8, d.y_split_hi_only = ptr(x_split8), ptr(y_split8), int(bool(y_split_hi_only))
     return d, x, out, res      # (res: the possibly re-laid-out residual must outlive the launch)
 
 
@@ -298,6 +303,25 @@ def act_split(x, slope=1.0, out=None, fmt=0):
 
 def split_like(B, c, t, device):
     return torch.empty(B, c // 16, 2, 2, t, 8, dtype=torch.float16, device=device)
+
+
+def sidecar_like(B, c, t, device):
+    """buffer of the e4m3 sidecar of [B, c, t] split planes: [B][c/16][2 (e4m3(hi) | e4m3(lo * 2^10))][t][16 channels] bytes"""
+    return torch.empty(B, c // 16, 2, t, 16, dtype=torch.uint8, device=device)
+
+
+def planes_f8_sidecar(x_split, out=None):
+    """e4m3 sidecar of SPLIT_F16 planes (sat_planes_f8_sidecar): the operand image SAT_CONV_F16F8R reads through x_split8"""
+    B, nch, _, _, t, _ = x_split.shape
+    if out is None:
+        out = sidecar_like(B, nch * 16, t, x_split.device)
+    check(lib().sat_planes_f8_sidecar(ptr(x_split), ptr(out), B, nch * 16, t, stream()), "sat_planes_f8_sidecar")
+    return out
+
+
+def conv1d_f8r_supported(x, w_packed, c_out, ksize, **kw):
+    d, *_ = _conv1d_desc(x, w_packed, c_out, ksize, **kw)
+    return bool(lib().sat_conv1d_f8r_supported(C.byref(d)))
 
 
 def unsplit(s):

@@ -1,0 +1,281 @@
+"""SAT_CONV_F16F8R (round 5): the LDS-DMA ring kernel with the cross terms of split-f16 on the block-scaled e4m3 MFMA
+(csrc/conv_ring16.hip, F8 instantiations) — the generator's ResBlock convs of the 256- and 128-channel stages, reference
+satools/satools/hifigan/nn.py:96-187, archi.py:77-91.  Needs a real MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rms
+from test_hip_parity import DEV, _e4m3, _ops, _rand, conv_option
+
+pytestmark = pytest.mark.gpu
+
+
+def _planes_hi_lo(ops, s):
+    """SPLIT_F16 planes -> (hi, lo) as f32 [B][C][T] on the CPU: the f16 values the kernels multiply (signed zeros kept)"""
+    B, nch, _, _, t, _ = s.shape
+    part = lambda i: s[:, :, i].float().permute(0, 1, 2, 4, 3).reshape(B, nch * 16, t).cpu()      # [B][nch][half][t][8] -> [B][C][T]
+    return part(0), part(1)
+
+
+def _sidecar_bytes(hi, lo):
+    """what the sidecar of planes (hi, lo) must hold: [B][C/16][2][T][16] uint8"""
+    B, C, T = hi.shape
+    h8 = _e4m3(hi).view(torch.uint8).reshape(B, C // 16, 16, T).permute(0, 1, 3, 2)
+    l8 = _e4m3(lo, 10).view(torch.uint8).reshape(B, C // 16, 16, T).permute(0, 1, 3, 2)
+    return torch.stack([h8, l8], 2).contiguous()
+
+
+@pytest.mark.parametrize("B,C,T", [(2, 32, 301), (1, 128, 5000), (3, 256, 77)], ids=lambda v: str(v))
+def test_planes_f8_sidecar_is_e4m3_of_the_plane_values(B, C, T):
+    """sat_planes_f8_sidecar: unit 0 = e4m3(hi), unit 1 = e4m3(lo * 2^10) of the f16 plane values, one byte per channel, OCP e4m3
+    round-to-nearest-even saturating at 448 like torch.float8_e4m3fn; large and tiny activations included"""
+    ops, _ = _ops()
+    x = _rand(B, C, T, seed=11, scale=3.0)
+    x[0, :, :7] *= 300.0            # beyond 448: saturates
+    x[0, :, 7:14] *= 1e-4           # e4m3 subnormals / zero
+    s = ops.act_split(x.to(DEV), 0.1)
+    got = ops.planes_f8_sidecar(s).cpu()
+    hi, lo = _planes_hi_lo(ops, s)
+    assert torch.equal(got, _sidecar_bytes(hi, lo))
+
+
+@pytest.mark.parametrize("C,T,k,dil", [(256, 1250, 11, 5), (256, 333, 7, 3), (128, 700, 3, 5), (128, 97, 11, 1), (192, 401, 7, 1), (512, 200, 3, 1),
+                                       (320, 161, 11, 3), (128, 5000, 7, 5), (256, 159, 3, 3), (128, 321, 3, 1), (128, 640, 4, 1)], ids=lambda v: str(v))
+def test_ring_conv_f16f8r_matches_its_decomposition(C, T, k, dil):
+    """Tight: against the decomposition evaluated in f64 (pins the operand order inside the K = 128 product, the E8M0 scales, the
+    tap pairing with its zero tap for odd kernels, the sidecar's rounding).  Loose: against the exact product (e4m3 cross terms
+    leave ~2^-15 per product).  The three ResBlock epilogues; planes and sidecar out; hi-only planes."""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    B = 3
+    x, w, b = _rand(B, C, T, seed=1).to(DEV), _rand(C, C, k, seed=2, scale=(k * C) ** -0.5).to(DEV), _rand(C, seed=3).to(DEV)
+    r, acc0 = _rand(B, C, T, seed=4).to(DEV), _rand(B, C, T, seed=5).to(DEV)
+    xs, rs = ops.act_split(x, 0.1), ops.act_split(r, 0.1)
+    xs8 = ops.planes_f8_sidecar(xs)
+    w8 = packing.pack_conv_weight_f16f8r(w)
+    pl = dil * (k - 1) // 2
+    pr = dil * (k - 1) - pl
+    kw = dict(bias=b, dilation=dil, pad_left=pl, mode=3, x_split=xs, x_split8=xs8, y_split_slope=0.1)
+    assert ops.conv1d_f8r_supported(x, w8, C, k, **kw)
+    # the value SAT_CONV_F16F8R computes, in float64, from the kernel's own input planes and the packer's own rounding:
+    # [hi . hi + e4m3(W_lo 2^9) 2^-9 . e4m3(x_hi) + e4m3(W_hi 2^-2) 2^2 . e4m3(x_lo 2^10) 2^-10] 2^-e  (explicit padding: an even
+    # kernel's 'same' padding is asymmetric)
+    xh, xl = _planes_hi_lo(ops, xs)
+
+    def padded(t):
+        return F.pad(t, (pl, pr))
+    e = packing.f16x3_scale_exponent(w)
+    ws = w.cpu() * 2.0 ** e
+    wh = ws.to(torch.float16).float()
+    wl = (ws - wh).to(torch.float16).float()
+    conv = lambda a, ww: F.conv1d(padded(a).double(), ww.double(), None, dilation=dil)
+    emu = (conv(xh, wh) + conv(_e4m3(xh).float(), _e4m3(wl, 9).float() / 2 ** 9)
+           + conv(_e4m3(xl, 10).float() / 2 ** 10, _e4m3(wh, -2).float() * 4.0)) / 2.0 ** e + b.double().cpu()[None, :, None]
+    exact = F.conv1d(padded(F.leaky_relu(x.double().cpu(), 0.1)), w.double().cpu(), b.double().cpu(), dilation=dil)
+    r64 = r.double().cpu()
+    # (1) planes + sidecar only
+    ys1, y81 = ops.split_like(B, C, T, DEV).zero_(), ops.sidecar_like(B, C, T, DEV).zero_()
+    ops.conv1d(x, w8, C, k, y_split=ys1, y_split8=y81, no_y=True, **kw)
+    name = _lib.lib().sat_last_dispatch_name().decode()
+    assert "ring16" in name and "F8" in name, name
+    # (2) residual from planes, f32 + planes + sidecar
+    ys2, y82 = ops.split_like(B, C, T, DEV).zero_(), ops.sidecar_like(B, C, T, DEV).zero_()
+    y2 = ops.conv1d(x, w8, C, k, y_split=ys2, y_split8=y82, res_split=rs, res_split_slope=0.1, **kw)
+    # (3) residual + MRF accumulation / 3
+    ys3 = ops.split_like(B, C, T, DEV).zero_()
+    y3 = ops.conv1d(x, w8, C, k, y_split=ys3, res_split=rs, res_split_slope=0.1, out=acc0.clone(), accum=True, accum_div=3.0, **kw)
+    # (4) hi-only planes: the lo units stay as they were
+    ys4, y84 = ops.split_like(B, C, T, DEV).fill_(7.0), ops.sidecar_like(B, C, T, DEV).zero_()
+    ops.conv1d(x, w8, C, k, y_split=ys4, y_split8=y84, y_split_hi_only=True, no_y=True, **kw)
+    scale = float(exact.abs().max())
+    d1 = (ops.unsplit(ys1).cpu().double() - F.leaky_relu(emu, 0.1)).abs().max().item()
+    d2 = (y2.cpu().double() - (emu + r64)).abs().max().item()
+    d3 = (y3.cpu().double() - (acc0.double().cpu() + emu + r64) / 3).abs().max().item()
+    l2 = (y2.cpu().double() - (exact + r64)).abs().max().item()
+    print(f"vs decomposition: {d1:.2e} {d2:.2e} {d3:.2e}; vs exact {l2:.2e} (rms {rms((y2.cpu().double() - (exact + r64)).numpy()):.2e}); scale {scale:.2f}")
+    assert max(d1, d2, d3) < 4e-6 * max(1.0, scale)
+    assert l2 < 1e-4 * max(1.0, scale) and rms((y2.cpu().double() - (exact + r64)).numpy()) < 2e-5
+    # output planes = split of the f32 values beside them, sidecars = e4m3 of those planes
+    assert torch.equal(ys2, ops.act_split(y2, 0.1)) and torch.equal(ys3, ops.act_split(y3, 0.1))
+    assert torch.equal(y81, ops.planes_f8_sidecar(ys1)) and torch.equal(y82, ops.planes_f8_sidecar(ys2))
+    assert torch.equal(ys4[:, :, 0], ys1[:, :, 0]) and bool((ys4[:, :, 1] == 7.0).all()) and torch.equal(y84, y81)
+
+
+@pytest.mark.parametrize("C,T", [(256, 1250), (128, 700)], ids=lambda v: str(v))
+def test_f16f8r_multi_launch_equals_the_single_calls(C, T):
+    """sat_conv1d_multi_f32 with SAT_CONV_F16F8R jobs (3 / 7 / 11 taps of the MRF branches in one launch, chained through the MRF
+    accumulator): the bits of the single calls; a job with its f32 output in a PITCHED view (per-job strides, round-4 advisor item)"""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    B, ks, dils = 4, (3, 7, 11), (1, 3, 5)
+    x = _rand(B, C, T, seed=1).to(DEV)
+    xs = ops.act_split(x, 0.1)
+    xs8 = ops.planes_f8_sidecar(xs)
+    ws = [packing.pack_conv_weight_f16f8r(_rand(C, C, k, seed=10 + k, scale=(k * C) ** -0.5).to(DEV)) for k in ks]
+    bs = [_rand(C, seed=20 + k).to(DEV) for k in ks]
+
+    def jobs(kind, ys, y8s, acc):
+        out = []
+        for j, k in enumerate(ks):
+            kw = dict(bias=bs[j], dilation=dils[j], pad_left=dils[j] * (k - 1) // 2, mode=3, x_split=xs, x_split8=xs8, y_split_slope=0.1)
+            if kind == "conv1":
+                kw.update(y_split=ys[j], y_split8=y8s[j], y_split_hi_only=True, no_y=True)
+            elif kind == "conv2":
+                kw.update(y_split=ys[j], y_split8=y8s[j], no_y=True, res_split=xs, res_split_slope=0.1)
+            else:
+                kw.update(res_split=xs, res_split_slope=0.1, out=acc, accum=j > 0, accum_div=3.0 if j == 2 else 0.0, y_split=ys[2] if j == 2 else None)
+            out.append((x, ws[j], C, k, kw))
+        return out
+
+    for kind in ("conv1", "conv2", "last"):
+        got = {}
+        for how in ("single", "multi"):
+            ys = [ops.split_like(B, C, T, DEV).zero_() for _ in ks]
+            y8s = [ops.sidecar_like(B, C, T, DEV).zero_() for _ in ks]
+            acc = torch.full((B, C, T), 7.0, device=DEV)
+            if how == "single":
+                for (xx, w, c, k, kw) in jobs(kind, ys, y8s, acc):
+                    ops.conv1d(xx, w, c, k, **kw)
+            else:
+                ops.conv1d_multi(jobs(kind, ys, y8s, acc))
+                assert "F8" in _lib.lib().sat_last_dispatch_name().decode()
+            got[how] = (ys, y8s, acc)
+        for a, bb in zip(got["single"][0] + got["single"][1], got["multi"][0] + got["multi"][1]):
+            assert torch.equal(a, bb), kind
+        assert torch.equal(got["single"][2], got["multi"][2]), kind
+    # per-job f32 strides: job 0 planes only, job 1 into a contiguous tensor, job 2 into a pitched view
+    for mode, wl in ((3, ws), (1, [packing.pack_conv_weight_f16x3(_rand(C, C, k, seed=10 + k, scale=(k * C) ** -0.5).to(DEV)) for k in ks])):
+        with conv_option("convring", 33, 1):
+            outs = {}
+            for how in ("single", "multi"):
+                y0s = ops.split_like(B, C, T, DEV).zero_()
+                o1 = torch.zeros(B, C, T, device=DEV)
+                o2 = torch.zeros(B, C, T + 24, device=DEV)
+                jl = []
+                for j, k in enumerate(ks):
+                    kw = dict(bias=bs[j], dilation=dils[j], pad_left=dils[j] * (k - 1) // 2, mode=mode, x_split=xs, y_split_slope=0.1)
+                    if mode == 3:
+                        kw["x_split8"] = xs8
+                    if j == 0:
+                        kw.update(y_split=y0s, no_y=True)
+                    elif j == 1:
+                        kw.update(out=o1)
+                    else:
+                        kw.update(out=o2[:, :, 8:8 + T])
+                    jl.append((x, wl[j], C, k, kw))
+                if how == "single":
+                    for (xx, w, c, k, kw) in jl:
+                        ops.conv1d(xx, w, c, k, **kw)
+                else:
+                    ops.conv1d_multi(jl)
+                    assert "ring16" in _lib.lib().sat_last_dispatch_name().decode()
+                outs[how] = (y0s, o1, o2)
+            for a, bb in zip(outs["single"], outs["multi"]):
+                assert torch.equal(a, bb), mode
+            assert bool((outs["multi"][2][:, :, :8] == 0).all()) and bool((outs["multi"][2][:, :, 8 + T:] == 0).all())
+
+
+@pytest.mark.parametrize("cfg", [(256, 128, 133, 2), (128, 64, 700, 3)])
+def test_stride4_upsampler_on_the_ring_writes_the_sidecar(cfg):
+    """ring_epilogue_ups with y_split8: the sidecar of the planes it writes (quad-transposed stores)"""
+    ops, packing = _ops()
+    cin, cout, T, B = cfg
+    k, u = 8, 4
+    x = _rand(B, cin, T, seed=1).to(DEV)
+    w = _rand(cin, cout, k, seed=2, scale=(k * cin) ** -0.5).to(DEV)
+    b = _rand(cout, seed=3).to(DEV)
+    wc, kp, pl = packing.convtranspose_as_phase_conv(w, u, (k - u) // 2, grouped=True)
+    wp = packing.pack_conv_weight_f16x3(wc, up=u)
+    xs = ops.act_split(x, 0.1)
+    outs = []
+    for with8 in (False, True):
+        ys = ops.split_like(B, cout, T * u, DEV).zero_()
+        y8 = ops.sidecar_like(B, cout, T * u, DEV).zero_() if with8 else None
+        ops.conv1d(x, wp, cout, kp, bias=b, pad_left=pl, up=u, mode=1, x_split=xs, y_split=ys, y_split8=y8, y_split_slope=0.1, no_y=True,
+                   up_grouped=True, up_zero_taps=packing.convtranspose_zero_taps(k, u, (k - u) // 2))
+        outs.append((ys, y8))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[1][1], ops.planes_f8_sidecar(outs[1][0]))
+
+
+class gen_precision:
+    def __init__(self, gen, precision, **attrs):
+        self.gen, self.new, self.attrs = gen, precision, attrs
+
+    def __enter__(self):
+        g = self.gen
+        self.old = (g.precision, {k: getattr(g, k) for k in self.attrs})
+        g.precision = self.new
+        for k, v in self.attrs.items():
+            setattr(g, k, v)
+        g.invalidate()
+
+    def __exit__(self, *a):
+        g = self.gen
+        g.precision = self.old[0]
+        for k, v in self.old[1].items():
+            setattr(g, k, v)
+        g.invalidate()
+
+
+@pytest.fixture(scope="module")
+def model():
+    import satools_amd
+    m = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1")
+    m.to(DEV)
+    m.eval()
+    return m
+
+
+def test_generator_f16f8r_matches_golden_teacher_forced(model, gold):
+    """the generator with the thick stages' ResBlock convs on e4m3 cross terms, on the reference's own BN / F0 / speaker input:
+    within 1e-5 RMS of the reference's waveform (bar of the path: 1e-4).  One utterance is too few tiles for the ring kernel by
+    default: option convring = 33 sends it there (and the test checks that the F8 kernels ran)"""
+    from satools_amd import _lib
+    fx = gold.npz("fx_gen.npz")
+    spk = F.one_hot(torch.from_numpy(fx["spk_argmax"]), len(model.spk))
+    y0 = model._forward(torch.from_numpy(fx["f0_raw"].copy()), torch.from_numpy(fx["bn"]), spk)
+    with gen_precision(model.hifigan, "f16f8r"), conv_option("convring", 33, 1):
+        y = model._forward(torch.from_numpy(fx["f0_raw"].copy()), torch.from_numpy(fx["bn"]), spk)
+        assert len(model.hifigan._packed8) == 36            # 2 stages x 3 branches x 3 steps x 2 convs
+    with gen_precision(model.hifigan, "f16f8r"):
+        y_small = model._forward(torch.from_numpy(fx["f0_raw"].copy()), torch.from_numpy(fx["bn"]), spk)
+    err, err0 = rms(y.cpu().numpy() - fx["y"]), rms(y0.cpu().numpy() - fx["y"])
+    print(f"f16f8r generator RMS error vs reference: {err:.3e} (f16x3: {err0:.3e}); signal RMS {rms(fx['y']):.3f}")
+    assert err < 1e-5
+    assert not torch.equal(y, y0)                           # the e4m3 kernels did run
+    assert torch.equal(y_small, y0)                         # too few tiles for the ring kernel: the f16x3 packing serves the batch
+
+
+def test_full_size_batch_f16f8r(model, fbank_tag_state):
+    """32 x 5 s through the f16f8r generator (BASELINE configs[1] sizes): utterance 17 against the CPU oracle's generator <= 1e-5 RMS;
+    slices of the batch = the bits of the full batch (with the ring kernel at every size); deterministic"""
+    from oracle import convert as oconv
+    from oracle import hifigan as ohg
+    from satools_amd import ops, synthetic
+    seeds = list(range(32))
+    wav = synthetic.harm_batch(seeds).to(DEV)
+    targets = synthetic.targets(model.spk, seeds)
+    f0 = model.get_f0(wav)
+    bn = model.get_bn(wav)
+    spk = model.get_spk_id(wav, targets).to(DEV, torch.float32).contiguous()
+    f0n = f0.to(DEV).clone()
+    ops.f0_norm_transform_(f0n)
+    x = ops.assemble_input(bn, f0n, spk, spk.shape[1])
+    base = model.hifigan(x)[0].clone()
+    with gen_precision(model.hifigan, "f16f8r"):
+        full = model.hifigan(x)[0].clone()
+        assert torch.equal(full, model.hifigan(x)[0])
+        with conv_option("convring", 33, 1):
+            for sl in (slice(0, 1), slice(5, 9), slice(29, 32)):
+                assert torch.equal(model.hifigan(x[sl].contiguous())[0], full[sl])
+        y = model.convert(wav, target=targets)
+        assert torch.equal(y, full.reshape(y.shape))
+    assert not torch.equal(full, base)
+    _, gen_sd = oconv.split_state_dict(fbank_tag_state[0]["base_model_state_dict"])
+    ref = ohg.generator(gen_sd, x[17:18].cpu())
+    err, err0 = rms((full[17:18].cpu() - ref).numpy()), rms((base[17:18].cpu() - ref).numpy())
+    print(f"full-size batch, utterance 17 vs oracle generator: f16f8r rms {err:.3e} (f16x3 {err0:.3e}); f16f8r vs f16x3 {rms((full - base).cpu().numpy()):.3e}")
+    assert err < 1e-5
