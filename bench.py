@@ -56,6 +56,11 @@ W2V2_ACT_BYTES_PER_UTT = 620e6 + 5e6   # per-layer streaming model of the extrac
 W2V2_WEIGHT_BYTES = 1.26e9             # its weights, streamed once per batch
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0       # dense f16/bf16 MFMA (MI355X_MICROARCH.md); split-f16 issues 3 MFMA products per product
+PEAK_F8_MFMA_TFLOPS = 5000.0        # dense block-scaled e4m3 MFMA
+# useful-FLOP peaks of the two split arithmetics: f16x3 = three f16 products per product; f16f8r = one f16 product + two e4m3
+# products at twice the rate = two f16-product units per product
+PEAK_F16X3 = PEAK_F16_MFMA_TFLOPS / 3.0
+PEAK_F16F8R = 1.0 / (1.0 / PEAK_F16_MFMA_TFLOPS + 2.0 / PEAK_F8_MFMA_TFLOPS)
 PEAK_HBM_TBS = 8.0
 F0_OPTS = {"frame_length": 35.0, "frame_space": 20.0, "nccf_thresh1": 0.25, "tda_frame_length": 25.0}
 
@@ -210,9 +215,10 @@ def load(tag, f0_transformation, dev):
     return m
 
 
-def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each):
+def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each, repeats=1):
     """N = 1 mode: K independent convert() batches, `jobs` deep in flight on separate HIP streams (the reference's
-    jobs_per_compute_device, satools/satools/bin/anonymize:85-93).  Returns (seconds, setup_steps)."""
+    jobs_per_compute_device, satools/satools/bin/anonymize:85-93), timed `repeats` times back to back (each window = exactly K steps
+    between two device synchronisations).  Returns (list of window seconds, setup_steps)."""
     import torch
     from satools_amd import synthetic
     seeds = [rank * BATCH + i for i in range(BATCH)]
@@ -234,20 +240,25 @@ def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each):
 
     for _ in range(setup_steps + warmup):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0, setup_steps
+    windows = []
+    for _ in range(max(1, repeats)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        windows.append(time.perf_counter() - t0)
+    return windows, setup_steps
 
 
-def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, gather="f32"):
+def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, gather="f32", repeats=1, chunk_batches=4):
     """N > 1 mode (and SAT_BENCH_FORCE_PG=1 with one rank): world x steps x 32 utterances sharded through
-    satools_amd.dist.convert_sharded, one all-gather of the shards at the end, all inside the timed region.
+    satools_amd.dist.convert_sharded, all inside the timed region.  The exchange of the anonymized waveforms is issued in chunks of
+    `chunk_batches` batches on a communication stream while the rest of the shard is computed (dist.ChunkedGather: the bytes of the
+    one all_gather_into_tensor, hidden behind compute; `chunk_batches` = 0: that single collective at the end).
     `gather` = "pcm16": the shards are converted to the int16 PCM the reference writes before the collective (half the
-    bytes).  Returns (seconds [max over ranks], all-gather ms [max over ranks], ranks seen, setup_steps, gathered job ==
-    this rank's shard at its place)."""
+    bytes).  The job is timed `repeats` times (each window: barrier + synchronize on both sides, MAX over ranks).
+    Returns a dict: window seconds, exposed all-gather ms, per-rank compute ms, ranks seen, setup_steps, checks."""
     import torch
     import torch.distributed as dist
     from satools_amd import dist as sdist
@@ -258,10 +269,12 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
     wav = torch.cat([synthetic.harm_batch(list(range(s, e))) for s, e in sdist.batches(lo, hi, BATCH)], 0).to(dev)
     targets = synthetic.targets(model.spk, list(range(lo, hi)))
     streams = [torch.cuda.Stream(device=dev) for _ in range(jobs)]
+    comm = torch.cuda.Stream(device=dev)
     local = torch.empty(hi - lo, 1, N_SAMPLES + 1, dtype=torch.float32, device=dev)
     setup_steps = max(0, jobs - warmup)
     cur = torch.cuda.current_stream(dev)
     n = [0]
+    produced = {}           # first utterance of a batch -> event behind its last kernel
 
     def convert_fn(a, b):
         s = streams[n[0] % jobs]
@@ -271,35 +284,65 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
         with torch.cuda.stream(s):
             y = model.convert(wav[a - lo:b - lo], target=targets[a - lo:b - lo])
             local[a - lo:b - lo].copy_(y.reshape(b - a, 1, -1))
+            e = torch.cuda.Event()
+            e.record(s)
+            produced[a] = e
         return None
+
+    def before_chunk(c, ra, rb):
+        # the communication stream waits for the job streams that produced this chunk's batches; the collective is issued behind it
+        for a in range(lo + ra, lo + rb, BATCH):
+            comm.wait_event(produced[a])
+        return torch.cuda.stream(comm)
 
     def join_streams():
         for s in streams:
             cur.wait_stream(s)
-        ev[0].record(cur)
+        ev[1].record(cur)           # this rank's compute is done
+        cur.wait_stream(comm)
 
-    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for i in range(setup_steps + warmup):
         convert_fn(lo + (i % steps) * BATCH, lo + (i % steps) * BATCH + BATCH)
-    join_streams()
+    for s in streams:
+        cur.wait_stream(s)
     transform = sdist.pcm16_rows if gather == "pcm16" else None
-    sdist.all_gather_rows(transform(local) if transform else local, n_items)   # first collective: RCCL builds its communicator / rings here
+    ref = sdist.all_gather_rows(transform(local) if transform else local, n_items)   # first collective: RCCL builds its communicator / rings here
     ranks_seen = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(ranks_seen, torch.tensor([rank], dtype=torch.int64, device=dev))
     ranks_seen = [int(t.item()) for t in ranks_seen]
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = sdist.convert_sharded(convert_fn, n_items, BATCH, gather=True, local_out=local, before_gather=join_streams, transform=transform)
-    ev[1].record(cur)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
+    windows, gather_ms, compute_ms, stats = [], [], [], {}
+    out = None
+    for _ in range(max(1, repeats)):
+        del out
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev[0].record(cur)
+        out = sdist.convert_sharded(convert_fn, n_items, BATCH, gather=True, local_out=local, before_gather=join_streams, transform=transform,
+                                    gather_chunk_batches=chunk_batches, before_chunk=before_chunk if chunk_batches else None, stats=stats)
+        ev[2].record(cur)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        # per window: MAX over ranks of the wall time and of the exposed exchange; every rank's compute time (a straggler is visible)
+        t = torch.tensor([dt, ev[1].elapsed_time(ev[2])], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comp = [torch.empty(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(comp, torch.tensor([ev[0].elapsed_time(ev[1])], dtype=torch.float64, device=dev))
+        windows.append(float(t[0].item()))
+        gather_ms.append(float(t[1].item()))
+        compute_ms.append([round(float(c.item()), 3) for c in comp])
     assert out.shape == (n_items, 1, N_SAMPLES + 1)
-    same = bool(torch.equal(out[lo:hi], transform(local) if transform else local))
-    t = torch.tensor([dt, ev[0].elapsed_time(ev[1]), 0.0 if same else 1.0], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t[0].item()), float(t[1].item()), ranks_seen, setup_steps, t[2].item() == 0.0
+    mine = transform(local) if transform else local
+    # the checked reference: ONE all_gather_into_tensor of the same shards (same inputs -> same waveforms as the warm-up pass it gathered)
+    ref2 = sdist.all_gather_rows(mine, n_items)
+    ok = torch.tensor([0.0 if torch.equal(out[lo:hi], mine) else 1.0, 0.0 if torch.equal(out, ref2) else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MAX)
+    del ref, ref2
+    return {"windows": windows, "all_gather_ms": gather_ms, "compute_ms_per_rank": compute_ms, "ranks_seen": ranks_seen, "setup_steps": setup_steps,
+            "gathered_equals_shard": ok[0].item() == 0.0, "chunked_equals_single_collective": ok[1].item() == 0.0,
+            "chunks": len(stats.get("chunks", [])), "chunk_batches": chunk_batches}
 
 
 def last_dispatch():
@@ -351,33 +394,50 @@ def roofline_generator(model, dev, reps):
         ops.f0_norm_transform_(f0n)
         x = ops.assemble_input(bn, f0n, spk.to(dev, torch.float32).contiguous(), spk.shape[1])
         gen_ms, gen_t = time_events(lambda: model.hifigan(x), reps)
-    split = model.hifigan.precision == "f16x3"
+    prec = model.hifigan.precision
+    split = prec in ("f16x3", "f16f8r")
+    f8 = prec == "f16f8r" and bool(getattr(model.hifigan, "_packed8", None))
     dom = None
     if split:
-        # what the generator launches on its thick stages (hifigan.hip, option multi_branch): ONE launch for the second conv of the
-        # three MRF branches (3 / 7 / 11 taps, residual from planes, planes out) — here at C = 256, T = 1250
-        C, T, ks = 256, 1250, (3, 7, 11)
-        g = torch.Generator(device="cpu").manual_seed(0)
-        xk = torch.randn(BATCH, C, T, generator=g).to(dev)
-        xs, rs = ops.act_split(xk, 0.1), ops.act_split(xk * 0.5, 0.1)
-        jobs = []
-        for k in ks:
-            wk = packing.pack_conv_weight_f16x3((torch.randn(C, C, k, generator=g) * 0.02).to(dev))
-            jobs.append((xk, wk, C, k, dict(bias=torch.zeros(C, device=dev), dilation=1, pad_left=(k - 1) // 2, mode=1, x_split=xs,
-                                            y_split=ops.split_like(BATCH, C, T, dev), y_split_slope=0.1, res_split=rs, res_split_slope=0.1, no_y=True)))
-        run = lambda: ops.conv1d_multi(jobs)
-        us, us_t = time_events(run, 20, warm=3)
-        us, us_t = us * 1e3, {k_: (round(v * 1e3, 1) if k_ in ("min", "max") else v) for k_, v in us_t.items()}
-        flop = 2.0 * BATCH * C * C * sum(ks) * T
-        dom = {"name": last_dispatch() + " — one launch = the second conv (3 + 7 + 11 taps, residual from planes, planes out) of the three MRF "
-                                         "branches at C=256, T=1250, batch 32 (12 launches of this kind per forward: 6 per thick stage)",
-               "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "us_per_launch_min_max": us_t, "achieved": round(flop / us / 1e6, 1),
-               "frac": round(flop / us / 1e6 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)}
+        # The generator's thick stages launch ONE kernel per conv of the three MRF branches (hifigan.hip, option multi_branch): 12
+        # launches of the LDS-DMA ring kernel per forward, 6 at C = 256 / T = 1250 and 6 at C = 128 / T = 5000.  Both shapes are
+        # timed live (the second conv of a ResBlock step: 3 + 7 + 11 taps, residual from planes, planes out) and the one with the
+        # larger TOTAL time per forward is reported as the dominant kernel (round 4 reported the C = 256 shape by fiat).
+        cands = []
+        for C, T in ((256, 1250), (128, 5000)):
+            ks = (3, 7, 11)
+            g = torch.Generator(device="cpu").manual_seed(0)
+            xk = torch.randn(BATCH, C, T, generator=g).to(dev)
+            xs, rs = ops.act_split(xk, 0.1), ops.act_split(xk * 0.5, 0.1)
+            xs8 = ops.planes_f8_sidecar(xs) if f8 else None
+            jobs = []
+            for k in ks:
+                wf = (torch.randn(C, C, k, generator=g) * 0.02).to(dev)
+                wk = packing.pack_conv_weight_f16f8r(wf) if f8 else packing.pack_conv_weight_f16x3(wf)
+                kw = dict(bias=torch.zeros(C, device=dev), dilation=1, pad_left=(k - 1) // 2, mode=3 if f8 else 1, x_split=xs,
+                          y_split=ops.split_like(BATCH, C, T, dev), y_split_slope=0.1, res_split=rs, res_split_slope=0.1, no_y=True)
+                if f8:
+                    kw.update(x_split8=xs8, y_split8=ops.sidecar_like(BATCH, C, T, dev))
+                jobs.append((xk, wk, C, k, kw))
+            run = lambda: ops.conv1d_multi(jobs)
+            us, us_t = time_events(run, 20, warm=3)
+            us, us_t = us * 1e3, {k_: (round(v * 1e3, 1) if k_ in ("min", "max") else v) for k_, v in us_t.items()}
+            flop = 2.0 * BATCH * C * C * sum(ks) * T
+            peak_k = PEAK_F16F8R if f8 else PEAK_F16X3
+            cands.append({"name": last_dispatch() + f" — one launch = the second conv (3 + 7 + 11 taps, residual from planes, planes out) of the three MRF "
+                                                    f"branches at C={C}, T={T}, batch 32 (6 launches of this shape per forward)",
+                          "launches_per_forward": 6, "total_us_per_forward": round(6 * us, 1),
+                          "flop_per_launch": flop, "avg_us_per_launch": round(us, 1), "us_per_launch_min_max": us_t, "achieved": round(flop / us / 1e6, 1),
+                          "peak": round(peak_k, 1), "frac": round(flop / us / 1e6 / peak_k, 4)})
+            del xk, xs, rs, jobs
+        cands.sort(key=lambda c: -c["total_us_per_forward"])
+        dom = dict(cands[0], chosen_by="largest total time per forward among the generator's launch shapes timed live",
+                   other_candidates=[{k_: c[k_] for k_ in ("name", "total_us_per_forward", "avg_us_per_launch", "achieved", "frac")} for c in cands[1:]])
     achieved = GEN_FLOP_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
-    peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+    _, peak, arithmetic = gen_arithmetic(model)
     hbm = GEN_BYTES_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
     traffic, note = None, None
-    for name in ("r04_generator_traffic.json", "r03_generator_traffic.json", "r02_generator_traffic.json", "r01o_generator_traffic.json"):
+    for name in (["r05_generator_f16f8r_traffic.json"] if f8 else []) + ["r05_generator_traffic.json", "r04_generator_traffic.json", "r03_generator_traffic.json"]:
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))["per_forward"]
@@ -386,16 +446,16 @@ def roofline_generator(model, dev, reps):
             traffic = (tj["fetch_GB_doubled"] + tj["write_GB"]) * 1e9
             note = (f"HBM bytes per generator forward (batch 32), separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                     f"(profiles/{name}): fetch {tj['fetch_GB_doubled']} GB (FETCH_SIZE x 2, the gfx950 wide-load correction) "
-                    f"+ write {tj['write_GB']} GB; per-layer streaming model {tj['algorithmic_GB_per_layer_model']} GB")
+                    f"+ write {tj['write_GB']} GB; per-layer streaming model {tj['algorithmic_GB_per_layer_model']} GB"
+                    + ("" if (name.startswith("r05_generator_f16f8r") or not f8) else " — counters of the f16x3 generator: the f16f8r forward also moves the e4m3 sidecars of the thick stages"))
             break
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note,
-            "kernel": ("split-f16 conv family of the generator" if split else "conv1d_mfma_kernel (exact f32)")
+            "kernel": (("split-f16 conv family of the generator" + (" (e4m3 cross terms on the thick stages)" if f8 else "")) if split else "conv1d_mfma_kernel (exact f32)")
                       + f": all launches of one forward, {gen_ms:.3f} ms per batch of {BATCH}",
             "timing_ms": dict(gen_t, median=round(gen_ms, 4)),
             "dominant_kernel": dom,
-            "arithmetic": ("f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 "
-                           "MFMA peak / 3" if split else "exact f32 MFMA"),
+            "arithmetic": arithmetic,
             "algorithmic_flop_per_launch_group": GEN_FLOP_PER_UTT * BATCH,
             "hbm_model": {"achieved_TBps": round(hbm, 3), "peak_TBps": PEAK_HBM_TBS, "frac": round(hbm / PEAK_HBM_TBS, 4),
                           "bytes_per_launch_group": GEN_BYTES_PER_UTT * BATCH}}
@@ -448,42 +508,83 @@ def roofline_w2v2(model, dev, reps):
             "algorithmic_flop_per_launch_group": W2V2_FLOP_PER_UTT * BATCH}
 
 
-def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu, cpu_args):
-    """measure one BASELINE config on the loaded device; returns the JSON object (rank 0) or None"""
+def gen_arithmetic(model):
+    """(dtype string, useful-FLOP peak in TFLOP/s, description) of what the generator's matrix products run as — read from the
+    loaded model (precision + the stages whose second packing is installed), not assumed"""
+    g = model.hifigan
+    if g.precision == "f32":
+        return "f32", PEAK_F32_MFMA_TFLOPS, "exact f32 MFMA"
+    if g.precision == "f16f8r" and getattr(g, "_packed8", None):
+        # FLOP share of the ResBlock convs that run with e4m3 cross terms (batch 32: the ring kernel serves them): per stage
+        # C^2 T (3 + 7 + 11) x 6 convs MACs (hifigan/archi.py:82-86)
+        n_ups, nk = len(g.upsample_rates), len(g.resblock_kernel_sizes)
+        C, T, f8 = g.upsample_initial_channel, 250, 0.0
+        stages = {(int(i) - 1 - n_ups) // (6 * nk) for i in g._packed8}
+        for i, u in enumerate(g.upsample_rates):
+            C, T = C // 2, T * u
+            if i in stages:
+                f8 += 2.0 * C * C * T * sum(g.resblock_kernel_sizes) * 6
+        share = f8 / GEN_FLOP_PER_UTT
+        peak = 1.0 / (share / PEAK_F16F8R + (1.0 - share) / PEAK_F16X3)
+        return (f"f32 (matrix products as split-f16: hi*hi on the f16 MFMA; cross terms on the e4m3 MFMA in the ResBlock convs of stages "
+                f"{sorted(s + 1 for s in stages)} = {100 * share:.0f} % of the generator's FLOP, as two more f16 products elsewhere; f32 accumulate)",
+                peak, f"split-f16; {100 * share:.0f} % of the FLOP at 2 f16-product units per product (f16 + 2 x e4m3 at twice the rate: peak "
+                      f"{PEAK_F16F8R:.0f}), the rest at 3 (peak {PEAK_F16X3:.0f}): FLOP-weighted harmonic peak")
+    if g.precision == "f16x3":
+        return "f32 (matrix products as split-f16 x3 with f32 accumulate)", PEAK_F16X3, "f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 MFMA peak / 3"
+    return f"f32 (matrix products: {g.precision})", PEAK_F16X3, g.precision
+
+
+def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu, cpu_args, repeats=1, gen_precision=None, want_roofline=True):
+    """measure one BASELINE config on the loaded device; returns the JSON object (rank 0) or None.  `value` = the MEDIAN of
+    `repeats` timed windows of `steps` steps (median of >= 5 repeats), min / max beside it."""
     model = load(tag, f0_tr, dev)
+    if gen_precision:
+        model.hifigan.precision = gen_precision
+        model.hifigan.invalidate()
     seed_each = "awgn" in f0_tr
     extra = {}
     if use_pg:
-        dt, ag_ms, ranks, setup, same = run_sharded(model, dev, rank, world, steps, warmup, a.jobs, seed_each, a.gather)
+        r = run_sharded(model, dev, rank, world, steps, warmup, a.jobs, seed_each, a.gather, repeats, a.gather_chunk)
+        windows, setup = r["windows"], r["setup_steps"]
         gb = 2 if a.gather == "pcm16" else 4
-        extra = {"all_gather_ms": round(ag_ms, 3), "ranks_seen_by_rccl": ranks,
+        mid = sorted(range(len(windows)), key=lambda i: windows[i])[len(windows) // 2]
+        comp = r["compute_ms_per_rank"][mid]
+        extra = {"all_gather_ms": round(r["all_gather_ms"][mid], 3), "ranks_seen_by_rccl": r["ranks_seen"],
                  "utterances": world * steps * BATCH, "gather_dtype": "int16" if a.gather == "pcm16" else "float32",
-                 "gathered_equals_shard": same,
-                 "all_gather": f"one all_gather_into_tensor of [{steps * BATCH}, 1, {N_SAMPLES + 1}] "
-                               f"{'int16 PCM' if a.gather == 'pcm16' else 'f32'} per rank "
-                               f"({steps * BATCH * (N_SAMPLES + 1) * gb / 1e6:.0f} MB) at the end, inside the timed region"}
+                 "gathered_equals_shard": r["gathered_equals_shard"], "chunked_equals_single_collective": r["chunked_equals_single_collective"],
+                 "compute_ms_per_rank": comp, "compute_ms_min_max": [min(comp), max(comp)],
+                 "all_gather": (f"{r['chunks']} asynchronous all-gathers of {r['chunk_batches']} batches each ([{r['chunk_batches'] * BATCH}, 1, {N_SAMPLES + 1}] "
+                                if r["chunk_batches"] else f"one all_gather_into_tensor of [{steps * BATCH}, 1, {N_SAMPLES + 1}] ")
+                               + f"{'int16 PCM' if a.gather == 'pcm16' else 'f32'} per rank; {steps * BATCH * (N_SAMPLES + 1) * gb / 1e6:.0f} MB per rank in all), "
+                               + ("issued on a communication stream as the batches complete, inside the timed region; all_gather_ms = what is left "
+                                  "exposed behind the slowest rank's last batch" if r["chunk_batches"] else "at the end, inside the timed region")}
     else:
-        dt, setup = run_steps(model, dev, rank, steps, warmup, a.jobs, seed_each)
+        windows, setup = run_steps(model, dev, rank, steps, warmup, a.jobs, seed_each, repeats)
     if rank != 0:
         return None
     w2 = tag == TAG_W2V2
     reps = max(3, min(steps, 10))
-    roof = roofline_w2v2(model, dev, reps) if w2 else roofline_generator(model, dev, reps)
-    split = model.hifigan.precision == "f16x3"
-    out = {"metric": METRIC, "value": round(world * steps * BATCH * UTT_SECONDS / dt, 2), "unit": UNIT, "n_gpus": world,
+    dt = statistics.median(windows) if len(windows) % 2 else sorted(windows)[len(windows) // 2]
+    dtype, _, _ = gen_arithmetic(model)
+    val = lambda t: round(world * steps * BATCH * UTT_SECONDS / t, 2)
+    out = {"metric": METRIC, "value": val(dt), "unit": UNIT, "n_gpus": world,
            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 (matrix products as split-f16 x3 with f32 accumulate)" if split else "f32", "data": "synthetic",
+           "dtype": dtype, "data": "synthetic",
+           "repeats": {"windows": len(windows), "steps_per_window": steps, "value": "median window", "value_min_max": [val(max(windows)), val(min(windows))],
+                       "ms_per_step_windows": [round(t / steps * 1e3, 3) for t in windows]},
            "config": dict({"workload": f"{name}: {tag}{'+f0-transformation=' + f0_tr if f0_tr else ''} model.convert, "
                                        f"batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
                            "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
                            "f0": "YAAPT computed on-path on the GPU inside convert()", "jobs_per_gpu": a.jobs,
-                           "setup_steps": setup,
+                           "setup_steps": setup, "generator_precision": model.hifigan.precision,
                            "reference_default_tag": f"{TAG_W2V2} (hubconf.py:69): its lines are configs[2] / configs[3] / configs[4] of this same run; "
                                                     f"the headline is BASELINE.json's configs[1], the tag the metric is quoted on",
                            "parallelism": f"dp{world}" + (" sharded (contiguous shards, batches of 32 in index order)" if use_pg else "")},
-                          **extra),
-           "roofline": roof}
+                          **extra)}
+    if want_roofline:
+        out["roofline"] = roofline_w2v2(model, dev, reps) if w2 else roofline_generator(model, dev, reps)
     if want_cpu:
         out["cpu_baseline"] = cpu_baseline(tag, f0_tr, model.spk, **cpu_args)
     del model
@@ -550,11 +651,20 @@ def main():
                          "jobs_per_compute_device, satools/satools/bin/anonymize:85-93)")
     ap.add_argument("--gather", choices=("f32", "pcm16"), default="f32",
                     help="sharded mode: gather the waveforms as f32 (default) or as the int16 PCM the reference writes (half the bytes)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed windows of --steps steps each; `value` = the median window (SURVEY 8(d): median of >= 5 repeats)")
+    ap.add_argument("--gather-chunk", type=int, default=4,
+                    help="sharded mode: the waveform exchange is issued in chunks of this many batches on a communication stream while "
+                         "the shard is still being computed (0 = one all_gather_into_tensor at the end)")
+    ap.add_argument("--gen-precision", default=None,
+                    help="generator arithmetic of every line (default: the package default, SATOOLS_AMD_GEN_PRECISION); when that is "
+                         "f16f8r the headline tag is also measured as f16x3 and kept in `configs`")
     ap.add_argument("--cpu-worker", nargs=4, metavar=("TAG", "F0TR", "N", "INDEX"), default=None, help=argparse.SUPPRESS)
     ap.add_argument("--tag", default=None, help="measure only this tag (one line)")
     ap.add_argument("--f0-transformation", default="", help="with --tag: e.g. quant_16_awgn_2")
     a = ap.parse_args()
     a.jobs = max(1, a.jobs)
+    a.repeats = max(1, a.repeats)
     if a.cpu_worker:
         return cpu_worker(a.cpu_worker[0], a.cpu_worker[1], int(a.cpu_worker[2]), int(a.cpu_worker[3]))
 
@@ -611,8 +721,17 @@ def main():
              dict(n_utt=8, runs_1=1, runs_n=1, n_utt_1=2,
                   budget_note="; configs[3] differs from configs[2] by the quantisation + noise of 250 x B values only, so its CPU leg is a shorter sample"))]) + \
             [("configs[1]", TAG, "", a.steps, a.warmup, dict(n_utt=8, runs_1=3, runs_n=3, procs=32, n_utt_proc=4))]
-    for name, tag, f0_tr, steps, warmup, cpu_args in plan:
-        out = one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu and cpu_args is not None, cpu_args or {})
+    from satools_amd.hifigan import CoreHifiGan
+    prec = a.gen_precision or CoreHifiGan.precision
+    if prec == "f16f8r" and not a.tag and not use_pg and not a.headline_only:
+        # the headline tag on the f16x3 generator too, beside the headline (same run, same box)
+        plan.insert(len(plan) - 1, ("configs[1] generator f16x3", TAG, "", a.steps, a.warmup, "f16x3"))
+    for i, (name, tag, f0_tr, steps, warmup, cpu_args) in enumerate(plan):
+        headline = i == len(plan) - 1
+        alt = cpu_args if isinstance(cpu_args, str) else None           # a generator precision instead of CPU-leg arguments
+        cpu_args = None if alt else cpu_args
+        out = one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu and cpu_args is not None, cpu_args or {},
+                         repeats=a.repeats if headline else min(a.repeats, 3), gen_precision=alt or a.gen_precision)
         torch.cuda.empty_cache()
         if rank == 0:
             lines.append(out)
@@ -624,7 +743,8 @@ def main():
             def brief(o):
                 r, c = o["roofline"], o["config"]
                 d = {"workload": c["workload"].split(" model.convert")[0], "value": o["value"], "unit": "x real-time", "ms_per_step": o["ms_per_step"],
-                     "steps": o["steps"], "n_gpus": o["n_gpus"],
+                     "steps": o["steps"], "n_gpus": o["n_gpus"], "windows": o["repeats"]["windows"], "value_min_max": o["repeats"]["value_min_max"],
+                     "generator_precision": c["generator_precision"], "dtype": o["dtype"],
                      "roofline": {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
                                   "kernel": r["kernel"].split(":")[0],
                                   "dominant_kernel_frac": (r.get("dominant_kernel") or {}).get("frac")}}

@@ -64,13 +64,41 @@ def vartoml(cfg):
     return out
 
 
+def visible_gpu_count():
+    """number of GPUs this process tree may use, found WITHOUT the HIP runtime: the parent of the per-GPU workers never touches the GPU
+    (it only spawns them; a process that has initialised HIP must not be replaced or forked around on this platform).  An explicit
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES list wins; else the amdgpu nodes the kernel driver exposes
+    (KFD topology: nodes with a non-zero simd_count are GPUs; fallback /sys/class/drm/card*/device/vendor == 0x1002 render nodes)."""
+    for name in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(name)
+        if v is not None and v.strip() != "":
+            return max(1, len([p for p in v.split(",") if p.strip() != ""]))
+    import glob
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(prop):
+                k, _, val = line.partition(" ")
+                if k == "simd_count" and int(val) > 0:
+                    n += 1
+                    break
+        except (OSError, ValueError):
+            pass
+    if n == 0:
+        for ven in glob.glob("/sys/class/drm/renderD*/device/vendor"):
+            try:
+                n += open(ven).read().strip().lower() == "0x1002"
+            except OSError:
+                pass
+    return max(1, n)
+
+
 def parse_ngpu(value):
     """'0' / '0,2' / '[0, 2]' -> those ids; 'all' -> every visible GPU; an integer N written as 'N gpus' is not
     supported by the reference either (its bare integers go through safe_gpu: the first N free GPUs)"""
-    import torch
     v = str(value).strip().strip("[]")
     if v.lower() in ("all", "all-force"):
-        return [str(i) for i in range(max(1, torch.cuda.device_count()))]
+        return [str(i) for i in range(visible_gpu_count())]
     return [p.strip().strip("'\"") for p in v.split(",") if p.strip()]
 
 

@@ -2000,6 +2000,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "pair64w")) { pair64w_set(value); return SAT_OK; }
   if (!strcmp(name, "convring")) { convring_set(value); return SAT_OK; }
   if (!strcmp(name, "convring_blocks")) { convring_set_blocks(value); return SAT_OK; }
+  if (!strcmp(name, "convring_wr")) { convring_set_wr(value); return SAT_OK; }
   if (!strcmp(name, "gemm_walk")) { gemm_walk_set(value); return SAT_OK; }
   if (!strcmp(name, "lean_balance")) { lean_set_balance(value); return SAT_OK; }
   if (!strcmp(name, "pair32s_waves")) { pair32s_set_waves(value); return SAT_OK; }

@@ -638,6 +638,7 @@ bool convring_supports(const ConvArgs& a, int B);
 bool convring_wanted(int rows_g, int T_q, int B);
 void convring_set(int v);
 void convring_set_blocks(int v);
+void convring_set_wr(int v);
 int convring_debug_stamps(long long* buf);
 bool ring16_supports(const ConvArgs& a);
 // the persistent, multi-job form of that ring for plain Linear layers (gemm_walk16.hip)

@@ -839,9 +839,12 @@ static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipS
   return SAT_OK;
 }
 
+// option "convring_wr": tile of the convs with more than 128 rows — 0 (default): 256 x 160; 2: 128 x 320 (bit 0: the f16x3 form, bit 1: F8)
+static int g_convring_wr = 0;
+void convring_set_wr(int v) { g_convring_wr = v; }
 int launch_f16x3_convring_multi(const ConvArgs* a, int njobs, int rotate, int B, hipStream_t s) {
-  if (a[0].f8r) return a[0].rows_g > 128 ? launch_convring<4, -1, true>(a, njobs, rotate, B, s) : launch_convring<2, -1, true>(a, njobs, rotate, B, s);
-  return a[0].rows_g > 128 ? launch_convring<4>(a, njobs, rotate, B, s) : launch_convring<2>(a, njobs, rotate, B, s);
+  if (a[0].f8r) return a[0].rows_g > 128 && !(g_convring_wr & 2) ? launch_convring<4, -1, true>(a, njobs, rotate, B, s) : launch_convring<2, -1, true>(a, njobs, rotate, B, s);
+  return a[0].rows_g > 128 && !(g_convring_wr & 1) ? launch_convring<4>(a, njobs, rotate, B, s) : launch_convring<2>(a, njobs, rotate, B, s);
 }
 
 int launch_f16x3_convring(const ConvArgs& a, int B, hipStream_t s) { return launch_f16x3_convring_multi(&a, 1, 0, B, s); }

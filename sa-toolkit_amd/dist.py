@@ -59,7 +59,80 @@ def all_gather_rows(local, n_items, group=None):
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], 0)
 
 
-def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, local_out=None, before_gather=None, transform=None):
+def _shard_sizes(n_items, world):
+    return [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
+
+
+class ChunkedGather:
+    """The same exchange as `all_gather_rows`, issued in pieces while the shard is still being computed: chunk c = local rows
+    [c * rows, (c + 1) * rows) of every rank (the last chunk of a ragged shard is shorter on some ranks: padded), one asynchronous
+    all-gather per chunk straight into the rows of `out` where they belong.  Same bytes on the links as the single collective,
+    hidden behind the batches still running, and a slow rank shows up at the chunk it delays (per-chunk issue / wait times in
+    `.stats`).  Every rank must call `issue(c, ...)` for the same chunks in the same order."""
+
+    def __init__(self, n_items, rows_per_chunk, group=None):
+        self.group, self.n_items, self.rows = group, int(n_items), int(rows_per_chunk)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.sizes = _shard_sizes(n_items, self.world)
+        self.starts = [shard_bounds(n_items, r, self.world)[0] for r in range(self.world)]
+        self.n_chunks = -(-max(self.sizes) // self.rows)
+        self.out = None
+        self.pending = []
+        self.stats = []
+        self._int16 = False
+
+    def chunk_rows(self, c, rank=None):
+        """local row range of chunk c on `rank` (empty past the end of a shorter shard)"""
+        n = self.sizes[self.rank if rank is None else rank]
+        return min(c * self.rows, n), min((c + 1) * self.rows, n)
+
+    def issue(self, c, local_chunk):
+        """local_chunk: this rank's rows of chunk c (already transformed), on the stream the collective may start behind"""
+        import time
+        if local_chunk.dtype == torch.int16:      # ProcessGroupNCCL has no int16: the PCM rows travel as bytes
+            local_chunk = local_chunk.contiguous().view(torch.uint8)
+            self._int16 = True
+        if self.out is None:
+            self.out = torch.empty((self.n_items,) + tuple(local_chunk.shape[1:]), dtype=local_chunk.dtype, device=local_chunk.device)
+        spans = [self.chunk_rows(c, r) for r in range(self.world)]
+        lens = [b - a for a, b in spans]
+        if local_chunk.shape[0] != lens[self.rank]:
+            raise ValueError(f"ChunkedGather.issue: chunk {c} of this rank holds {lens[self.rank]} rows, got {local_chunk.shape[0]}")
+        t0 = time.perf_counter()
+        if all(n == lens[0] for n in lens):
+            views = [self.out[self.starts[r] + spans[r][0]: self.starts[r] + spans[r][1]] for r in range(self.world)]
+            work = dist.all_gather(views, local_chunk.contiguous(), group=self.group, async_op=True)
+            self.pending.append((work, None))
+        else:
+            mx = max(lens)
+            mine = local_chunk
+            if mine.shape[0] != mx:
+                mine = torch.cat([mine, torch.zeros((mx - mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)], 0)
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            work = dist.all_gather(parts, mine.contiguous(), group=self.group, async_op=True)
+
+            def place(parts=parts, spans=spans, lens=lens):
+                for r in range(self.world):
+                    if lens[r]:
+                        self.out[self.starts[r] + spans[r][0]: self.starts[r] + spans[r][1]].copy_(parts[r][:lens[r]])
+            self.pending.append((work, place))
+        self.stats.append({"chunk": c, "rows": lens[self.rank], "issue_ms": (time.perf_counter() - t0) * 1e3})
+
+    def finish(self):
+        """wait for every chunk (the current stream waits for the collectives), place padded chunks; -> [n_items, ...]"""
+        import time
+        for i, (work, place) in enumerate(self.pending):
+            t0 = time.perf_counter()
+            work.wait()
+            if place is not None:
+                place()
+            self.stats[i]["wait_ms"] = (time.perf_counter() - t0) * 1e3
+        self.pending = []
+        return self.out.view(torch.int16) if self._int16 else self.out
+
+
+def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, local_out=None, before_gather=None, transform=None,
+                    gather_chunk_batches=0, before_chunk=None, stats=None):
     """run `convert_fn(lo, hi) -> [hi-lo, ...]` over this rank's shard in fixed batches and
     (optionally) all-gather the results in global index order.
 
@@ -68,20 +141,53 @@ def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, lo
     runs after the last batch has been issued and before the collective (e.g. make the current stream wait for the
     job streams); `transform(local)` then maps the shard to what is gathered (e.g. `pcm16_rows`).  Every rank must hold at least one item: with n_items < world some shard is empty, its rank has no
     rows to give the trailing shape of, and the collective would hang on the others — refused on ALL ranks before
-    anything is launched (the reference's `split_dict` never produces more shards than entries either)."""
+    anything is launched (the reference's `split_dict` never produces more shards than entries either).
+
+    `gather_chunk_batches` = K > 0 (needs `local_out`): the exchange is issued in chunks of K batches as they are enqueued
+    (`ChunkedGather`) instead of once at the end — `before_chunk(c, a, b)` runs before chunk c (local rows [a, b)) is handed to the
+    collective and may return a context manager the issue runs inside (e.g. a communication stream that waits for the job streams of
+    those batches).  The result equals the one-collective path's; `stats` (a dict) receives the per-chunk host timings."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if n_items < world:
         raise ValueError(f"convert_sharded: {n_items} items cannot be sharded over {world} ranks (every rank needs one)")
     lo, hi = shard_bounds(n_items, rank, world)
-    outs = [convert_fn(s, e) for s, e in batches(lo, hi, batch_size)]
+    chunked = None
+    if gather and gather_chunk_batches > 0:
+        if local_out is None:
+            raise ValueError("convert_sharded: gather_chunk_batches needs a preallocated local_out")
+        chunked = ChunkedGather(n_items, gather_chunk_batches * batch_size, group)
+    if local_out is not None and local_out.shape[0] != hi - lo:
+        raise ValueError(f"convert_sharded: local_out holds {local_out.shape[0]} rows, the shard {hi - lo}")
+    import contextlib
+
+    def issue_chunk(c):
+        a, b = chunked.chunk_rows(c)
+        ctx = before_chunk(c, a, b) if before_chunk is not None else None
+        with (ctx if ctx is not None else contextlib.nullcontext()):
+            piece = local_out[a:b]
+            chunked.issue(c, transform(piece) if transform is not None else piece)
+
+    outs, done = [], 0
+    for i, (s, e) in enumerate(batches(lo, hi, batch_size)):
+        outs.append(convert_fn(s, e))
+        if chunked is not None and (i + 1) % gather_chunk_batches == 0:
+            issue_chunk(done)
+            done += 1
     if local_out is not None:
-        if local_out.shape[0] != hi - lo:
-            raise ValueError(f"convert_sharded: local_out holds {local_out.shape[0]} rows, the shard {hi - lo}")
         local = local_out
     else:
         local = torch.cat(outs, 0)
+    if chunked is not None:
+        while done < chunked.n_chunks:            # the ragged tail of this shard, and chunks only longer shards have (empty here)
+            issue_chunk(done)
+            done += 1
     if before_gather is not None:
         before_gather()
+    if chunked is not None:
+        out = chunked.finish()
+        if stats is not None:
+            stats["chunks"] = chunked.stats
+        return out
     if transform is not None:
         local = transform(local)
     if not gather:

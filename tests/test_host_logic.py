@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.lib()
     header = open(os.path.join(ROOT, "include", "satools_hip.h")).read()
-    assert lib.sat_abi_version() == int(re.search(r"#define SAT_ABI_VERSION (\d+)", header).group(1)) == 4
+    assert lib.sat_abi_version() == int(re.search(r"#define SAT_ABI_VERSION (\d+)", header).group(1)) == 5
     declared = set(re.findall(r"\b(sat_[a-z0-9_]+)\s*\(", header))
     declared -= {"sat_status"}
     assert declared, "no declarations parsed"
@@ -191,6 +191,30 @@ out3 = sdist.convert_sharded(lambda a, b: (torch.arange(a, b, dtype=torch.float3
                              N, batch_size=4, transform=sdist.pcm16_rows)
 assert out3.dtype == torch.int16 and out3.shape == (N, 1, 5) and torch.equal(out3[:, 0, 0], torch.arange(N, dtype=torch.int16)), out3[:, 0, 0]
 assert torch.equal(sdist.pcm16_rows(torch.tensor([1.5, -1.5, 0.5 / 32768, 1.5 / 32768, -2.0])), torch.tensor([32767, -32768, 0, 2, -32768], dtype=torch.int16))
+# the exchange issued in chunks of K batches while the shard is being filled (ChunkedGather): the result of the one-collective
+# path — equal chunks go straight into their rows, the ragged last chunk (2 rows on rank 0, 1 on rank 1) travels padded
+for K in (1, 2, 5):
+    buf.fill_(-1.0)
+    order, st = [], {{}}
+    def before_chunk(c, a, b):
+        order.append((c, a, b))
+        assert bool((buf[a:b] >= 0).all())          # the chunk's batches have been produced when it is handed over
+    out4 = sdist.convert_sharded(fill, N, batch_size=4, local_out=buf, gather_chunk_batches=K, before_chunk=before_chunk,
+                                 before_gather=lambda: hooked.append(2), stats=st)
+    assert torch.equal(out4, out), (K, out4[:, 0, 0])
+    exp_chunks = {{1: [(0, 0, 4), (1, 4, hi - lo)], 2: [(0, 0, hi - lo)], 5: [(0, 0, hi - lo)]}}[K]
+    assert order == exp_chunks, (K, order)
+    assert len(st["chunks"]) == len(exp_chunks) and all("wait_ms" in c for c in st["chunks"])
+out5 = sdist.convert_sharded(lambda a, b: buf.__setitem__(slice(a - lo, b - lo), (torch.arange(a, b, dtype=torch.float32).view(-1, 1, 1) / 32768.0) * torch.ones(1, 1, 5)),
+                             N, batch_size=4, local_out=buf, transform=sdist.pcm16_rows, gather_chunk_batches=1)
+assert out5.dtype == torch.int16 and torch.equal(out5, out3)
+# equal shards (16 items): every chunk goes straight into its rows
+lo16, hi16 = sdist.shard_bounds(16, rank, 2)
+buf16 = torch.full((8, 1, 5), -1.0)
+def fill16(a, b):
+    buf16[a - lo16:b - lo16] = torch.arange(a, b, dtype=torch.float32).view(-1, 1, 1)
+out6 = sdist.convert_sharded(fill16, 16, batch_size=4, local_out=buf16, gather_chunk_batches=1)
+assert torch.equal(out6[:, 0, 0], torch.arange(16, dtype=torch.float32)) and out6.shape == (16, 1, 5)
 # fewer items than ranks: refused on every rank before any collective (no hang)
 try:
     sdist.convert_sharded(conv, 1, batch_size=4)
@@ -306,3 +330,53 @@ def test_conv_options_from_the_environment(monkeypatch):
             _lib.lib()
     finally:
         _lib._lib = saved
+
+
+def test_f16f8r_weight_packing_layout():
+    """packing.pack_conv_weight_f16f8r (SAT_CONV_F16F8R, include/satools_hip.h): [C_in/32][2 ceil(K/2) steps][8 planes][co_pad][16 B];
+    E steps carry hi f16 (plane = 4 tap + 2 chunk + half), O steps e4m3(lo 2^9) | e4m3(hi 2^-2) (plane = 4 tap + 2 term + chunk); the
+    layer scale of the SAT_CONV_F16X3 packing; an odd K is padded with a zero tap"""
+    torch.manual_seed(3)
+    w = torch.randn(128, 64, 7) * 0.05
+    p = packing.pack_conv_weight_f16f8r(w)
+    p3 = packing.pack_conv_weight_f16x3(w)
+    assert p.shape == (2, 8, 8, 128, 16) and p.dtype == torch.uint8 and p.w_descale == p3.w_descale
+    e = packing.f16x3_scale_exponent(w)
+    ws = w * 2.0 ** e
+    assert 2 ** 9 <= float(ws.abs().max()) < 2 ** 10
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    f8 = lambda t, ex: (t.float() * 2.0 ** ex).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    for pp in range(2):
+        for tp in range(4):
+            for j in range(2):
+                tap = 2 * tp + j
+                for c in range(2):
+                    ch = slice(32 * pp + 16 * c, 32 * pp + 16 * c + 16)
+                    for hf in range(2):
+                        got = p[pp, 2 * tp, 4 * j + 2 * c + hf].contiguous().view(torch.float16)           # [co][8]
+                        exp = hi[:, 32 * pp + 16 * c + 8 * hf: 32 * pp + 16 * c + 8 * hf + 8, tap] if tap < 7 else torch.zeros(128, 8, dtype=torch.float16)
+                        assert torch.equal(got, exp), (pp, tp, j, c, hf)
+                    for term, (src, ex) in enumerate(((lo, 9), (hi, -2))):
+                        got = p[pp, 2 * tp + 1, 4 * j + 2 * term + c]
+                        exp = f8(src[:, ch, tap], ex) if tap < 7 else torch.zeros(128, 16, dtype=torch.uint8)
+                        assert torch.equal(got, exp), (pp, tp, j, term, c)
+    with pytest.raises(ValueError):
+        packing.pack_conv_weight_f16f8r(torch.randn(64, 48, 3))
+
+
+def test_gpu_count_without_the_hip_runtime(monkeypatch):
+    """`ngpu = all` of the anonymize config is resolved in the PARENT of the per-GPU workers, which must not initialise HIP
+    (round-4 review): from the visibility variables, else from sysfs"""
+    from satools_amd import anonymize
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,5,7")
+    assert anonymize.parse_ngpu("all") == ["0", "1", "2"]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
+    assert anonymize.parse_ngpu("all-force") == ["0"]
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    assert len(anonymize.parse_ngpu("all")) >= 1                  # sysfs (none here: at least one id)
+    assert anonymize.parse_ngpu("[0, 3]") == ["0", "3"]
+    import inspect
+    assert "torch" not in inspect.getsource(anonymize.parse_ngpu) and "torch" not in inspect.getsource(anonymize.visible_gpu_count)

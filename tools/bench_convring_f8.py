@@ -25,6 +25,7 @@ def timed(f, n=20):
 
 
 torch.manual_seed(0)
+_lib.check(_lib.lib().sat_conv_set_option(b"convring_wr", int(os.environ.get("WR", "0"))), "convring_wr")      # 3: 128 x 320 tiles at C = 256 too
 if "gen" not in sys.argv[1:]:
     for C, T in ((256, 1250), (128, 5000)):
         x = torch.randn(B, C, T, device=dev)
