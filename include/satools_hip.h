@@ -108,12 +108,12 @@ int sat_convring_debug_stamps(int64_t* buf);
 #define SAT_CONV_F16F8 2
 /*   SAT_CONV_F16F8R (round 5) the same decomposition inside the LDS-DMA ring kernel (csrc/conv_ring16.hip; k-tap convs with
  *                  C_out > 64, C_in % 32 == 0, the generator's ResBlock epilogues): hi*hi on v_mfma_f32_16x16x32_f16, both cross
- *                  terms of a PAIR of taps in one block-scaled e4m3 v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 = 2 terms x 2 taps
+ *                  terms of a PAIR of taps in one block-scaled 8-bit v_mfma_scale_f32_16x16x128_f8f6f4 (weights e4m3, activations e5m2) (K = 128 = 2 terms x 2 taps
  *                  x 32 channels) — 2 MFMA units per product instead of 3.  The main planes stay SAT_SPLIT_F16 (the residual is
- *                  still rebuilt from hi + lo: 22 bits); the e4m3 operands travel in a SIDECAR next to them,
- *                    S8[b][c/16][2 units][t][16 B] = e4m3(hi) of 16 channels | e4m3(lo * 2^10) of 16 channels
- *                  (hi, lo = the f16 values of the main planes, round to nearest even, saturating at 448: a pure function
- *                  of the planes), read through x_split8 and written by the producer's epilogue through y_split8
+ *                  still rebuilt from hi + lo: 22 bits); the 8-bit activation operands travel in a SIDECAR next to them,
+ *                    S8[b][c/16][2 units][t][16 B] = e5m2(hi) of 16 channels | e5m2(lo * 2^10) of 16 channels
+ *                  (hi, lo = the f16 values of the main planes, round to nearest even, saturating at 57344: a pure function
+ *                  of the planes; e5m2 = f16's exponent range, so activations of any f16 magnitude keep their cross terms), read through x_split8 and written by the producer's epilogue through y_split8
  *                  (or by sat_planes_f8_sidecar).  Weights: packing.pack_conv_weight_f16f8r,
  *                    w[C_in/32][2 ceil(k/2) steps][8 planes][co_pad][16 B]; per pair of taps an f16 step (planes = (tap of the
  *                    pair, chunk of the channel pair, channel half): hi f16 of 8 channels) and an e4m3 step (planes = (tap of the
@@ -190,7 +190,7 @@ typedef struct {
 
 /* 1 when sat_conv1d_f32 / sat_conv1d_multi_f32 serve this SAT_CONV_F16F8R descriptor (the LDS-DMA ring kernel's shapes and epilogues), else 0 */
 int sat_conv1d_f8r_supported(const sat_conv1d_desc* d);
-/* the e4m3 sidecar of SAT_SPLIT_F16 planes [B][C][T] (C % 16 == 0): x_split8[b][c/16][2][t][16 B] = e4m3(hi) | e4m3(lo * 2^10) */
+/* the 8-bit (e5m2) sidecar of SAT_SPLIT_F16 planes [B][C][T] (C % 16 == 0): x_split8[b][c/16][2][t][16 B] = e5m2(hi) | e5m2(lo * 2^10) */
 int sat_planes_f8_sidecar(const void* x_split, void* x_split8, int B, int C, int T, void* stream);
 
 /* the shapes sat_conv1d_desc.up_grouped serves (1 / 0), and the zero (tap slot, phase) pairs of ConvTranspose1d(k, stride u, padding

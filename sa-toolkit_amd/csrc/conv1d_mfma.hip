@@ -1942,8 +1942,8 @@ extern "C" int sat_conv1d_f8r_supported(const sat_conv1d_desc* d) {
   return convring_supports(a, d->B) ? 1 : 0;
 }
 
-// e4m3 sidecar of SAT_SPLIT_F16 planes: thread = (utterance, chunk, position); reads the chunk's four 16-byte units at t, writes
-// e4m3(hi) and e4m3(lo * 2^10) of its 16 channels as two 16-byte units (HBM-streaming)
+// 8-bit sidecar of SAT_SPLIT_F16 planes: thread = (utterance, chunk, position); reads the chunk's four 16-byte units at t, writes
+// e5m2(hi) and e5m2(lo * 2^10) of its 16 channels as two 16-byte units (HBM-streaming)
 __global__ void __launch_bounds__(256) planes_f8_sidecar_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C, int T) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int chunk = blockIdx.y, b = blockIdx.z;
@@ -1953,15 +1953,15 @@ __global__ void __launch_bounds__(256) planes_f8_sidecar_kernel(const uint4* __r
   const h8v h0 = __builtin_bit_cast(h8v, xb[0]), h1 = __builtin_bit_cast(h8v, xb[T]);
   const h8v l0 = __builtin_bit_cast(h8v, xb[2LL * T]), l1 = __builtin_bit_cast(h8v, xb[3LL * T]);
   uint4 oh, ol;
-  oh.x = pack_e4m3x4((float)h0[0], (float)h0[1], (float)h0[2], (float)h0[3]);
-  oh.y = pack_e4m3x4((float)h0[4], (float)h0[5], (float)h0[6], (float)h0[7]);
-  oh.z = pack_e4m3x4((float)h1[0], (float)h1[1], (float)h1[2], (float)h1[3]);
-  oh.w = pack_e4m3x4((float)h1[4], (float)h1[5], (float)h1[6], (float)h1[7]);
+  oh.x = pack_e5m2x4((float)h0[0], (float)h0[1], (float)h0[2], (float)h0[3]);
+  oh.y = pack_e5m2x4((float)h0[4], (float)h0[5], (float)h0[6], (float)h0[7]);
+  oh.z = pack_e5m2x4((float)h1[0], (float)h1[1], (float)h1[2], (float)h1[3]);
+  oh.w = pack_e5m2x4((float)h1[4], (float)h1[5], (float)h1[6], (float)h1[7]);
   const float k = F8_XLO_SCALE;
-  ol.x = pack_e4m3x4((float)l0[0] * k, (float)l0[1] * k, (float)l0[2] * k, (float)l0[3] * k);
-  ol.y = pack_e4m3x4((float)l0[4] * k, (float)l0[5] * k, (float)l0[6] * k, (float)l0[7] * k);
-  ol.z = pack_e4m3x4((float)l1[0] * k, (float)l1[1] * k, (float)l1[2] * k, (float)l1[3] * k);
-  ol.w = pack_e4m3x4((float)l1[4] * k, (float)l1[5] * k, (float)l1[6] * k, (float)l1[7] * k);
+  ol.x = pack_e5m2x4((float)l0[0] * k, (float)l0[1] * k, (float)l0[2] * k, (float)l0[3] * k);
+  ol.y = pack_e5m2x4((float)l0[4] * k, (float)l0[5] * k, (float)l0[6] * k, (float)l0[7] * k);
+  ol.z = pack_e5m2x4((float)l1[0] * k, (float)l1[1] * k, (float)l1[2] * k, (float)l1[3] * k);
+  ol.w = pack_e5m2x4((float)l1[4] * k, (float)l1[5] * k, (float)l1[6] * k, (float)l1[7] * k);
   uint4* yb = y + ((long long)b * (C / 16) + chunk) * 2 * T + t;
   yb[0] = oh;
   yb[T] = ol;

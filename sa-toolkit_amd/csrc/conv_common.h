@@ -31,6 +31,19 @@ __device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float
   return (unsigned)w;
 }
 
+// the same for e5m2 (bf8: f16's exponent range with two mantissa bits; saturates at 57344) — the ACTIVATION operands of SAT_CONV_F16F8R:
+// e4m3's normal range starts at 2^-6, which a layer's inner activations can sit far below (a ResBlock whose conv1 is scaled down against its
+// conv2: the cross terms then degrade to plain-f16 accuracy, 2e-5 RMS on the waveform); e5m2 carries every f16 magnitude at 2^-3 relative
+__device__ __forceinline__ unsigned pack_e5m2x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -57344.f, 57344.f);
+  b = __builtin_amdgcn_fmed3f(b, -57344.f, 57344.f);
+  c = __builtin_amdgcn_fmed3f(c, -57344.f, 57344.f);
+  d = __builtin_amdgcn_fmed3f(d, -57344.f, 57344.f);
+  int w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+
 constexpr int CI_CHUNK = 16;  // input channels staged per K-chunk (8 MFMA k-pairs)
 
 struct ConvArgs {
@@ -415,15 +428,28 @@ __device__ __forceinline__ void mfma16_acc(f32x4& acc, const h8& a, const h8& b)
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 #endif
 }
-// the same for the block-scaled e4m3 product of K = 128 (scale operands: one E8M0 byte per lane = its 32-byte K block)
+// the same for the block-scaled 8-bit product of K = 128 (scale operands: one E8M0 byte per lane = its 32-byte K block)
 __device__ __forceinline__ void mfma8_acc(f32x4& acc, const i32x8& a, const i32x8& b, int scale_a, int scale_b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(scale_a), "v"(scale_b));
+  // (A = the weights: e4m3; B = the activations: e5m2, blgp 1)
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] blgp:1" : "+v"(acc) : "v"(a), "v"(b), "v"(scale_a), "v"(scale_b));
 #endif
 }
 __device__ __forceinline__ void mfma16_drain() {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+// the same, TIED to the accumulators it protects: every accumulator passes through an (empty) volatile asm statement behind the wait
+// states, so no vector read, copy or spill of one can be scheduled in front of them whatever else the epilogue depends on
+template <int MT, int NT>
+__device__ __forceinline__ void mfma16_drain(f32x4 (&acc)[MT][NT]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(acc[m][n]));
 #endif
 }
 

@@ -31,13 +31,13 @@ namespace sat {
 // associates differently from the 32x32x16 tile: agreement to f32 rounding of the accumulation, not bit for bit.
 //
 // F8 (round 5, SAT_CONV_F16F8R): 2 MFMA units per product instead of 3.  hi * hi stays on the f16 MFMA; the two cross terms
-// (2^-11 of the product) of a PAIR of taps go through ONE block-scaled e4m3 v_mfma_scale_f32_16x16x128_f8f6f4: K = 128 = lane
+// (2^-11 of the product) of a PAIR of taps go through ONE block-scaled 8-bit v_mfma_scale_f32_16x16x128_f8f6f4 (weights e4m3, activations e5m2: f16's exponent range): K = 128 = lane
 // group lg -> (term lg >> 1, chunk lg & 1 of the pair) x 32 bytes = 16 channels of the first tap | 16 channels of the second.
 // The rings do not change shape.  A step is still 8 planes of ROWS 16-byte units from the W ring and reads the same X tile:
 //   E step (even): W planes (tap of the pair, chunk, half) = hi f16: 40 f16 MFMAs per wave (both taps)
-//   O step (odd):  W planes (tap of the pair, term, chunk): e4m3(W_lo * 2^9) | e4m3(W_hi * 2^-2): 20 e4m3 MFMAs — the same
+//   O step (odd):  W planes (tap of the pair, term, chunk): e4m3(W_lo * 2^9) | e4m3(W_hi * 2^-2): 20 8-bit MFMAs — the same
 //                  640 matrix cycles; the per-lane E8M0 scales undo the powers of two exactly
-//   X tile:        [chunk][hi0 hi1 | e4m3(hi) e4m3(lo * 2^10)][XW]: units 0, 1 from the main planes, 2, 3 from the sidecar
+//   X tile:        [chunk][hi0 hi1 | e5m2(hi) e5m2(lo * 2^10)][XW]: units 0, 1 from the main planes, 2, 3 from the sidecar
 // An odd kernel size is padded with a zero tap (the packed weights hold it; its B operand re-reads the last tap's columns).
 // ------------------------------------------------------------------------------------------------
 
@@ -67,8 +67,8 @@ struct RingJob {
   float* y;              // f32 output (and MRF accumulator), or null
   void* y16;             // output planes of lrelu(y, y16_slope), or null
   const void* res16;     // residual as planes of lrelu(r, 1 / res16_inv), or null
-  const void* x8;        // F8: e4m3 sidecar of x16
-  void* y8;              // e4m3 sidecar of y16 to write, or null
+  const void* x8;        // F8: e5m2 sidecar of x16
+  void* y8;              // e5m2 sidecar of y16 to write, or null
   long long y_bs, y_cs;  // f32 output strides (elements) — per job: a job may store into a pitched view of its own
   float w_descale, y16_slope, res16_inv, accum_div;
   int ksize, dil, pad_left, accum;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
   const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(e.res16 ? (const char*)e.res16 + (long long)b * rows_g * T_q * 4 : (const char*)e.bias), 0,
       e.res16 ? (unsigned)(rows_g * T_q * 4) : 0u, 0x00020000);
-  // e4m3 sidecar of the output planes: [chunk][e4m3(hi) | e4m3(lo * 2^10)][T_q] x 16 bytes (one byte per channel)
+  // e5m2 sidecar of the output planes: [chunk][e5m2(hi) | e5m2(lo * 2^10)][T_q] x 16 bytes (one byte per channel)
   const __amdgpu_buffer_rsrc_t y8rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(e.y8 ? (char*)e.y8 + (long long)b * rows_g * T_q * 2 : (char*)e.bias), 0, e.y8 ? (unsigned)(rows_g * T_q * 2) : 0u, 0x00020000);
   const int y_rb = (int)e.y_cs * 4;
@@ -210,8 +210,8 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
         __builtin_amdgcn_raw_buffer_store_b128(unit, y16rs, off, 0, 0);
         if (has_y8) {
           // a function of the plane values (hi, lo as f16): four channels = bytes 4 lg .. 4 lg + 3 of the chunk's unit at q
-          const unsigned x8h = pack_e4m3x4((float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]);
-          const unsigned x8l = pack_e4m3x4((float)l01[0] * F8_XLO_SCALE, (float)l01[1] * F8_XLO_SCALE, (float)l23[0] * F8_XLO_SCALE,
+          const unsigned x8h = pack_e5m2x4((float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]);
+          const unsigned x8l = pack_e5m2x4((float)l01[0] * F8_XLO_SCALE, (float)l01[1] * F8_XLO_SCALE, (float)l23[0] * F8_XLO_SCALE,
                                            (float)l23[1] * F8_XLO_SCALE);
           const unsigned off8 = qok ? (unsigned)(((chunk * 2) * T_q + q) * 16 + 4 * lg) : OOB;
           __builtin_amdgcn_raw_buffer_store_b32(x8h, y8rs, off8, 0, 0);
@@ -250,7 +250,7 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     u32x4 un[4];
-    unsigned x8[2][4];                                  // e4m3 sidecar: [e4m3(hi) | e4m3(lo * 2^10)][strip], this lane's four channels
+    unsigned x8[2][4];                                  // e5m2 sidecar: [e5m2(hi) | e5m2(lo * 2^10)][strip], this lane's four channels
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       float u[4];
@@ -268,8 +268,8 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
       const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, l23), false, false);
       un[m] = u32x4{s0[0], s1[0], s0[1], s1[1]};
       if (has_y8) {
-        x8[0][m] = pack_e4m3x4((float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]);
-        x8[1][m] = pack_e4m3x4((float)l01[0] * F8_XLO_SCALE, (float)l01[1] * F8_XLO_SCALE, (float)l23[0] * F8_XLO_SCALE, (float)l23[1] * F8_XLO_SCALE);
+        x8[0][m] = pack_e5m2x4((float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]);
+        x8[1][m] = pack_e5m2x4((float)l01[0] * F8_XLO_SCALE, (float)l01[1] * F8_XLO_SCALE, (float)l23[0] * F8_XLO_SCALE, (float)l23[1] * F8_XLO_SCALE);
       }
     }
     // 4 x 4 transposition (strip m, lane l of the quad) -> (store j, lane l): first strip bit 0 against lane bit 0, then bit 1 against bit 1
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     NP = A.cin_pad / (2 * CI_CHUNK), NS = NP * KS;
     seg_bytes = A.co_pad * 16;
     if (F8 && idx >= 2) {
-      // this wave's X rows are the sidecar's: units (e4m3(hi), e4m3(lo * 2^10)) of its chunk
+      // this wave's X rows are the sidecar's: units (e5m2(hi), e5m2(lo * 2^10)) of its chunk
       x_chunk_bytes = 2 * A.T_in * 16;
       xrs = dma_rsrc((const char*)p.x8 + (long long)t.b * A.cin_g * A.T_in * 2, (unsigned)(A.cin_g * A.T_in * 2));
     } else {
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
   };
 
   // fragment addresses (units): lane (li, lg) reads chunk lg >> 1, half lg & 1; lo planes 2 segments further
-  // (F8: W plane = 4 (tap of the pair) + lg in both kinds of step; the e4m3 B unit of lane group lg = plane 2 + term of chunk lg & 1)
+  // (F8: W plane = 4 (tap of the pair) + lg in both kinds of step; the 8-bit B unit of lane group lg = plane 2 + term of chunk lg & 1)
   const int a_lane = F8 ? lg * ROWS + wr * 64 + li : (lg >> 1) * 4 * ROWS + (lg & 1) * ROWS + wr * 64 + li;
   const int b_lane = (lg >> 1) * 4 * XW + (lg & 1) * XW + wc * (16 * NT) + li;
   const int b_lane8 = (lg & 1) * 4 * XW + (2 + (lg >> 1)) * XW + wc * (16 * NT) + li;
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     if (++t3 == KS) t3 = 0, ++p3;
   };
   // ---- F8: CUR = 0 the E step of a pair of taps (hi * hi of both taps on the f16 MFMA: 40 per wave), CUR = 1 its O step (both
-  // cross terms of both taps in one e4m3 MFMA of K = 128: 20 per wave, the same matrix cycles).  Same rings, same waits.
+  // cross terms of both taps in one 8-bit MFMA of K = 128: 20 per wave, the same matrix cycles).  Same rings, same waits.
   auto body8 = [&](auto cur, auto late_c, auto more_c) __attribute__((always_inline)) {
     constexpr int CUR = decltype(cur)::value;
     constexpr bool LATE = decltype(late_c)::value, MORE = decltype(more_c)::value;
@@ -633,16 +633,15 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
       while (s + 6 < NS) six(std::true_type{});
       six(std::false_type{});
     } else {
+      // (NS = NP x taps is even: convring_supports sends an odd number of steps to the register-staged tile — one loop tail less to
+      // instantiate; with three the register allocator shuffled accumulators between the tails and spilled some right behind the MFMA
+      // that writes them, tests/test_codegen_invariants.py)
       while (s + 2 < NS) {
         body(I0{}, L{}, std::true_type{}, NOT{});
         body(I1{}, L{}, std::true_type{}, NOT{});
       }
-      if (s + 1 < NS) {
-        body(I0{}, L{}, std::true_type{}, NOT{});
-        body(I1{}, L{}, std::false_type{}, NOT{});
-      } else {
-        body(I0{}, L{}, std::false_type{}, NOT{});
-      }
+      body(I0{}, L{}, std::true_type{}, NOT{});
+      body(I1{}, L{}, std::false_type{}, NOT{});
     }
   };
 
@@ -703,7 +702,7 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     }
     long long p0 = 0;
     if constexpr (STAMP) p0 = cr_clock();
-    mfma16_drain();
+    mfma16_drain(acc);
     if (!(A.diag & 4)) {
       const RingJob ej = A.job[done.j];
       if constexpr (UPS) ring_epilogue_ups<NT>(ej, A, acc, done.b, done.co_b + wr * 64, done.q_b + wc * (16 * NT), li, lg);
@@ -768,6 +767,8 @@ bool convring_supports(const ConvArgs& a, int B) {
   if (a.ch_scale || a.relu || a.gelu || a.res || a.res_after || !a.bias || (a.res16 && a.res_scale != 1.f) || (a.accum && a.no_y)) return false;
   const int halo = (a.ksize - 1) * a.dil;
   if (halo > 64) return false;                     // (X tiles: 160 + 64, 320 + 64, 384 + 64 columns)
+  // an even number of K steps (chunk pairs x taps; the F8 form's E / O steps always are): the loop has ONE tail
+  if (!a.f8r && ((a.cin_pad / (2 * CI_CHUNK)) * a.ksize) % 2 != 0) return false;
   const long long tiles = a.rows_g > 128 ? (long long)ceil_div(a.rows_g, 256) * ceil_div(a.T_q, 160) * B
                           : a.rows_g > 64 ? (long long)ceil_div(a.T_q, 320) * B : (long long)ceil_div(a.T_q, 384) * B;
   // (SAT_CONV_F16F8R weights are packed for this kernel alone: at every number of tiles)
@@ -835,7 +836,7 @@ static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipS
   }
   if (g_convring_dbg) hipLaunchKernelGGL(kern_st, dim3(grid), dim3(512), lds_bytes, s, A, g_convring_dbg);
   else hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, s, A, (long long*)nullptr);
-  SAT_LAUNCH_CHECK(F8 ? "conv1d_f16x3_ring16_kernel (F8: e4m3 cross terms)" : "conv1d_f16x3_ring16_kernel");
+  SAT_LAUNCH_CHECK(F8 ? "conv1d_f16x3_ring16_kernel (F8: 8-bit cross terms)" : "conv1d_f16x3_ring16_kernel");
   return SAT_OK;
 }
 

@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_ring16_kernel(const ConvArg
 
   // the residual of the whole wave tile is requested in one go (the fragment registers are dead by now): one memory
   // round trip in the exposed epilogue of a one-block-per-CU kernel
-  mfma16_drain();
+  mfma16_drain(acc);
   f32x4 rpre[MT][NT];
   if (p.res || p.res16) epilogue16_prefetch_res<MT, NT>(p, rpre, b, co_b + wm * 64, q_b + wn * 64, li, lg);
   conv_epilogue16<MT, NT>(p, acc, rpre, b, co_b + wm * 64, q_b + wn * 64, li, lg);

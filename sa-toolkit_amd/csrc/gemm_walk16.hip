@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16x3_walk16_kernel(const WalkArg
       setup(nxt_t);
       issue_prologue(par);
     }
-    mfma16_drain();
+    mfma16_drain(acc);
     if (!(A.diag & 4)) {
       const WalkJob e = A.job[done.j];
       const float* bl = bias_lds + done_par * (WK_BIAS_UNITS * 4);

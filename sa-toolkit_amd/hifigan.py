@@ -16,12 +16,12 @@ from .params import CoreHifiGanParams
 
 class CoreHifiGan(CoreHifiGanParams):
     #: matrix-product arithmetic of the generator convs: "f16x3" (split-f16 on the f16 matrix cores,
-    #: ~2^-21 relative per product), "f16f8r" (round 5: "f16x3" with the ResBlock convs of the THICK stages — C >= 128, the
+    #: ~2^-21 relative per product), "f16f8r" (round 5, the default: "f16x3" with the ResBlock convs of the THICK stages — C >= 128, the
     #: LDS-DMA ring kernel — computing hi*hi in f16 and both cross terms on the block-scaled e4m3 MFMA: 2 MFMA units per
     #: product instead of 3, ~2^-15 per product on those layers; batches too small for the ring kernel run "f16x3"),
     #: "f16f8" (round 1: every conv that way on the register-staged tile, slower than "f16x3") or "f32" (exact f32 MFMA).
     #: The output stage is always f32.
-    precision = os.environ.get("SATOOLS_AMD_GEN_PRECISION", "f16x3")
+    precision = os.environ.get("SATOOLS_AMD_GEN_PRECISION", "f16f8r")
     #: "f16f8r": bit i = stage i may run its ResBlock convs with e4m3 cross terms (default: every stage the ring kernel serves)
     f8_stages = int(os.environ.get("SATOOLS_AMD_GEN_F8_STAGES", "255"))
     #: hand activations between layers as split planes (csrc/hifigan.hip); 0 = f32 tensors

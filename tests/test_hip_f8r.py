@@ -9,6 +9,11 @@ import torch.nn.functional as F
 from conftest import rms
 from test_hip_parity import DEV, _e4m3, _ops, _rand, conv_option
 
+
+def _e5m2(t, exp=0):
+    """the activation operands' format: e5m2 (bf8), round to nearest even, saturating at 57344"""
+    return (t * 2.0 ** exp).clamp(-57344, 57344).to(torch.float32).to(torch.float8_e5m2)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -22,19 +27,20 @@ def _planes_hi_lo(ops, s):
 def _sidecar_bytes(hi, lo):
     """what the sidecar of planes (hi, lo) must hold: [B][C/16][2][T][16] uint8"""
     B, C, T = hi.shape
-    h8 = _e4m3(hi).view(torch.uint8).reshape(B, C // 16, 16, T).permute(0, 1, 3, 2)
-    l8 = _e4m3(lo, 10).view(torch.uint8).reshape(B, C // 16, 16, T).permute(0, 1, 3, 2)
+    h8 = _e5m2(hi).view(torch.uint8).reshape(B, C // 16, 16, T).permute(0, 1, 3, 2)
+    l8 = _e5m2(lo, 10).view(torch.uint8).reshape(B, C // 16, 16, T).permute(0, 1, 3, 2)
     return torch.stack([h8, l8], 2).contiguous()
 
 
 @pytest.mark.parametrize("B,C,T", [(2, 32, 301), (1, 128, 5000), (3, 256, 77)], ids=lambda v: str(v))
-def test_planes_f8_sidecar_is_e4m3_of_the_plane_values(B, C, T):
-    """sat_planes_f8_sidecar: unit 0 = e4m3(hi), unit 1 = e4m3(lo * 2^10) of the f16 plane values, one byte per channel, OCP e4m3
-    round-to-nearest-even saturating at 448 like torch.float8_e4m3fn; large and tiny activations included"""
+def test_planes_f8_sidecar_is_e5m2_of_the_plane_values(B, C, T):
+    """sat_planes_f8_sidecar: unit 0 = e5m2(hi), unit 1 = e5m2(lo * 2^10) of the f16 plane values, one byte per channel, round to
+    nearest even like torch.float8_e5m2, saturating at 57344; large and tiny activations included"""
     ops, _ = _ops()
     x = _rand(B, C, T, seed=11, scale=3.0)
-    x[0, :, :7] *= 300.0            # beyond 448: saturates
-    x[0, :, 7:14] *= 1e-4           # e4m3 subnormals / zero
+    x[0, :, :7] *= 300.0
+    x[0, :, 7:14] *= 1e-4           # e5m2 subnormals
+    x[-1, :, 20:27] *= 30000.0      # beyond 57344 (and f16): saturates
     s = ops.act_split(x.to(DEV), 0.1)
     got = ops.planes_f8_sidecar(s).cpu()
     hi, lo = _planes_hi_lo(ops, s)
@@ -60,7 +66,7 @@ def test_ring_conv_f16f8r_matches_its_decomposition(C, T, k, dil):
     kw = dict(bias=b, dilation=dil, pad_left=pl, mode=3, x_split=xs, x_split8=xs8, y_split_slope=0.1)
     assert ops.conv1d_f8r_supported(x, w8, C, k, **kw)
     # the value SAT_CONV_F16F8R computes, in float64, from the kernel's own input planes and the packer's own rounding:
-    # [hi . hi + e4m3(W_lo 2^9) 2^-9 . e4m3(x_hi) + e4m3(W_hi 2^-2) 2^2 . e4m3(x_lo 2^10) 2^-10] 2^-e  (explicit padding: an even
+    # [hi . hi + e4m3(W_lo 2^9) 2^-9 . e5m2(x_hi) + e4m3(W_hi 2^-2) 2^2 . e5m2(x_lo 2^10) 2^-10] 2^-e  (explicit padding: an even
     # kernel's 'same' padding is asymmetric)
     xh, xl = _planes_hi_lo(ops, xs)
 
@@ -71,8 +77,8 @@ def test_ring_conv_f16f8r_matches_its_decomposition(C, T, k, dil):
     wh = ws.to(torch.float16).float()
     wl = (ws - wh).to(torch.float16).float()
     conv = lambda a, ww: F.conv1d(padded(a).double(), ww.double(), None, dilation=dil)
-    emu = (conv(xh, wh) + conv(_e4m3(xh).float(), _e4m3(wl, 9).float() / 2 ** 9)
-           + conv(_e4m3(xl, 10).float() / 2 ** 10, _e4m3(wh, -2).float() * 4.0)) / 2.0 ** e + b.double().cpu()[None, :, None]
+    emu = (conv(xh, wh) + conv(_e5m2(xh).float(), _e4m3(wl, 9).float() / 2 ** 9)
+           + conv(_e5m2(xl, 10).float() / 2 ** 10, _e4m3(wh, -2).float() * 4.0)) / 2.0 ** e + b.double().cpu()[None, :, None]
     exact = F.conv1d(padded(F.leaky_relu(x.double().cpu(), 0.1)), w.double().cpu(), b.double().cpu(), dilation=dil)
     r64 = r.double().cpu()
     # (1) planes + sidecar only
@@ -236,7 +242,8 @@ def test_generator_f16f8r_matches_golden_teacher_forced(model, gold):
     from satools_amd import _lib
     fx = gold.npz("fx_gen.npz")
     spk = F.one_hot(torch.from_numpy(fx["spk_argmax"]), len(model.spk))
-    y0 = model._forward(torch.from_numpy(fx["f0_raw"].copy()), torch.from_numpy(fx["bn"]), spk)
+    with gen_precision(model.hifigan, "f16x3"):
+        y0 = model._forward(torch.from_numpy(fx["f0_raw"].copy()), torch.from_numpy(fx["bn"]), spk)
     with gen_precision(model.hifigan, "f16f8r"), conv_option("convring", 33, 1):
         y = model._forward(torch.from_numpy(fx["f0_raw"].copy()), torch.from_numpy(fx["bn"]), spk)
         assert len(model.hifigan._packed8) == 36            # 2 stages x 3 branches x 3 steps x 2 convs
@@ -264,7 +271,8 @@ def test_full_size_batch_f16f8r(model, fbank_tag_state):
     f0n = f0.to(DEV).clone()
     ops.f0_norm_transform_(f0n)
     x = ops.assemble_input(bn, f0n, spk, spk.shape[1])
-    base = model.hifigan(x)[0].clone()
+    with gen_precision(model.hifigan, "f16x3"):
+        base = model.hifigan(x)[0].clone()
     with gen_precision(model.hifigan, "f16f8r"):
         full = model.hifigan(x)[0].clone()
         assert torch.equal(full, model.hifigan(x)[0])
@@ -294,6 +302,7 @@ def test_check_precision_f16f8r_falls_back_to_f16x3_first():
     m.to(DEV)
     m.eval()
     wav = synthetic.harm_batch([2], 16000).to(DEV)
+    m.hifigan.precision = "f16x3"
     y3 = m.convert(wav, target=m.spk[1]).clone()
     m.hifigan.precision = "f16f8r"
     rep = m.check_precision()
@@ -307,3 +316,59 @@ def test_check_precision_f16f8r_falls_back_to_f16x3_first():
     assert "generator: f16f8r -> f16x3" in rep["fallback"] and "generator" not in rep["fallback"] and m.hifigan.precision == "f16x3" and w
     m.bn_extractor.precision = "f16x3"          # (the extractor's own guard tripped on that tolerance too)
     assert torch.equal(m.convert(wav, target=m.spk[1]), y3)
+
+
+# ---------------------------------------------------------------------------------------------
+# the parity gates of the other test modules, run again with the e4m3 kernels on EVERY batch size (their own batches are too small for
+# the ring kernel's default dispatch, so the default "f16f8r" generator serves them on the f16x3 tiles): option convring = 33
+# ---------------------------------------------------------------------------------------------
+class f8_everywhere:
+    def __enter__(self):
+        from satools_amd import _lib
+        from satools_amd.hifigan import CoreHifiGan
+        self.keep = CoreHifiGan.precision
+        CoreHifiGan.precision = "f16f8r"
+        _lib.check(_lib.lib().sat_conv_set_option(b"convring", 33), "sat_conv_set_option")
+
+    def __exit__(self, *a):
+        from satools_amd import _lib
+        from satools_amd.hifigan import CoreHifiGan
+        CoreHifiGan.precision = self.keep
+        _lib.check(_lib.lib().sat_conv_set_option(b"convring", 1), "sat_conv_set_option")
+
+
+def test_golden_gates_with_the_e4m3_kernels_at_every_batch_size(model, gold, fbank_tag_state):
+    """every generator / end-to-end golden fixture of tests/test_hip_parity.py with the thick stages on SAT_CONV_F16F8R"""
+    import test_hip_parity as P
+    g = model.hifigan
+    with f8_everywhere():
+        g.precision = "f16f8r"
+        g.invalidate()
+        x = torch.randn(1, g.imput_dim, 40, generator=torch.Generator().manual_seed(1)).to(DEV)
+        y8 = g(x)[0].clone()
+        assert len(g._packed8) == 36
+        P.test_generator_matches_golden_teacher_forced(model, gold)
+        P.test_convert_matches_golden(model, gold)
+        for shape in [(1, 4800), (3, 16123), (2, 31999), (5, 9600)]:
+            P.test_convert_ragged_sizes_match_oracle(model, fbank_tag_state, shape)
+        P.test_generator_survives_rescaled_layer_pairs()
+    with P.conv_option("convring", 33, 1):
+        g.precision = "f16x3"
+        g.invalidate()
+        y3 = g(x)[0].clone()
+    g.precision = "f16f8r"
+    g.invalidate()
+    assert not torch.equal(y8, y3) and rms((y8 - y3).cpu().numpy()) < 1e-5          # the e4m3 kernels did run, and agree
+
+
+@pytest.mark.parametrize("seconds", [20, 35])
+def test_long_utterances_with_the_e4m3_kernels(fbank_tag_state, seconds):
+    """convert() of 2 x 20 s and 2 x 35 s (tests/test_hip_robust.py) with the thick stages on SAT_CONV_F16F8R: RMS < 1e-5 against the oracle"""
+    import satools_amd
+    import test_hip_robust as R
+    with f8_everywhere():
+        m = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1")
+        m.to(DEV)
+        m.eval()
+        assert m.hifigan.precision == "f16f8r"
+        R.test_convert_long_utterances_fbank_tag(m, fbank_tag_state, seconds)

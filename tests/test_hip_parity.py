@@ -271,6 +271,21 @@ def model():
     return _model()
 
 
+@pytest.fixture
+def model_f16x3(model):
+    """the module's model with the generator pinned to "f16x3" (the tests of that arithmetic's own bit equalities; the product default
+    is "f16f8r" since round 5, whose kernels tests/test_hip_f8r.py covers)"""
+    g = model.hifigan
+    old = g.precision
+    g.precision = "f16x3"
+    g.invalidate()
+    try:
+        yield model
+    finally:
+        g.precision = old
+        g.invalidate()
+
+
 def test_fbank_cmvn_pad_matches_oracle(model):
     from oracle import fbank as ofb
     from oracle import tdnnf as otd
@@ -485,13 +500,14 @@ def test_fused_pair_split_planes(case):
     assert (ops.unsplit(ys3) - F.leaky_relu(ref, 0.1)).abs().max() <= 2e-6
 
 
-def test_generator_split_plane_pipeline_equals_f32_handover(model, gold):
+def test_generator_split_plane_pipeline_equals_f32_handover(model_f16x3, gold):
     """the generator with split-plane activations between layers vs the same kernels fed with f32
     activations: same arithmetic, different staging"""
     from satools_amd._lib import lib, check
     fx = gold.npz("fx_gen.npz")
+    model = model_f16x3
     g = model.hifigan
-    if g.precision != "f16x3":
+    if g.precision not in ("f16x3", "f16f8r"):
         pytest.skip("split planes belong to the split-f16 generator")
     x = torch.randn(2, g.imput_dim, 25, generator=torch.Generator().manual_seed(3)).to(DEV)
     with conv_option("convring", 33, 1):
@@ -709,8 +725,10 @@ def test_full_size_batch_properties(model, fbank_tag_state):
         assert torch.equal(full_ring, full)
         for sl in (slice(0, 1), slice(5, 9), slice(29, 32)):
             assert torch.equal(model.hifigan(x[sl].contiguous())[0], full[sl])
+    # (round 5: with the default "f16f8r" generator a small batch is also another ARITHMETIC on the thick stages — the f16x3 tiles instead
+    # of the ring kernel's e4m3 cross terms, 7e-7 RMS apart; both within 1e-5 of the oracle)
     for sl in (slice(0, 1), slice(5, 9)):
-        assert rms((model.hifigan(x[sl].contiguous())[0] - full[sl]).cpu().numpy()) < 5e-7
+        assert rms((model.hifigan(x[sl].contiguous())[0] - full[sl]).cpu().numpy()) < (5e-7 if model.hifigan.precision == "f16x3" else 3e-6)
     _, gen_sd = oconv.split_state_dict(fbank_tag_state[0]["base_model_state_dict"])
     ref = ohg.generator(gen_sd, x[17:18].cpu())
     err = rms((full[17:18].cpu() - ref).numpy())
@@ -1394,12 +1412,13 @@ def _multi_equals_singles(ops, packing, _lib, jobs, ks, B, C, T, x, xs, bs):
         ops.conv1d_multi([j3] * 4)
 
 
-def test_generator_multi_branch_launches_give_the_same_bits(model):
+def test_generator_multi_branch_launches_give_the_same_bits(model_f16x3):
     """generator option "multi_branch": the i-th conv of all three MRF branches of the thick stages as one
     sat_conv1d_multi_f32 call against the eighteen single launches per stage"""
     from satools_amd._lib import lib, check
+    model = model_f16x3
     g = model.hifigan
-    if g.precision != "f16x3":
+    if g.precision not in ("f16x3", "f16f8r"):
         pytest.skip("the ring conv belongs to the split-f16 generator")
     x = torch.randn(3, g.imput_dim, 57, generator=torch.Generator().manual_seed(5)).to(DEV)
     with conv_option("convring", 33, 1):                 # (the ring kernel also for this small batch)
@@ -1412,13 +1431,14 @@ def test_generator_multi_branch_launches_give_the_same_bits(model):
     assert torch.equal(y0, y1)
 
 
-def test_generator_stride4_upsamplers_on_the_ring(model):
+def test_generator_stride4_upsamplers_on_the_ring(model_f16x3):
     """generator attribute `ups_ring`: the two stride-4 upsamplers packed with their rows grouped by phase and run by the LDS-DMA ring
     (another accumulation order than the 64 x 256 tile: f32 rounding), the row order kept by the frozen export, and the pipelines that
     cannot read that order refusing it"""
     from satools_amd._lib import lib, check, SatError
+    model = model_f16x3
     g = model.hifigan
-    if g.precision != "f16x3" or not g.split_acts:
+    if g.precision not in ("f16x3", "f16f8r") or not g.split_acts:
         pytest.skip("the grouped rows belong to the split-f16 generator on the split-plane pipeline")
     x = torch.randn(2, g.imput_dim, 41, generator=torch.Generator().manual_seed(6)).to(DEV)
     keep = g.ups_ring

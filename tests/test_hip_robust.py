@@ -404,7 +404,7 @@ def test_check_precision_guards_against_out_of_range_checkpoints():
     rep = model.check_precision()
     print("check_precision on the synthetic checkpoint:", rep)
     assert rep["fallback"] == [] and rep["generator"] < 2e-5 and rep["bn_index_agreement"] == 1.0 and rep["bn_extractor"] < 1e-4
-    assert model.hifigan.precision == "f16x3" and model.bn_extractor.precision == "f16x3"
+    assert model.hifigan.precision in ("f16x3", "f16f8r") and model.bn_extractor.precision == "f16x3"      # kept as loaded
     state, _ = synthetic.checkpoint(FBANK_TAG)
     sd = {k: v.clone() for k, v in state["base_model_state_dict"].items()}
     for k in list(sd):
