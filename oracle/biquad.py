@@ -81,23 +81,65 @@ def fir(x, kind, sample_rate, cutoff, order="torchaudio"):
     raise ValueError(order)
 
 
-def biquad(x, kind, sample_rate, cutoff, order="torchaudio"):
-    """x: 1-D float32 numpy array -> filtered, clamped float32 array"""
+#: evaluation orders of the RECURSION half (the study of tests/golden/make_biquad_iir_crosscheck.py; "torchaudio" is shipped):
+#:   "torchaudio"  v = f - c2*y2; v = v - c1*y1      the C++ loop as published: multiply, subtract, a2 term first
+#:   "c1_first"    v = f - c1*y1; v = v - c2*y2
+#:   "fma"         v = fma(-c2, y2, f); v = fma(-c1, y1, v)   the same loop compiled with FMA contraction (-ffp-contract=fast, e.g. aarch64 builds)
+#:   "sum_first"   v = f - (c1*y1 + c2*y2)
+IIR_ORDERS = ("torchaudio", "c1_first", "fma", "sum_first")
+
+
+def _fma32_scalar(a, b, c):
+    """correctly rounded f32 fma of three python floats holding f32 values (exact product, round-to-odd float64 sum)"""
+    import struct
+    p = a * b
+    s = p + c
+    bb = s - p
+    e = (p - (s - bb)) + (c - bb)
+    if e != 0.0 and not (struct.unpack("<q", struct.pack("<d", s))[0] & 1):
+        s = math.nextafter(s, math.inf if e > 0 else -math.inf)
+    return float(np.float32(s))
+
+
+def biquad(x, kind, sample_rate, cutoff, order="torchaudio", iir="torchaudio", clamp=True):
+    """x: 1-D float32 numpy array -> filtered, clamped float32 array.  `order`: FIR summation order (ORDERS), `iir`: evaluation
+    order of the recursion (IIR_ORDERS)"""
     _, _, _, _, c1, c2 = kernel_constants(kind, sample_rate, cutoff)
     f = fir(x, kind, sample_rate, cutoff, order)
     out = np.empty_like(f)
-    y1 = np.float32(0)
-    y2 = np.float32(0)
-    for t in range(f.shape[0]):
-        v = f[t] - c2 * y2
-        v = v - c1 * y1
-        out[t] = v
-        y2 = y1
-        y1 = v
-    return np.clip(out, np.float32(-1), np.float32(1))
+    if iir == "fma":
+        fc1, fc2 = float(c1), float(c2)
+        y1 = y2 = 0.0
+        fl = f.astype(np.float64).tolist()
+        res = []
+        for t in range(len(fl)):
+            v = _fma32_scalar(-fc2, y2, fl[t])
+            v = _fma32_scalar(-fc1, y1, v)
+            res.append(v)
+            y2 = y1
+            y1 = v
+        out[:] = np.asarray(res, dtype=np.float32)
+    else:
+        y1 = np.float32(0)
+        y2 = np.float32(0)
+        for t in range(f.shape[0]):
+            if iir == "torchaudio":
+                v = f[t] - c2 * y2
+                v = v - c1 * y1
+            elif iir == "c1_first":
+                v = f[t] - c1 * y1
+                v = v - c2 * y2
+            elif iir == "sum_first":
+                v = f[t] - (c1 * y1 + c2 * y2)
+            else:
+                raise ValueError(iir)
+            out[t] = v
+            y2 = y1
+            y1 = v
+    return np.clip(out, np.float32(-1), np.float32(1)) if clamp else out
 
 
-def band_limit(x, sample_rate=16000, bp_low=50.0, bp_high=1500.0, order="torchaudio"):
+def band_limit(x, sample_rate=16000, bp_low=50.0, bp_high=1500.0, order="torchaudio", iir="torchaudio"):
     """SignalObj.filtered_version (yaapt.py:42-51): low-pass at bp_low THEN high-pass at bp_high
     (yes, as written in the reference), each through its own clamped lfilter"""
-    return biquad(biquad(x, "lp", sample_rate, bp_low, order), "hp", sample_rate, bp_high, order)
+    return biquad(biquad(x, "lp", sample_rate, bp_low, order, iir), "hp", sample_rate, bp_high, order, iir)

@@ -373,12 +373,12 @@ def dynamic(rp, rm, energy, plan):
     return rp[path, torch.arange(T)]
 
 
-def yaapt_one(x, opts, aux=None, biquad_order="torchaudio"):
+def yaapt_one(x, opts, aux=None, biquad_order="torchaudio", biquad_iir="torchaudio"):
     """x [n] f32 -> final pitch [nframes] (Hz, 0 = unvoiced)   (`_yaapt`, yaapt.py:795-944).
     `biquad_order`: FIR summation order of the third-party biquads (oracle/biquad.py)"""
     plan = Plan(x.numel(), opts)
     sig = F.pad(x.to(F32), (plan.pad, plan.pad))
-    bl = lambda v: torch.from_numpy(biquad.band_limit(v.numpy(), int(plan.fs), plan.p["bp_low"], plan.p["bp_high"], biquad_order))
+    bl = lambda v: torch.from_numpy(biquad.band_limit(v.numpy(), int(plan.fs), plan.p["bp_low"], plan.p["bp_high"], biquad_order, biquad_iir))
     filt = bl(sig)
     filt2 = bl(sig ** 2)
     energy, vuv = nlfer(filt, plan)

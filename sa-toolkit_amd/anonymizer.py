@@ -165,10 +165,14 @@ def build(args):
                     try:                                   # whatever happens in between (an OOM on the 16x slower exact kernels ...),
                         for k in cfg:                      # the configuration is restored unless the fall-back was DECIDED
                             setattr(ext, k, "f32")
-                        _, (z32, idx32, _) = ext.extract_bn(wav.clone(), want_aux=True)
+                        _, (z32, idx32, d32) = ext.extract_bn(wav.clone(), want_aux=True)
                         bn32 = self.get_bn(wav)
                         out["bn_extractor"] = relrms(z, z32)
                         out["bn_index_agreement"] = float((idx == idx32).float().mean())
+                        # index work is exact work: say how many decisions differ, and whether each is a near-tie of the exact kernels
+                        from .asrbn import vq_flip_stats
+                        st = vq_flip_stats(z, idx, z32, idx32, d32)
+                        out["bn_index_flips"] = {k: st[k] for k in ("frames", "flips", "flips_per_million", "flips_outside_error_bound")}
                         if not (out["bn_extractor"] <= 5 * tol and out["bn_index_agreement"] >= 0.98) and fallback:
                             fell.append("bn_extractor")
                             keep_f32 = True

@@ -55,6 +55,27 @@ def mel_banks(num_bins=80, n_fft=512, sample_freq=16000.0, low_freq=20.0, high_f
     return torch.nn.functional.pad(bins, (0, 1)).to(torch.float32).contiguous()
 
 
+def vq_flip_stats(z, idx, z_exact, idx_exact, dist_exact):
+    """VQ decisions of one arithmetic against the exact-f32 kernels' on the same frames (chain/nn.py:424-459: argmin over the
+    codebook's squared distances).  z / z_exact [B, D, T] projections before the decision, idx / idx_exact [B, T], dist_exact
+    [B, T, n_codes].  A frame whose index differs ("flip") is INSIDE the bound when the exact kernels' own two best distances are
+    closer than what that frame's measured feature difference dz can move them, |d_k(z + dz) - d_k(z)| <= 2 |dz| sqrt(d_k) + |dz|^2
+    for both candidates — a near-tie, not an error of the arithmetic.  Returns counts (python ints / floats)."""
+    idx, idx_exact = idx.reshape(-1).long(), idx_exact.reshape(-1).long()
+    flips = torch.nonzero(idx != idx_exact).flatten()
+    out = {"frames": int(idx.numel()), "flips": int(flips.numel()), "flips_per_million": 1e6 * flips.numel() / max(1, idx.numel()),
+           "flips_outside_error_bound": 0, "flip_frames": flips.tolist()[:64]}
+    if flips.numel():
+        d2 = torch.sort(dist_exact.reshape(-1, dist_exact.shape[-1]).double()[flips], dim=1)[0].clamp_min(0)
+        D = z.shape[1]
+        dz = (z.permute(0, 2, 1).reshape(-1, D)[flips].double() - z_exact.permute(0, 2, 1).reshape(-1, D)[flips].double()).norm(dim=1)
+        bound = 2 * dz * (d2[:, 0].sqrt() + d2[:, 1].sqrt()) + 2 * dz ** 2
+        gap = d2[:, 1] - d2[:, 0]
+        out["flips_outside_error_bound"] = int((gap > bound).sum())
+        out["largest_gap_over_bound"] = float((gap / bound.clamp_min(1e-300)).max())
+    return out
+
+
 class _LayerCache:
     """device-side, kernel-ready form of one TDNNFBatchNorm layer"""
     __slots__ = ("wB", "bB", "wA", "bA", "scale", "shift", "codebook", "modeA", "modeB")
@@ -184,6 +205,21 @@ class _TdnnfBase(nn.Module):
         y = ops.conv1d(z, c.wA, lay.out_dim, 1, bias=c.bA, ch_scale=c.scale, ch_shift=c.shift, relu=True, mode=c.modeA,
                        x_split=zs, y_split=ys, y_split_slope=1.0, **kw)
         return y, ys
+
+    def vq_flip_report(self, wav):
+        """`vq_flip_stats` of this extractor as configured against its exact-f32 kernels on `wav` [N, n] (device tensor; left
+        untouched): how many VQ indices the split-f16 arithmetic decides differently, and whether every one of them is a near-tie."""
+        keys = [k for k in ("precision", "w2v2_precision") if hasattr(self, k)]
+        cfg = {k: getattr(self, k) for k in keys}
+        _, (z, idx, _) = self.extract_bn(wav.clone(), want_aux=True)
+        try:
+            for k in keys:
+                setattr(self, k, "f32")
+            _, (z32, idx32, d32) = self.extract_bn(wav.clone(), want_aux=True)
+        finally:
+            for k, v in cfg.items():
+                setattr(self, k, v)
+        return vq_flip_stats(z, idx, z32, idx32, d32)
 
     def _run_stack(self, x, want_aux=False):
         """x [B, C, T] (already padded) through tdnn1, tdnnfs[:-2], and the bottleneck of tdnnfs[-2]"""

@@ -311,7 +311,11 @@ def test_vq_matches_oracle():
     margin = srt[..., 1] - srt[..., 0]
     agree = idx.cpu().long() == ir.view(2, 300)
     assert agree[margin > 2e-3].all()
-    assert agree.float().mean() > 0.99
+    # the margin rule, tight: an index may differ from the oracle's only where the oracle's two best distances are closer than twice
+    # the largest difference between the kernel's and the oracle's distances (both are f32 evaluations of the same expanded form)
+    derr = float((dist.cpu() - dr).abs().max())
+    print(f"vq: {int((~agree).sum())} of {agree.numel()} indices differ; distance error {derr:.1e}; their margins {margin[~agree].tolist()}")
+    assert (margin[~agree] <= 2 * derr).all()
     assert (q.cpu().permute(0, 2, 1) - qr)[agree].abs().max() < 1e-6
 
 
