@@ -207,7 +207,9 @@ int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packe
  * ring kernel serves (csrc/conv_ring16.hip: C_out > 64, C_in % 32 == 0, ksize >= 3, option "convring"), ONE launch walks the
  * tiles of all jobs: a block finishes job 0, 1, 2 of its region in turn (in a per-block rotated order when no job reads what
  * another writes), requesting the next tile's operands before the epilogue of the current one.  Otherwise: n calls of
- * sat_conv1d_f32 in index order.  Results are those of the n single calls. */
+ * sat_conv1d_f32 in index order.  Results are those of the n single calls.  Buffers of different jobs must be the SAME (equal base:
+ * kept in index order inside the launch) or DISJOINT; byte ranges that overlap at different bases are detected and served by the
+ * single calls. */
 int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const* x, const void* const* w_packed, float* const* y, int n,
                          void* stream);
 /* One fused ResBlock1 step of the thin generator stages (C = 16 or 32; C = 64 with split planes end to end: x_split in,

@@ -1814,27 +1814,48 @@ extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const
                                     int n, void* stream) {
   SAT_REQUIRE(d && x && w_packed && y && n >= 1 && n <= 3, "conv1d_multi: 1..3 convolutions");
   ConvArgs a[3];
-  bool ring = true, writes_read = false;
+  bool ring = true, writes_read = false, partial = false;
   for (int j = 0; j < n; ++j) {
     int st = conv1d_prepare(&d[j], x[j], w_packed[j], y[j], a[j]);
     if (st != SAT_OK) return st;
     ring = ring && (d[j].mode == SAT_CONV_F16X3 || d[j].mode == SAT_CONV_F16F8R) && d[j].groups == 1 && d[j].B == d[0].B && convring_supports(a[j], d[j].B) && convring_same_shape(a[j], a[0]);
   }
   // the order of the jobs may rotate from block to block unless a job reads (accumulates into, takes its residual or
-  // input from) what another one writes
+  // input from) what another one writes, or two jobs write the same bytes: compared as BYTE RANGES (views of one buffer at
+  // different offsets overlap without being equal; round-4 advisor item)
+  struct Span { const char* lo; const char* hi; };
+  auto span = [](const void* p, long long bytes) { return Span{(const char*)p, p ? (const char*)p + (bytes > 0 ? bytes : 0) : (const char*)p}; };
+  auto overlap = [](const Span& u, const Span& v) { return u.lo && v.lo && u.lo < v.hi && v.lo < u.hi; };
+  auto writes = [&](const ConvArgs& c, int B, Span (&w)[3]) {
+    w[0] = span(c.no_y ? nullptr : (const void*)c.y, ((long long)(B - 1) * c.y_bs + (long long)(c.rows_g - 1) * c.y_cs + (long long)c.T_q * c.up) * 4);
+    w[1] = span(c.y16, (long long)B * c.rows_g * c.T_q * c.up * 4);
+    w[2] = span(c.y8, (long long)B * c.rows_g * c.T_q * c.up * 2);
+  };
   for (int j = 0; j < n; ++j)
     for (int i = 0; i < n; ++i) {
       if (i == j) continue;
-      const void* wr0 = a[i].no_y ? nullptr : (const void*)a[i].y;
-      const void* wr1 = a[i].y16;
-      const void* wr2 = a[i].y8;
-      const void* rd[6] = {a[j].accum ? (const void*)a[j].y : nullptr, a[j].res, a[j].res16, a[j].x16, a[j].x, a[j].x8};
-      for (const void* r : rd) writes_read = writes_read || (r && (r == wr0 || r == wr1 || r == wr2));
-      writes_read = writes_read || (wr0 && wr0 == (a[j].no_y ? nullptr : (const void*)a[j].y)) || (wr1 && wr1 == a[j].y16) || (wr2 && wr2 == a[j].y8);
+      const int B = d[0].B;
+      Span wi[3], wj[3];
+      writes(a[i], B, wi);
+      writes(a[j], B, wj);
+      const Span rd[6] = {a[j].accum ? wj[0] : Span{nullptr, nullptr},
+                          span(a[j].res, ((long long)(B - 1) * a[j].r_bs + (long long)(a[j].rows_g - 1) * a[j].r_cs + (long long)a[j].T_q * a[j].res_tstride + a[j].res_toff) * 4),
+                          span(a[j].res16, (long long)B * a[j].rows_g * a[j].T_q * 4), span(a[j].x16, (long long)B * a[j].cin_g * a[j].T_in * 4),
+                          span(a[j].x, ((long long)(B - 1) * a[j].x_bs + (long long)(a[j].cin_g - 1) * a[j].x_cs + a[j].T_in) * 4),
+                          span(a[j].x8, (long long)B * a[j].cin_g * a[j].T_in * 2)};
+      // the SAME buffer read / written by two jobs: kept in index order inside a block (a tile of job j + 1 touches what its block's
+      // tile of job j touched); buffers that overlap at DIFFERENT bases: tiles of different blocks would meet — single launches
+      for (const Span& r : rd)
+        for (const Span& w : wi)
+          if (overlap(r, w)) (r.lo == w.lo ? writes_read : partial) = true;
+      for (const Span& u : wi)
+        for (const Span& v : wj)
+          if (overlap(u, v)) (u.lo == v.lo ? writes_read : partial) = true;
     }
+  if (partial) ring = false;
   if (ring && n > 1) return launch_f16x3_convring_multi(a, n, !writes_read, d[0].B, (hipStream_t)stream);
   // 1x1 convs of one shape on split planes (q | k | v of an attention layer): one launch of the persistent ring GEMM
-  bool walk = n > 1 && !writes_read && g_k1_gemm >= 3;
+  bool walk = n > 1 && !writes_read && !partial && g_k1_gemm >= 3;
   for (int j = 0; j < n && walk; ++j) {
     const long long c256 = (long long)ceil_div(a[j].T_q, 256) * 256, c128 = (long long)ceil_div(a[j].T_q, 128) * 128;
     walk = d[j].mode == SAT_CONV_F16X3 && d[j].groups == 1 && d[j].B == d[0].B && gemm_walk_supports(a[j]) && gemm_walk_same_shape(a[j], a[0]) &&

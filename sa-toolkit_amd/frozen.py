@@ -26,6 +26,8 @@ def _enc(x):
         d = {"__t__": x.detach().cpu()}
         if hasattr(x, "w_descale"):
             d["w_descale"] = float(x.w_descale)
+        if hasattr(x, "up_zero_taps"):
+            d["up_zero_taps"] = int(x.up_zero_taps)
         return d
     if isinstance(x, _LayerCache):
         return {"__lc__": {k: _enc(getattr(x, k, None)) for k in _LayerCache.__slots__}}
@@ -62,6 +64,8 @@ def _dec(x, device, mods=None):
             t = x["__t__"].to(device)
             if "w_descale" in x:
                 t.w_descale = x["w_descale"]
+            if "up_zero_taps" in x:
+                t.up_zero_taps = x["up_zero_taps"]
             return t
         if "__lc__" in x:
             c = _LayerCache()

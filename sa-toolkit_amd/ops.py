@@ -124,6 +124,13 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
     d.res_split, d.res_split_slope = ptr(res_split), float(res_split_slope)
     d.relu_first = int(relu_first)
     d.x_wrap_channels = int(x_wrap_channels)
+    if up_grouped and up_zero_taps:
+        # the mask is a promise about the WEIGHTS (the kernel leaves those products out): only zeros the packer saw may be claimed
+        have = getattr(w_packed, "up_zero_taps", None)
+        if have is None or (int(up_zero_taps) & ~int(have)):
+            raise _lib.SatError(f"conv1d: up_zero_taps = {int(up_zero_taps):#x} claims all-zero (tap slot, phase) pairs the packed weights do not have "
+                                f"({'no record on the packed tensor' if have is None else hex(int(have))}: pack with packing.pack_conv_weight_f16x3(..., up=4) "
+                                "from packing.convtranspose_as_phase_conv(..., grouped=True))")
     d.up_grouped, d.up_zero_taps = int(bool(up_grouped)), int(up_zero_taps)
     d.x_split8, d.y_split8, d.y_split_hi_only = ptr(x_split8), ptr(y_split8), int(bool(y_split_hi_only))
     return d, x, out, res      # (res: the possibly re-laid-out residual must outlive the launch)

@@ -67,6 +67,21 @@ def convtranspose_as_phase_conv(w: torch.Tensor, stride: int, padding: int, grou
     return wc, kp, pad_left
 
 
+def grouped_zero_taps(wc: torch.Tensor, u: int) -> int:
+    """the all-zero (tap slot, phase) pairs of a polyphase weight whose rows are grouped by phase (convtranspose_as_phase_conv(...,
+    grouped=True)), read from the WEIGHTS: bit (slot * 4 + phase).  pack_conv_weight_f16x3 attaches it to the packed tensor of such a
+    weight (`.up_zero_taps`) when told so, and ops.conv1d refuses a descriptor mask that claims more zeros than the weights have
+    (sat_conv1d_desc.up_zero_taps is a promise about the weights: a wrong mask drops products silently)."""
+    rows, c_in, kp = wc.shape
+    v = wc.reshape(rows // (16 * u), u, 16, c_in, kp)
+    mask = 0
+    for slot in range(kp):
+        for r in range(u):
+            if not bool(v[:, r, :, :, slot].any()):
+                mask |= 1 << (slot * 4 + r)
+    return mask
+
+
 class SplitRangeError(ValueError):
     """weights that the split-f16 representation cannot carry (non-finite values)"""
 
@@ -110,6 +125,10 @@ def pack_conv_weight_f16x3(w: torch.Tensor, groups: int = 1, up: int = 1, scale:
     lo = (p - hi.to(torch.float32)).to(torch.float16)
     out = torch.stack([hi, lo], dim=3).contiguous()                  # [g][nch][K][part][half][co][8]
     out.w_descale = float(2.0 ** -e)
+    if up == 4 and groups == 1 and w.shape[0] % 64 == 0 and w.shape[2] <= 8:
+        # the zero (tap slot, phase) pairs this weight WOULD have with its rows grouped by phase (the caller knows whether they are:
+        # ops.conv1d(up_grouped=True, up_zero_taps=...) compares its mask with this one)
+        out.up_zero_taps = grouped_zero_taps(w, up)
     return out
 
 
@@ -117,8 +136,9 @@ def move_packed(w: torch.Tensor, *args, **kwargs) -> torch.Tensor:
     """`w.to(*args, **kwargs)` for a tensor packed by pack_conv_weight_f16x3, keeping its `.w_descale` (a plain .to() / .clone() /
     .contiguous() returns a tensor without the attribute, which ops.* refuse in split-f16 mode)"""
     out = w.to(*args, **kwargs)
-    if hasattr(w, "w_descale"):
-        out.w_descale = w.w_descale
+    for attr in ("w_descale", "up_zero_taps"):
+        if hasattr(w, attr):
+            setattr(out, attr, getattr(w, attr))
     return out
 
 

@@ -181,6 +181,25 @@ def test_f16f8r_multi_launch_equals_the_single_calls(C, T):
             for a, bb in zip(outs["single"], outs["multi"]):
                 assert torch.equal(a, bb), mode
             assert bool((outs["multi"][2][:, :, :8] == 0).all()) and bool((outs["multi"][2][:, :, 8 + T:] == 0).all())
+            # two jobs storing into OVERLAPPING views of one buffer at different offsets: tiles of different blocks would meet, so the call
+            # must serve them as the single launches in index order (byte ranges are compared, not base pointers)
+            res = {}
+            for how in ("single", "multi"):
+                big = torch.zeros(B, C, T + 24, device=DEV)
+                jl = []
+                for j, k in enumerate(ks[:2]):
+                    kw = dict(bias=bs[j], dilation=dils[j], pad_left=dils[j] * (k - 1) // 2, mode=mode, x_split=xs, y_split_slope=0.1,
+                              out=big[:, :, 8 * j:8 * j + T])
+                    if mode == 3:
+                        kw["x_split8"] = xs8
+                    jl.append((x, wl[j], C, k, kw))
+                if how == "single":
+                    for (xx, w, c, k, kw) in jl:
+                        ops.conv1d(xx, w, c, k, **kw)
+                else:
+                    ops.conv1d_multi(jl)
+                res[how] = big
+            assert torch.equal(res["single"], res["multi"]), mode
 
 
 @pytest.mark.parametrize("cfg", [(256, 128, 133, 2), (128, 64, 700, 3)])

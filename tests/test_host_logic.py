@@ -131,6 +131,23 @@ def test_grouped_polyphase_rows_and_their_zero_tap_mask():
                 for r in range(u):
                     assert bool((wc[r::u, :, slot] == 0).all()) == bool(mask >> (slot * 4 + r) & 1), (k, u, slot, r)
     assert packing.convtranspose_zero_taps(8, 4, 2) == 0x30c and packing.convtranspose_zero_taps(11, 5, 3) == 0        # (stride 5: no 4-bit phase field)
+    # the mask is a promise about the weights, so it is RECORDED from them at pack time and a descriptor may only claim recorded zeros
+    # (round-4 advisor item: a caller's mask used to be trusted)
+    wg, kp, pl = packing.convtranspose_as_phase_conv(torch.randn(256, 128, 8), 4, 2, grouped=True)
+    assert packing.grouped_zero_taps(wg, 4) == 0x30c
+    wp = packing.pack_conv_weight_f16x3(wg, up=4)
+    assert wp.up_zero_taps == 0x30c and packing.move_packed(wp, "cpu").up_zero_taps == 0x30c
+    from satools_amd import ops
+    x = torch.zeros(1, 256, 20)
+    kw = dict(pad_left=pl, up=4, mode=1, up_grouped=True)
+    ops._conv1d_desc(x, wp, 128, kp, up_zero_taps=0x30c, **kw)
+    ops._conv1d_desc(x, wp, 128, kp, up_zero_taps=0x300, **kw)                  # fewer zeros claimed than there are: fine
+    with pytest.raises(_lib.SatError):
+        ops._conv1d_desc(x, wp, 128, kp, up_zero_taps=0x30d, **kw)              # slot 0 of phase 0 carries weights
+    dense = packing.pack_conv_weight_f16x3(torch.randn(512, 256, 3), up=4)
+    assert dense.up_zero_taps == 0
+    with pytest.raises(_lib.SatError):
+        ops._conv1d_desc(x, dense, 128, 3, up_zero_taps=0x30c, **kw)
     ok = packing.upsample_grouped_supported
     assert ok(256, 128, 8, 4, 2) and ok(128, 64, 8, 4, 2)
     assert not ok(512, 256, 11, 5, 3) and not ok(64, 32, 4, 2, 1) and not ok(64, 32, 8, 4, 2) and not ok(96, 64, 8, 4, 2) and not ok(128, 72, 8, 4, 2)
