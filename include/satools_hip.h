@@ -113,12 +113,15 @@ int sat_convring_debug_stamps(int64_t* buf);
  *                  still rebuilt from hi + lo: 22 bits); the 8-bit activation operands travel in a SIDECAR next to them,
  *                    S8[b][c/16][2 units][t][16 B] = e5m2(hi) of 16 channels | e5m2(lo * 2^10) of 16 channels
  *                  (hi, lo = the f16 values of the main planes, round to nearest even, saturating at 57344: a pure function
- *                  of the planes; e5m2 = f16's exponent range, so activations of any f16 magnitude keep their cross terms), read through x_split8 and written by the producer's epilogue through y_split8
+ *                  of the planes; e5m2 = f16's exponent range, so activations of any f16 magnitude keep their cross terms),
+ *                  read through x_split8 and written by the producer's epilogue through y_split8
  *                  (or by sat_planes_f8_sidecar).  Weights: packing.pack_conv_weight_f16f8r,
- *                    w[C_in/32][2 ceil(k/2) steps][8 planes][co_pad][16 B]; per pair of taps an f16 step (planes = (tap of the
- *                    pair, chunk of the channel pair, channel half): hi f16 of 8 channels) and an e4m3 step (planes = (tap of the
- *                    pair, term, chunk): term 0 e4m3(lo * 2^9), term 1 e4m3(hi * 2^-2) of 16 channels), hi / lo of w * 2^e with
- *                    the SAT_CONV_F16X3 layer scale (largest |w| * 2^e in [2^9, 2^10)); an odd k is padded with a zero tap.
+ *                    w[2 ceil(C_in/32 x k / 2) steps][8 planes][co_pad][16 B] over the LINEAR sequence of (32-channel pair pp, tap t),
+ *                    L = pp k + t; elements (2 q, 2 q + 1) form a pair (the last tap of a channel pair goes with the first tap of the
+ *                    next one: an odd k costs no padding).  Per pair an f16 step (planes = (element of the pair, chunk of its channel
+ *                    pair, channel half): hi f16 of 8 channels) and an 8-bit step (planes = (element, term, chunk): term 0
+ *                    e4m3(lo * 2^9), term 1 e4m3(hi * 2^-2) of 16 channels), hi / lo of w * 2^e with the SAT_CONV_F16X3 layer scale
+ *                    (largest |w| * 2^e in [2^9, 2^10)).
  *                  Served by that kernel only (sat_conv1d_f8r_supported), at every batch size. */
 #define SAT_CONV_F16F8R 3
 /* split-plane formats: per 16-channel chunk and position four 16-byte units

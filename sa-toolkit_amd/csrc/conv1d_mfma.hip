@@ -1741,8 +1741,8 @@ static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* 
       SAT_REQUIRE(!(d->no_y && d->accum), "conv1d: no_y with accum");
     }
     a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;   // bytes per group
-    // (SAT_CONV_F16F8R packing: [C_in / 32][2 ceil(k / 2) steps][8 planes][co_pad][16 B])
-    if (a.f8r) a.w_gs = (long long)(a.cin_pad / (2 * CI_CHUNK)) * (2 * ((a.ksize + 1) / 2)) * 8 * a.co_pad * 16;
+    // (SAT_CONV_F16F8R packing: [2 ceil(C_in / 32 x k / 2) steps][8 planes][co_pad][16 B])
+    if (a.f8r) a.w_gs = (long long)(2 * (((a.cin_pad / (2 * CI_CHUNK)) * a.ksize + 1) / 2)) * 8 * a.co_pad * 16;
     return SAT_OK;
   }
   SAT_REQUIRE(d->mode == SAT_CONV_F32, "conv1d: unknown mode %d", d->mode);

@@ -38,7 +38,10 @@ namespace sat {
 //   O step (odd):  W planes (tap of the pair, term, chunk): e4m3(W_lo * 2^9) | e4m3(W_hi * 2^-2): 20 8-bit MFMAs — the same
 //                  640 matrix cycles; the per-lane E8M0 scales undo the powers of two exactly
 //   X tile:        [chunk][hi0 hi1 | e5m2(hi) e5m2(lo * 2^10)][XW]: units 0, 1 from the main planes, 2, 3 from the sidecar
-// An odd kernel size is padded with a zero tap (the packed weights hold it; its B operand re-reads the last tap's columns).
+// The K dimension is the LINEAR sequence of (chunk pair, tap) elements, L = pp x taps + t, and a pair = elements (2 q, 2 q + 1): the last
+// tap of a chunk pair goes with the first tap of the next one (its two B halves then come from the two X slots), so the odd kernel
+// sizes of the generator (3, 7, 11) cost no padding.  X tile p + 1 is requested as soon as the last tap of tile p - 1 has been
+// multiplied; the first step that touches a tile reads its column 0 behind its own barrier instead of one step ahead.
 // ------------------------------------------------------------------------------------------------
 
 #define SAT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -73,7 +76,7 @@ struct RingJob {
   float w_descale, y16_slope, res16_inv, accum_div;
   int ksize, dil, pad_left, accum;
   unsigned w_bytes;
-  int nstep;             // steps per chunk pair: ksize, F8: 2 * ceil(ksize / 2)
+  int nstep;             // F8: steps of a tile, 2 * ceil(chunk pairs x ksize / 2)
   int hi_only;           // the lo units of y16 are not stored
   int pad_;
 };
@@ -383,16 +386,16 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
 
   // ---- DMA state of the tile whose operands are being requested
   i32x4 xrs, wrs;
-  int KS = 1, dil = 1, NP = 1, NS = 1, seg_bytes = 0, x_chunk_bytes = 0;      // (KS: steps per chunk pair — the taps, F8: 2 * ceil(taps / 2))
-  int ktaps = 1;                                                                // F8: the taps
+  int KS = 1, dil = 1, NP = 1, NS = 1, seg_bytes = 0, x_chunk_bytes = 0;      // (KS: the taps; NS: steps of a tile)
+  int ktaps = 1;
   int d_co = 0, d_q0 = 0, d_copad = 0, d_tin = 0;      // row / first input position of the tile, padded rows, input length
   // this wave's DMA pieces: of every W slot the (chunk of the pair = wave >> 2, segment = wave & 3) row, of every X tile the
   // (chunk of the pair, plane = wave & 3) row
   const int my_w_unit = half * 4 * ROWS + idx * ROWS, my_x_unit = half * 4 * XW + idx * XW;
   auto setup = [&](const Tile& t) __attribute__((always_inline)) {
     const RingJob p = A.job[t.j];
-    KS = F8 ? p.nstep : p.ksize, dil = p.dil, ktaps = p.ksize;
-    NP = A.cin_pad / (2 * CI_CHUNK), NS = NP * KS;
+    KS = p.ksize, dil = p.dil, ktaps = p.ksize;
+    NP = A.cin_pad / (2 * CI_CHUNK), NS = F8 ? p.nstep : NP * KS;
     seg_bytes = A.co_pad * 16;
     if (F8 && idx >= 2) {
       // this wave's X rows are the sidecar's: units (e5m2(hi), e5m2(lo * 2^10)) of its chunk
@@ -417,8 +420,8 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
   };
   auto issue_w = [&](int pp, int t, int slot) __attribute__((always_inline)) {
     const uint4* dst = lds4 + W0 + slot * W_UNITS + my_w_unit;
-    // F8: packed [pair][step][plane = wave][row]; else [chunk][tap][plane][row]
-    const unsigned soff = F8 ? (unsigned)(((pp * KS + t) * 8 + wave) * seg_bytes) : (unsigned)((((2 * pp + half) * KS + t) * 4) * seg_bytes);
+    // F8: packed [step][plane = wave][row] (called with pp = 0, t = the step); else [chunk][tap][plane][row]
+    const unsigned soff = F8 ? (unsigned)((t * 8 + wave) * seg_bytes) : (unsigned)((((2 * pp + half) * KS + t) * 4) * seg_bytes);
 #pragma unroll
     for (int j = 0; j < PW; ++j) lds_dma16(dst + j * 64, wrs, voff_w(j), soff);
   };
@@ -531,8 +534,12 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     ++s, pp = p1, t = t1, ws = ws1;
     if (++t3 == KS) t3 = 0, ++p3;
   };
-  // ---- F8: CUR = 0 the E step of a pair of taps (hi * hi of both taps on the f16 MFMA: 40 per wave), CUR = 1 its O step (both
-  // cross terms of both taps in one 8-bit MFMA of K = 128: 20 per wave, the same matrix cycles).  Same rings, same waits.
+  // ---- F8: CUR = 0 the E step of a pair of elements (hi * hi of both on the f16 MFMA: 40 per wave), CUR = 1 its O step (both cross
+  // terms of both in one 8-bit MFMA of K = 128: 20 per wave, the same matrix cycles).  Same rings, same counted waits.
+  int e0p = 0, e0t = 0, e1p = 0, e1t = 1;      // the two elements (chunk pair, tap) of the current pair
+  int n0p = 0, n0t = 0, n1p = 0, n1t = 0;      // ... of the next pair (set by the O step)
+  int nxt_x = 2;                               // next X tile to request (0 and 1: the prologue)
+  bool xprev = false, fresh = false;           // an X tile was requested in the previous step; this E step is the first to touch a tile
   auto body8 = [&](auto cur, auto late_c, auto more_c) __attribute__((always_inline)) {
     constexpr int CUR = decltype(cur)::value;
     constexpr bool LATE = decltype(late_c)::value, MORE = decltype(more_c)::value;
@@ -541,8 +548,9 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     if constexpr (MORE) {
       long long w0 = 0;
       if constexpr (STAMP) w0 = cr_clock();
+      // barrier s: W of step s + 1 landed — everything but the youngest W request, and the X tile requested in between (step s - 1)
       if (s + 2 < NS) {
-        if (t == 1 && pp >= 1 && pp + 1 < NP) SAT_WAIT_VM_LGKM0(PW + PX);
+        if (xprev) SAT_WAIT_VM_LGKM0(PW + PX);
         else SAT_WAIT_VM_LGKM0(PW);
       } else {
         SAT_WAIT_VM_LGKM0(0);
@@ -550,41 +558,67 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
       asm volatile("s_barrier" ::: "memory");
       if constexpr (STAMP) st_wait += cr_clock() - w0;
     }
-    int t1 = t + 1, p1 = pp;
-    if (t1 == KS) t1 = 0, p1 = pp + 1;
+    xprev = false;
     const int ws1 = ws == 2 ? 0 : ws + 1;
     const uint4* wnext = lds4 + W0 + ws1 * W_UNITS + a_lane;
-    // columns of the two taps of this step's pair (the zero tap that pads an odd kernel re-reads the last tap's columns: finite
-    // values against zero weights)
-    const int tp = t & ~1;
-    const int sh0 = tp * dil, sh1 = (tp + 1 < ktaps ? tp + 1 : tp) * dil;
-    const uint4* x16 = lds4 + (pp & 1) * X_UNITS + b_lane;
-    const uint4* x8 = lds4 + (pp & 1) * X_UNITS + b_lane8;
-    // (O step: the next step is the E step of pair (p1, taps t1, t1 + 1))
-    const int nh0 = t1 * dil, nh1 = (t1 + 1 < ktaps ? t1 + 1 : t1) * dil;
-    const uint4* xn16 = lds4 + (p1 & 1) * X_UNITS + b_lane;
+    // B columns of the two elements: (X slot of its chunk pair) + tap x dilation
+    const int o0 = (e0p & 1) * X_UNITS + e0t * dil, o1 = (e1p & 1) * X_UNITS + e1t * dil;
+    const uint4* x16a = lds4 + o0 + b_lane;
+    const uint4* x16b = lds4 + o1 + b_lane;
+    const uint4* x8a = lds4 + o0 + b_lane8;
+    const uint4* x8b = lds4 + o1 + b_lane8;
+    const uint4* xn16a = x16a;
+    const uint4* xn16b = x16b;
+    bool fresh_next = false;
+    if constexpr (CUR == 0) {
+      if (fresh) {                              // the first step on a tile: its column 0 was not read ahead (the tile may have been in flight)
+        fb[0][0] = __builtin_bit_cast(h8, x16a[0]);
+        fb[0][1] = __builtin_bit_cast(h8, x16b[0]);
+      }
+    } else {
+      // the next pair: two more elements of the linear sequence (past its end: the zero element, on the last element's columns)
+      n0p = e1p, n0t = e1t + 1;
+      if (n0t == ktaps) n0t = 0, ++n0p;
+      n1p = n0p, n1t = n0t + 1;
+      if (n1t == ktaps) n1t = 0, ++n1p;
+      if (n1p >= NP) n1p = n0p, n1t = n0t;
+      if (n0p >= NP) n0p = e1p, n0t = e1t, n1p = e1p, n1t = e1t;      // (behind the last pair: never multiplied)
+      fresh_next = n1p > e1p;
+      xn16a = lds4 + (n0p & 1) * X_UNITS + n0t * dil + b_lane;
+      xn16b = lds4 + (n1p & 1) * X_UNITS + n1t * dil + b_lane;
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       __builtin_amdgcn_sched_barrier(0);
       if (n == N_HAND && !(STAMP && (A.diag & 8))) {
-        if (t == 0 && pp >= 1 && pp + 1 < NP) issue_x(pp + 1);
-        if (s + 3 < NS) issue_w(p3, t3, ws);
+        if constexpr (CUR == 0) {
+          // X tile nxt_x takes the slot of tile nxt_x - 2: free once every element of that tile has been multiplied, i.e. this pair's
+          // first element lies in tile nxt_x - 1 or later (s = 2 q = the linear index of this pair's first element)
+          if (nxt_x < NP && s >= (nxt_x - 1) * ktaps) {
+            issue_x(nxt_x);
+            ++nxt_x;
+            xprev = true;
+          }
+        }
+        if (s + 3 < NS) issue_w(0, s + 3, ws);
       }
       if (!(STAMP && (A.diag & 16))) {
         if constexpr (CUR == 0) {
           if (n + 1 < NT) {
-            fb[(n + 1) & 1][0] = __builtin_bit_cast(h8, x16[(n + 1) * 16 + sh0]);
-            fb[(n + 1) & 1][1] = __builtin_bit_cast(h8, x16[(n + 1) * 16 + sh1]);
+            fb[(n + 1) & 1][0] = __builtin_bit_cast(h8, x16a[(n + 1) * 16]);
+            fb[(n + 1) & 1][1] = __builtin_bit_cast(h8, x16b[(n + 1) * 16]);
           } else {
-            read8(fb8[0], x8 + sh0, x8 + sh1);          // column 0 of the O step that always follows
+            read8(fb8[0], x8a, x8b);                    // column 0 of the O step that always follows
           }
           if (n >= 1) read8(fa8[n - 1], wnext + (n - 1) * 16, wnext + (n - 1) * 16 + 4 * ROWS);
         } else {
           if (n + 1 < NT) {
-            read8(fb8[(n + 1) & 1], x8 + (n + 1) * 16 + sh0, x8 + (n + 1) * 16 + sh1);
+            read8(fb8[(n + 1) & 1], x8a + (n + 1) * 16, x8b + (n + 1) * 16);
           } else if constexpr (MORE) {
-            fb[0][0] = __builtin_bit_cast(h8, xn16[nh0]);
-            fb[0][1] = __builtin_bit_cast(h8, xn16[nh1]);
+            if (!fresh_next) {
+              fb[0][0] = __builtin_bit_cast(h8, xn16a[0]);
+              fb[0][1] = __builtin_bit_cast(h8, xn16b[0]);
+            }
           }
           if constexpr (MORE) {
             if (n >= 1) read_a(fa[0][n - 1], wnext, n - 1);
@@ -603,8 +637,8 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    ++s, pp = p1, t = t1, ws = ws1;
-    if (++t3 == KS) t3 = 0, ++p3;
+    ++s, ws = ws1;
+    if constexpr (CUR == 1) e0p = n0p, e0t = n0t, e1p = n1p, e1t = n1t, fresh = fresh_next;
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -613,7 +647,7 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
   auto loop = [&](auto late_c) __attribute__((always_inline)) {
     using L = decltype(late_c);
     if constexpr (F8) {
-      // NS = NP x 2 ceil(taps / 2): E and O steps alternate, the last step is an O step
+      // NS = 2 ceil(NP x taps / 2): E and O steps alternate, the last step is an O step
       while (s + 2 < NS) {
         body8(I0{}, L{}, std::true_type{});
         body8(I1{}, L{}, std::true_type{});
@@ -674,6 +708,7 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     asm volatile("s_nop 3" ::: "memory");       // (vector write of the accumulators -> matrix read, were the loop to start at once)
     s = 0, pp = 0, t = 0, ws = 0;
     p3 = KS > 3 ? 0 : 1, t3 = KS > 3 ? 3 : 0;
+    e0p = 0, e0t = 0, e1p = 0, e1t = 1, nxt_x = 2, xprev = false, fresh = false;      // (F8; taps >= 3)
     if constexpr (STAMP) st_pro += cr_clock() - e0;
     long long l0 = 0;
     if constexpr (STAMP) l0 = cr_clock();
@@ -812,7 +847,7 @@ static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipS
     r.w_bytes = (unsigned)a[j].w_gs;
     r.y_bs = a[j].y_bs, r.y_cs = a[j].y_cs;
     r.x8 = a[j].x8, r.y8 = a[j].y8, r.hi_only = a[j].y16_hi_only && a[j].y8;
-    r.nstep = F8 ? 2 * ((a[j].ksize + 1) / 2) : a[j].ksize;
+    r.nstep = F8 ? 2 * (((a[j].cin_pad / (2 * CI_CHUNK)) * a[j].ksize + 1) / 2) : a[j].ksize;
   }
   A.cin_g = a[0].cin_g, A.cin_pad = a[0].cin_pad, A.rows_g = a[0].rows_g, A.co_pad = a[0].co_pad, A.T_in = a[0].T_in, A.T_q = a[0].T_q;
   A.njobs = njobs;

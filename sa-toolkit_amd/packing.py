@@ -174,12 +174,14 @@ F8R_W_HI_EXP, F8R_W_LO_EXP = -2, 9      # power-of-two scales of the e4m3 weight
 
 
 def pack_conv_weight_f16f8r(w: torch.Tensor) -> torch.Tensor:
-    """packing for SAT_CONV_F16F8R (the LDS-DMA ring kernel with e4m3 cross terms, csrc/conv_ring16.hip):
-    w [C_out, C_in, K] f32 (C_in % 32 == 0) -> uint8 [C_in/32][2 * ceil(K/2) steps][8 planes][co_pad][16 B].
+    """packing for SAT_CONV_F16F8R (the LDS-DMA ring kernel with 8-bit cross terms, csrc/conv_ring16.hip):
+    w [C_out, C_in, K] f32 (C_in % 32 == 0) -> uint8 [2 * ceil(C_in/32 * K / 2) steps][8 planes][co_pad][16 B].
     hi = f16(w'), lo = f16(w' - hi) of w' = w * 2^e, the SAT_CONV_F16X3 layer scale (`.w_descale` = 2^-e travels with the
-    tensor).  Per pair of taps (2 tp, 2 tp + 1; an odd K is padded with a zero tap) two steps:
-      E step, plane (tap j, chunk c, half hf) = 4 j + 2 c + hf: hi f16 of channels 32 pp + 16 c + 8 hf .. + 7
-      O step, plane (tap j, term, chunk c)    = 4 j + 2 term + c: 16 channels of chunk c as e4m3 — term 0: lo * 2^9,
+    tensor).  The K dimension is the LINEAR sequence of (32-channel pair pp, tap t), L = pp * K + t; consecutive elements (2 q, 2 q + 1)
+    form a pair — the last tap of a channel pair goes with the first tap of the next one, so an odd K costs no padding (only an odd
+    C_in/32 * K ends with one zero element).  Per pair two steps:
+      E step, plane (element j, chunk c, half hf) = 4 j + 2 c + hf: hi f16 of channels 32 pp_j + 16 c + 8 hf .. + 7 at tap t_j
+      O step, plane (element j, term, chunk c)    = 4 j + 2 term + c: 16 channels of chunk c as e4m3 — term 0: lo * 2^9,
               term 1: hi * 2^-2 (the products W_lo . x_hi and W_hi . x_lo of the cross terms)"""
     rows, cin, k = w.shape
     if cin % 32 != 0:
@@ -189,22 +191,28 @@ def pack_conv_weight_f16f8r(w: torch.Tensor) -> torch.Tensor:
     if e:
         p = p * float(2.0 ** e)
     cin_pad, _, co_pad = p.shape
-    tp = (k + 1) // 2
-    if 2 * tp != k:
-        p = torch.cat([p, torch.zeros(cin_pad, 1, co_pad, dtype=p.dtype, device=p.device)], dim=1)
+    npair = cin_pad // 32
+    nlin = npair * k
+    nq = (nlin + 1) // 2
     hi = p.to(torch.float16)
     lo = (p - hi.to(torch.float32)).to(torch.float16)
-    npair = cin_pad // 32
-    # E images: [pp][c][hf][8][tp][j][co] -> [pp][tp][j][c][hf][co][8]
-    e_img = hi.reshape(npair, 2, 2, 8, tp, 2, co_pad).permute(0, 4, 5, 1, 2, 6, 3).contiguous()
-    e_img = e_img.view(torch.uint8).reshape(npair, tp, 8, co_pad, 16)
 
-    def e4m3(t, exp):                                                # [cin_pad][Kp][co] -> [pp][tp][j][c][co][16] bytes
-        q = (t.to(torch.float32) * float(2.0 ** exp)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
-        return q.reshape(npair, 2, 16, tp, 2, co_pad).permute(0, 3, 4, 1, 5, 2).contiguous()
+    def linear(t):                                                   # [cin_pad][K][co] -> [2 nq][32][co], element L = pp * K + t (zero padded)
+        v = t.reshape(npair, 32, k, co_pad).permute(0, 2, 1, 3).reshape(nlin, 32, co_pad)
+        if 2 * nq != nlin:
+            v = torch.cat([v, torch.zeros(1, 32, co_pad, dtype=v.dtype, device=v.device)], dim=0)
+        return v
 
-    o_img = torch.stack([e4m3(lo, F8R_W_LO_EXP), e4m3(hi, F8R_W_HI_EXP)], dim=3)       # [pp][tp][j][term][c][co][16]
-    o_img = o_img.reshape(npair, tp, 8, co_pad, 16)
-    out = torch.stack([e_img, o_img], dim=2).reshape(npair, 2 * tp, 8, co_pad, 16).contiguous()
+    # E images: [q][j][c][hf][8][co] -> [q][j][c][hf][co][8]
+    e_img = linear(hi).reshape(nq, 2, 2, 2, 8, co_pad).permute(0, 1, 2, 3, 5, 4).contiguous()
+    e_img = e_img.view(torch.uint8).reshape(nq, 8, co_pad, 16)
+
+    def e4m3(t, exp):                                                # -> [q][j][c][co][16] bytes
+        q = (linear(t).to(torch.float32) * float(2.0 ** exp)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        return q.reshape(nq, 2, 2, 16, co_pad).permute(0, 1, 2, 4, 3).contiguous()
+
+    o_img = torch.stack([e4m3(lo, F8R_W_LO_EXP), e4m3(hi, F8R_W_HI_EXP)], dim=2)       # [q][j][term][c][co][16]
+    o_img = o_img.reshape(nq, 8, co_pad, 16)
+    out = torch.stack([e_img, o_img], dim=1).reshape(2 * nq, 8, co_pad, 16).contiguous()
     out.w_descale = float(2.0 ** -e)
     return out

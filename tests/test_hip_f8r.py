@@ -48,10 +48,11 @@ def test_planes_f8_sidecar_is_e5m2_of_the_plane_values(B, C, T):
 
 
 @pytest.mark.parametrize("C,T,k,dil", [(256, 1250, 11, 5), (256, 333, 7, 3), (128, 700, 3, 5), (128, 97, 11, 1), (192, 401, 7, 1), (512, 200, 3, 1),
-                                       (320, 161, 11, 3), (128, 5000, 7, 5), (256, 159, 3, 3), (128, 321, 3, 1), (128, 640, 4, 1)], ids=lambda v: str(v))
+                                       (320, 161, 11, 3), (128, 5000, 7, 5), (256, 159, 3, 3), (128, 321, 3, 1), (128, 640, 4, 1), (96, 333, 3, 1), (160, 401, 7, 3), (96, 700, 11, 5)], ids=lambda v: str(v))
 def test_ring_conv_f16f8r_matches_its_decomposition(C, T, k, dil):
     """Tight: against the decomposition evaluated in f64 (pins the operand order inside the K = 128 product, the E8M0 scales, the
-    tap pairing with its zero tap for odd kernels, the sidecar's rounding).  Loose: against the exact product (e4m3 cross terms
+    pairing of the linear (channel pair, tap) sequence across channel pairs — odd kernels, and an odd number of elements with its one
+    zero element: C = 96 / 160 —, the X tile hand-over, the sidecar's rounding).  Loose: against the exact product (e4m3 cross terms
     leave ~2^-15 per product).  The three ResBlock epilogues; planes and sidecar out; hi-only planes."""
     ops, packing = _ops()
     from satools_amd import _lib

@@ -350,34 +350,38 @@ def test_conv_options_from_the_environment(monkeypatch):
 
 
 def test_f16f8r_weight_packing_layout():
-    """packing.pack_conv_weight_f16f8r (SAT_CONV_F16F8R, include/satools_hip.h): [C_in/32][2 ceil(K/2) steps][8 planes][co_pad][16 B];
-    E steps carry hi f16 (plane = 4 tap + 2 chunk + half), O steps e4m3(lo 2^9) | e4m3(hi 2^-2) (plane = 4 tap + 2 term + chunk); the
-    layer scale of the SAT_CONV_F16X3 packing; an odd K is padded with a zero tap"""
+    """packing.pack_conv_weight_f16f8r (SAT_CONV_F16F8R, include/satools_hip.h): [2 ceil(C_in/32 K / 2) steps][8 planes][co_pad][16 B] over
+    the LINEAR sequence of (channel pair, tap): E steps carry hi f16 (plane = 4 element + 2 chunk + half), O steps e4m3(lo 2^9) |
+    e4m3(hi 2^-2) (plane = 4 element + 2 term + chunk); the layer scale of the SAT_CONV_F16X3 packing; pairs straddle channel pairs
+    (an odd K costs nothing), only an odd total ends with a zero element"""
     torch.manual_seed(3)
-    w = torch.randn(128, 64, 7) * 0.05
-    p = packing.pack_conv_weight_f16f8r(w)
-    p3 = packing.pack_conv_weight_f16x3(w)
-    assert p.shape == (2, 8, 8, 128, 16) and p.dtype == torch.uint8 and p.w_descale == p3.w_descale
-    e = packing.f16x3_scale_exponent(w)
-    ws = w * 2.0 ** e
-    assert 2 ** 9 <= float(ws.abs().max()) < 2 ** 10
-    hi = ws.half()
-    lo = (ws - hi.float()).half()
     f8 = lambda t, ex: (t.float() * 2.0 ** ex).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
-    for pp in range(2):
-        for tp in range(4):
+    for cin, k in ((64, 7), (96, 3), (64, 4)):
+        w = torch.randn(128, cin, k) * 0.05
+        p = packing.pack_conv_weight_f16f8r(w)
+        p3 = packing.pack_conv_weight_f16x3(w)
+        nlin = cin // 32 * k
+        nq = (nlin + 1) // 2
+        assert p.shape == (2 * nq, 8, 128, 16) and p.dtype == torch.uint8 and p.w_descale == p3.w_descale
+        e = packing.f16x3_scale_exponent(w)
+        ws = w * 2.0 ** e
+        assert 2 ** 9 <= float(ws.abs().max()) < 2 ** 10
+        hi = ws.half()
+        lo = (ws - hi.float()).half()
+        for q in range(nq):
             for j in range(2):
-                tap = 2 * tp + j
+                L = 2 * q + j
+                pp, tap = divmod(L, k)
                 for c in range(2):
                     ch = slice(32 * pp + 16 * c, 32 * pp + 16 * c + 16)
                     for hf in range(2):
-                        got = p[pp, 2 * tp, 4 * j + 2 * c + hf].contiguous().view(torch.float16)           # [co][8]
-                        exp = hi[:, 32 * pp + 16 * c + 8 * hf: 32 * pp + 16 * c + 8 * hf + 8, tap] if tap < 7 else torch.zeros(128, 8, dtype=torch.float16)
-                        assert torch.equal(got, exp), (pp, tp, j, c, hf)
+                        got = p[2 * q, 4 * j + 2 * c + hf].contiguous().view(torch.float16)           # [co][8]
+                        exp = hi[:, 32 * pp + 16 * c + 8 * hf: 32 * pp + 16 * c + 8 * hf + 8, tap] if L < nlin else torch.zeros(128, 8, dtype=torch.float16)
+                        assert torch.equal(got, exp), (cin, k, q, j, c, hf)
                     for term, (src, ex) in enumerate(((lo, 9), (hi, -2))):
-                        got = p[pp, 2 * tp + 1, 4 * j + 2 * term + c]
-                        exp = f8(src[:, ch, tap], ex) if tap < 7 else torch.zeros(128, 16, dtype=torch.uint8)
-                        assert torch.equal(got, exp), (pp, tp, j, term, c)
+                        got = p[2 * q + 1, 4 * j + 2 * term + c]
+                        exp = f8(src[:, ch, tap], ex) if L < nlin else torch.zeros(128, 16, dtype=torch.uint8)
+                        assert torch.equal(got, exp), (cin, k, q, j, term, c)
     with pytest.raises(ValueError):
         packing.pack_conv_weight_f16f8r(torch.randn(64, 48, 3))
 
