@@ -44,6 +44,20 @@ __device__ __forceinline__ unsigned pack_e5m2x4(float a, float b, float c, float
   return (unsigned)w;
 }
 
+// e5m2(lo * 2^10) of two lo halves straight from their packed f16 pair: v_cvt_scalef32_pk_bf8_f16 converts src / scale (measured on all
+// 65536 patterns, tools/scratch/probe_cvt_bf8.hip: identical to the f32 path except that it overflows to Inf where the clamp saturates),
+// and a lo half — |lo| <= ulp(hi) / 2... < 2^-10 |x| — times 2^10 never reaches e5m2's 57344 while |x| is an f16: no clamp needed.
+// `old` carries the other half of the dword (op_sel picks the destination half).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+template <class H2>       // (the 2 x f16 vector type v_cvt_pkrtz returns)
+__device__ __forceinline__ unsigned pack_e5m2_lo_x4(H2 l01, H2 l23) {
+  s16x2_t r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r, __builtin_bit_cast(f16x2_t, l01), 1.0f / F8_XLO_SCALE, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r, __builtin_bit_cast(f16x2_t, l23), 1.0f / F8_XLO_SCALE, true);
+  return (unsigned)__builtin_bit_cast(int, r);
+}
+
 constexpr int CI_CHUNK = 16;  // input channels staged per K-chunk (8 MFMA k-pairs)
 
 struct ConvArgs {

@@ -177,8 +177,9 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
         rv[1] = (float)c01[1] + (float)c01[3];
         rv[2] = (float)c23[0] + (float)c23[2];
         rv[3] = (float)c23[1] + (float)c23[3];
+        // (leaky-relu undone: x > 0 ? x : x * inv with inv >= 1 is min(x, x * inv) — one instruction less per value)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rv[r] = rv[r] > 0.f ? rv[r] : rv[r] * inv;
+        for (int r = 0; r < 4; ++r) rv[r] = __builtin_fminf(rv[r], rv[r] * inv);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += rv[r];
       }
@@ -197,8 +198,9 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
       }
       if (has_y16 && rows_ok) {
         float u[4];
+        // (leaky-relu with 0 < slope <= 1 is max(v, v * slope))
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = v[r] > 0.f ? v[r] : v[r] * slope;
+        for (int r = 0; r < 4; ++r) u[r] = __builtin_fmaxf(v[r], v[r] * slope);
         const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
         const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
         const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
@@ -214,8 +216,7 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
         if (has_y8) {
           // a function of the plane values (hi, lo as f16): four channels = bytes 4 lg .. 4 lg + 3 of the chunk's unit at q
           const unsigned x8h = pack_e5m2x4((float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]);
-          const unsigned x8l = pack_e5m2x4((float)l01[0] * F8_XLO_SCALE, (float)l01[1] * F8_XLO_SCALE, (float)l23[0] * F8_XLO_SCALE,
-                                           (float)l23[1] * F8_XLO_SCALE);
+          const unsigned x8l = pack_e5m2_lo_x4(l01, l23);
           const unsigned off8 = qok ? (unsigned)(((chunk * 2) * T_q + q) * 16 + 4 * lg) : OOB;
           __builtin_amdgcn_raw_buffer_store_b32(x8h, y8rs, off8, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b32(x8l, y8rs, off8, T_q * 16, 0);
@@ -272,7 +273,7 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
       un[m] = u32x4{s0[0], s1[0], s0[1], s1[1]};
       if (has_y8) {
         x8[0][m] = pack_e5m2x4((float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]);
-        x8[1][m] = pack_e5m2x4((float)l01[0] * F8_XLO_SCALE, (float)l01[1] * F8_XLO_SCALE, (float)l23[0] * F8_XLO_SCALE, (float)l23[1] * F8_XLO_SCALE);
+        x8[1][m] = pack_e5m2_lo_x4(l01, l23);
       }
     }
     // 4 x 4 transposition (strip m, lane l of the quad) -> (store j, lane l): first strip bit 0 against lane bit 0, then bit 1 against bit 1
@@ -795,6 +796,9 @@ bool convring_supports(const ConvArgs& a, int B) {
   if (!(a.x16 && !a.f8 && !a.y16_f8 && !a.poly_planes && !a.k1_wrap && a.fast_epi && a.up == 1 && a.stride == 1)) return false;
   if (a.f8r && !a.x8) return false;
   if (a.y8 && !a.y16) return false;
+  // (the epilogue evaluates the leaky-relus as max(v, v * slope) and min(r, r / slope): slopes in (0, 1])
+  if (a.y16 && !(a.y16_slope > 0.f && a.y16_slope <= 1.f)) return false;
+  if (a.res16 && !(a.res16_inv >= 1.f)) return false;
   // (rows <= 64: the kernel has a 64 x 384 layout, WR = 1, whose X tiles hold both chunk pairs of the 64-channel stage — measured SLOWER
   // than the register-staged tile there, 183-189 against 150 us at 11 taps: 6.6 tiles per block with 112 KB of X each; not dispatched)
   if (!epilogue16_supports(a) || a.ksize < 3 || a.cin_g % 32 != 0 || a.rows_g <= 64) return false;

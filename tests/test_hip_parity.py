@@ -226,7 +226,7 @@ def test_stride4_upsampler_on_the_ring_with_rows_grouped_by_phase(cfg):
                y_split_slope=0.1, no_y=True)
     wpg = packing.pack_conv_weight_f16x3(wg, up=u)
     outs = []
-    for mask in (zt, 0, 0x1):     # (0x1 is not the pattern with an instantiation of its own: everything is multiplied)
+    for mask in (zt, 0, 0x300):   # (a subset of the true zeros is not the pattern with an instantiation of its own: everything is multiplied)
         ys = torch.full((B, cout // 16, 2, 2, T * u, 8), 7.0, dtype=torch.float16, device=DEV)
         guard = torch.full((B, cout, T * u), 7.0, device=DEV)
         ops.conv1d(x, wpg, cout, kp, bias=b, pad_left=pl, up=u, mode=1, x_split=xs, y_split=ys, y_split_slope=0.1, no_y=True, out=guard,
@@ -235,6 +235,10 @@ def test_stride4_upsampler_on_the_ring_with_rows_grouped_by_phase(cfg):
         assert (guard == 7.0).all()
         outs.append(ys)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # a mask that claims a (slot, phase) pair the packed weights do NOT have all-zero is refused (the packer recorded the true zeros)
+    with pytest.raises(_lib.SatError):
+        ops.conv1d(x, wpg, cout, kp, bias=b, pad_left=pl, up=u, mode=1, x_split=xs, y_split=ys, y_split_slope=0.1, no_y=True,
+                   up_grouped=True, up_zero_taps=0x1)
     ref = F.leaky_relu(F.conv_transpose1d(F.leaky_relu(x.double().cpu(), 0.1), w.double().cpu(), b.double().cpu(), stride=u, padding=pad), 0.1)
     got = ops.unsplit(outs[0]).double().cpu()
     assert (got - ref).abs().max() < 4e-6
