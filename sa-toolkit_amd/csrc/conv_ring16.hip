@@ -95,7 +95,14 @@ struct RingArgs {
 // planes, MRF accumulation, f32 and / or plane stores — the arithmetic of conv_epilogue16 for exactly these options, in its
 // order (same bits).  Every load is requested before the stores that would delay it (vmcnt retires in issue order): the
 // biases of all rows first, then per 16-row strip the residual words and the accumulator values of the NEXT strip.
-template <int MT, int NT>
+// PROF: the option set as compile-time constants for the three launches a ResBlock step makes (round 5: the generic form spent ~7
+// wave-uniform branches and ~20 register copies per 16 x 16 subtile on options that never change inside a launch) —
+//   0 whatever the job says (run-time flags);
+//   1 conv1: planes out (+ sidecar, lo units not stored, when Y8), nothing else;
+//   2 conv2 of steps 1, 2: residual from planes, planes out (+ sidecar when Y8);
+//   3 conv2 of step 3: residual from planes, f32 out with the MRF accumulation / division and the next stage's planes as the job says.
+// Same arithmetic in the same order: the bits of the generic form.
+template <int MT, int NT, int PROF = 0, bool Y8 = false>
 __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& A, f32x4 (&acc)[MT][NT], int b, int co_w, int q_w, int li, int lg) {
   const unsigned OOB = 0x80000000u;
   const int rows_g = A.rows_g, T_q = A.T_q;
@@ -111,9 +118,13 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
   const __amdgpu_buffer_rsrc_t y8rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(e.y8 ? (char*)e.y8 + (long long)b * rows_g * T_q * 2 : (char*)e.bias), 0, e.y8 ? (unsigned)(rows_g * T_q * 2) : 0u, 0x00020000);
   const int y_rb = (int)e.y_cs * 4;
-  const bool has_y = e.y != nullptr, has_y16 = e.y16 != nullptr, has_res = e.res16 != nullptr, accum = e.accum != 0;
-  const bool has_y8 = e.y8 != nullptr, hi_only = e.hi_only != 0;
-  const float descale = e.w_descale, slope = e.y16_slope, inv = e.res16_inv, div = e.accum_div;
+  const bool has_y = PROF == 0 ? e.y != nullptr : PROF == 3;
+  const bool has_y16 = (PROF == 0 || PROF == 3) ? e.y16 != nullptr : true;
+  const bool has_res = PROF == 0 ? e.res16 != nullptr : PROF >= 2;
+  const bool accum = (PROF == 0 || PROF == 3) ? e.accum != 0 : false;
+  const bool has_y8 = PROF == 0 ? e.y8 != nullptr : (PROF == 3 ? false : Y8);
+  const bool hi_only = PROF == 0 ? e.hi_only != 0 : (PROF == 1 && Y8);
+  const float descale = e.w_descale, slope = e.y16_slope, inv = e.res16_inv, div = (PROF == 0 || PROF == 3) ? e.accum_div : 0.f;
   float bi[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -122,9 +133,11 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
     for (int r = 0; r < 4; ++r) bi[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (row0 + r) * 4, 0, 0));
   }
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 rn[NT];
-  f32x4 yn[NT];
+  u32x4 rbuf[2][NT];          // residual words / accumulator values of strip m in set m & 1 (the loop is unrolled: static indices, no copies)
+  f32x4 ybuf[2][NT];
   auto load_strip = [&](int m) __attribute__((always_inline)) {
+    u32x4 (&rn)[NT] = rbuf[m & 1];
+    f32x4 (&yn)[NT] = ybuf[m & 1];
     const int chunk = (co_w >> 4) + m, row0 = co_w + m * 16 + 4 * lg;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -149,11 +162,9 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
   for (int m = 0; m < MT; ++m) {
     const int row0 = co_w + m * 16 + 4 * lg, chunk = (co_w >> 4) + m;
     const bool rows_ok = co_w + m * 16 < rows_g;       // wave-uniform: padding rows of the block's tile
-    u32x4 rr[NT];
-    f32x4 yv[NT];
+    u32x4 (&rr)[NT] = rbuf[m & 1];
+    f32x4 (&yv)[NT] = ybuf[m & 1];
     if (has_res || accum) {
-#pragma unroll
-      for (int n = 0; n < NT; ++n) rr[n] = rn[n], yv[n] = yn[n];
       if (m + 1 < MT) load_strip(m + 1);
     }
 #pragma unroll
@@ -742,7 +753,15 @@ __global__ void __launch_bounds__(512, 2) conv1d_f16x3_ring16_kernel(const RingA
     if (!(A.diag & 4)) {
       const RingJob ej = A.job[done.j];
       if constexpr (UPS) ring_epilogue_ups<NT>(ej, A, acc, done.b, done.co_b + wr * 64, done.q_b + wc * (16 * NT), li, lg);
-      else ring_epilogue<MT, NT>(ej, A, acc, done.b, done.co_b + wr * 64, done.q_b + wc * (16 * NT), li, lg);
+      else {
+        // the option set of this job as one of the three ResBlock profiles (wave-uniform: one branch per tile instead of seven per subtile)
+        const bool plain = !ej.y && ej.y16 && !ej.accum && ej.accum_div == 0.f && ((ej.y8 != nullptr) == F8);
+        const int co_e = done.co_b + wr * 64, q_e = done.q_b + wc * (16 * NT);
+        if (plain && !ej.res16 && ((ej.hi_only != 0) == F8)) ring_epilogue<MT, NT, 1, F8>(ej, A, acc, done.b, co_e, q_e, li, lg);
+        else if (plain && ej.res16 && !ej.hi_only) ring_epilogue<MT, NT, 2, F8>(ej, A, acc, done.b, co_e, q_e, li, lg);
+        else if (ej.y && ej.res16 && !ej.y8) ring_epilogue<MT, NT, 3, F8>(ej, A, acc, done.b, co_e, q_e, li, lg);
+        else ring_epilogue<MT, NT>(ej, A, acc, done.b, co_e, q_e, li, lg);
+      }
     }
     if constexpr (STAMP) st_epi += cr_clock() - p0;
     if (!more) break;

@@ -382,7 +382,9 @@ def test_sharded_job_runs_on_rccl_in_a_child_process():
                WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     # (--headline-only: the fbank tag of configs[1]; without it the wav2vec2 tag of BASELINE configs[4] runs first through the same
     # code and its line goes to stderr as CONFIG_LINE)
-    for extra in (["--headline-only"], ["--gather", "pcm16"]):
+    # (round 5: the exchange is issued in chunks of --gather-chunk batches on a communication stream while the shard is computed;
+    # 0 = the single all_gather_into_tensor at the end, which every run also performs afterwards as the checked reference)
+    for extra in (["--headline-only", "--gather-chunk", "1"], ["--gather", "pcm16"], ["--headline-only", "--gather-chunk", "0"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                             "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -393,9 +395,13 @@ def test_sharded_job_runs_on_rccl_in_a_child_process():
             cfg = line["config"]
             assert cfg["ranks_seen_by_rccl"] == [0], cfg
             assert cfg["all_gather_ms"] > 0.0
-            assert cfg["gathered_equals_shard"] is True, cfg
+            assert cfg["gathered_equals_shard"] is True and cfg["chunked_equals_single_collective"] is True, cfg
+            assert len(cfg["compute_ms_per_rank"]) == 1 and cfg["compute_ms_min_max"][0] > 0.0
+            if "--gather-chunk" in extra:
+                k = int(extra[extra.index("--gather-chunk") + 1])
+                assert ("2 asynchronous all-gathers" in cfg["all_gather"]) == (k == 1) and ("one all_gather_into_tensor" in cfg["all_gather"]) == (k == 0), cfg["all_gather"]
             assert cfg["gather_dtype"] == ("int16" if "pcm16" in extra else "float32")
-            assert cfg["utterances"] == 64 and line["n_gpus"] == 1 and line["value"] > 0
+            assert cfg["utterances"] == 64 and line["n_gpus"] == 1 and line["value"] > 0 and line["repeats"]["windows"] >= 1
         if len(lines) == 2:
             assert "wav2vec2" in lines[1]["config"]["workload"] and "wav2vec2" not in lines[0]["config"]["workload"]
 

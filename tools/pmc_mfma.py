@@ -27,6 +27,7 @@ def load(path):
     return per, cnt, dur
 
 
+# (clock_GHz = GRBM_GUI_ACTIVE / 8 / duration reads high on dispatches under 0.3 ms: reported as null there)
 def main():
     a, cnt, dur = load(sys.argv[1])
     b, _, _ = load(sys.argv[2])
@@ -40,7 +41,7 @@ def main():
         wc = max(w.get("SQ_WAVE_CYCLES", 0.0), 1.0)
         rows.append({"kernel": k[0], "grid": k[1], "launches_per_forward": round(cnt[k] / fw, 1),
                      "avg_us": round(dur[k] / cnt[k] / 1e3, 1), "ms_per_forward": round(dur[k] / fw / 1e6, 3),
-                     "clock_GHz": (round(cyc / dur[k], 2) if dur[k] / cnt[k] >= 3e5 else None),      # (GRBM_GUI_ACTIVE / duration reads high on dispatches under 0.3 ms: not reported) "mfma_util": round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc, 3),
+                     "clock_GHz": (round(cyc / dur[k], 2) if dur[k] / cnt[k] >= 3e5 else None), "mfma_util": round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc, 3),
                      "wait_any": round(w.get("SQ_WAIT_ANY", 0) / wc, 2), "wait_inst_any": round(w.get("SQ_WAIT_INST_ANY", 0) / wc, 2),
                      "wait_inst_lds": round(w.get("SQ_WAIT_INST_LDS", 0) / wc, 2),
                      "lds_bank_conflict_share": round(w.get("SQ_LDS_BANK_CONFLICT", 0) / max(w.get("SQ_LDS_IDX_ACTIVE", 0), 1), 3)})
