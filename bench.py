@@ -451,7 +451,7 @@ def roofline_generator(model, dev, reps):
             break
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note,
-            "kernel": (("split-f16 conv family of the generator" + (" (e4m3 cross terms on the thick stages)" if f8 else "")) if split else "conv1d_mfma_kernel (exact f32)")
+            "kernel": (("split-f16 conv family of the generator" + (" (8-bit cross terms on the thick stages)" if f8 else "")) if split else "conv1d_mfma_kernel (exact f32)")
                       + f": all launches of one forward, {gen_ms:.3f} ms per batch of {BATCH}",
             "timing_ms": dict(gen_t, median=round(gen_ms, 4)),
             "dominant_kernel": dom,
@@ -526,9 +526,9 @@ def gen_arithmetic(model):
                 f8 += 2.0 * C * C * T * sum(g.resblock_kernel_sizes) * 6
         share = f8 / GEN_FLOP_PER_UTT
         peak = 1.0 / (share / PEAK_F16F8R + (1.0 - share) / PEAK_F16X3)
-        return (f"f32 (matrix products as split-f16: hi*hi on the f16 MFMA; cross terms on the e4m3 MFMA in the ResBlock convs of stages "
+        return (f"f32 (matrix products as split-f16: hi*hi on the f16 MFMA; cross terms on the block-scaled 8-bit MFMA (weights e4m3, activations e5m2) in the ResBlock convs of stages "
                 f"{sorted(s + 1 for s in stages)} = {100 * share:.0f} % of the generator's FLOP, as two more f16 products elsewhere; f32 accumulate)",
-                peak, f"split-f16; {100 * share:.0f} % of the FLOP at 2 f16-product units per product (f16 + 2 x e4m3 at twice the rate: peak "
+                peak, f"split-f16; {100 * share:.0f} % of the FLOP at 2 f16-product units per product (f16 + 2 x 8-bit at twice the rate: peak "
                       f"{PEAK_F16F8R:.0f}), the rest at 3 (peak {PEAK_F16X3:.0f}): FLOP-weighted harmonic peak")
     if g.precision == "f16x3":
         return "f32 (matrix products as split-f16 x3 with f32 accumulate)", PEAK_F16X3, "f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 MFMA peak / 3"
