@@ -37,3 +37,27 @@ def test_oracle_matches_reference_outputs():
     wav = synthetic.harm_batch([1, 2], 16000)
     both = ox.xvector(sd, wav)
     assert torch.allclose(both[0], ox.xvector(sd, wav[0])[0], atol=1e-6)
+
+
+def test_melspectrogram_is_cross_checked_against_an_independent_implementation():
+    """SURVEY §8 row aX / f3, the front end: torchaudio.transforms.MelSpectrogram (satools/satools/sidekit/preprocessor.py:205-213: n_fft 1024,
+    win 400, hop 160, hann, power 2, 80 mel over 90-7600 Hz) is third party and absent; oracle/melspec.py restates it.  Round 5 pins the
+    restatement against an independent implementation that IS installed: HF transformers' `audio_utils` (its `mel_filter_bank(norm=None,
+    mel_scale="htk")` and `spectrogram(center=True, pad_mode="reflect")` are written to reproduce torchaudio's `melscale_fbanks` and
+    `Spectrogram`) — filter bank, power mel spectrogram and the log the reference takes of it; the other mel scale differs by O(1)."""
+    from transformers import audio_utils as au
+    from oracle import melspec
+    fb_o = melspec.melscale_fbanks().numpy()
+    fb_t = au.mel_filter_bank(513, 80, 90.0, 7600.0, 16000, norm=None, mel_scale="htk")
+    assert fb_o.shape == fb_t.shape == (513, 80) and np.abs(fb_o - fb_t).max() < 2e-5        # (f32 linspace against float64)
+    assert np.abs(fb_o - au.mel_filter_bank(513, 80, 90.0, 7600.0, 16000, norm=None, mel_scale="slaney")).max() > 0.5
+    win = au.window_function(400, "hann", periodic=True, frame_length=1024, center=True)       # the 400-sample window centred in the 1024-point frame, as torch.stft does
+    assert np.abs(win[312:712] - torch.hann_window(400, periodic=True).numpy()).max() < 1e-7 and not win[:312].any() and not win[712:].any()
+    for seed, n in ((0, 16000), (1, 48000), (2, 8123)):
+        x = synthetic.harm_batch([seed], n)[0] if seed else torch.randn(n, generator=torch.Generator().manual_seed(0)) * 0.1
+        ref = au.spectrogram(x.numpy().astype(np.float64), win, frame_length=1024, hop_length=160, fft_length=1024, power=2.0, center=True,
+                             pad_mode="reflect", onesided=True, mel_filters=fb_t, mel_floor=0.0, dtype=np.float64)
+        got = melspec.melspectrogram(x).numpy()
+        assert got.shape == ref.shape == (80, 1 + n // 160)
+        assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max()
+        assert np.abs(np.log(got + 1e-6) - np.log(ref + 1e-6)).max() < 2e-4                     # (`torch.log(MelSpec(x) + 1e-6)`, preprocessor.py:229-230)
