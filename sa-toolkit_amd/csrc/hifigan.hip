@@ -142,7 +142,7 @@ struct sat_hifigan {
                              // to it, and measured 5 % faster: fewer live registers); 1 = kept in f32 registers
   int ups_ring = 0;          // the stride-4 upsamplers' packed rows are grouped by phase (sat_conv1d_desc.up_grouped): set by the packer's side
   int ups2 = 1;              // the thin upsamplers (C_in = 64, 32; k 4, stride 2) on the streaming kernel of ups2.hip
-  int f8_stages = 0;         // bit i: the ResBlock convs of stage i as SAT_CONV_F16F8R (e4m3 cross terms on the ring kernel) where their second packing is
+  int f8_stages = 0;         // bit i: the ResBlock convs of stage i as SAT_CONV_F16F8R (8-bit cross terms on the ring kernel) where their second packing is
                              // installed and the ring kernel serves the batch
   int multi_branch = 1;      // thick stages (C > 64): the i-th conv of all MRF branches as one sat_conv1d_multi_f32 call (one launch where the ring kernel serves them)
   int fuse_mrf = 1;          // a whole MRF block (all branches, all steps, the mean) as one launch where mrf.hip supports the stage (C = 16)
@@ -389,7 +389,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
       const int u = h->up_rates[i], k = h->up_kernels[i];
       const int Cn = C / 2, Tn = Tc * u;
       const bool last_stage = i == h->n_ups() - 1;
-      // this stage's ResBlock convs with e4m3 cross terms (SAT_CONV_F16F8R): the one-launch-per-conv path of the thick stages, every
+      // this stage's ResBlock convs with 8-bit cross terms (SAT_CONV_F16F8R): the one-launch-per-conv path of the thick stages, every
       // conv's second packing installed, and a batch the ring kernel would serve anyway (small batches keep the f16x3 tiles)
       bool use_f8 = ((h->f8_stages >> i) & 1) && h->multi_branch && planes_res_all && !(side && i < h->branch_streams) && nk >= 2 && nk <= 3 &&
                     Cn > 64 && Cn % 32 == 0 && convring_wanted(Cn, Tn, B);
@@ -397,7 +397,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         for (int pair = 0; pair < 3; ++pair)
           use_f8 = use_f8 && h->convs[h->id_rb(i, j, pair, 0)].w8 && h->convs[h->id_rb(i, j, pair, 1)].w8 &&
                    (h->rb_kernels[j] - 1) * h->rb_dil[j * 3 + pair] <= 64 && h->rb_kernels[j] >= 3;
-      // e4m3 sidecars (half a slot each: 2 bytes per element) in the slots of the f32 twins this pipeline does not write
+      // 8-bit (e5m2) sidecars (half a slot each: 2 bytes per element) in the slots of the f32 twins this pipeline does not write
       void* Hs8 = ws + 0 * slot;
       auto br8 = [&](int j, int which) { return ws + (size_t)(5 + j * 5 + (which < 2 ? 1 : 3)) * slot + (which == 1 ? slot / 2 : 0); };   // 0 T1, 1 RA, 2 RB
       {
