@@ -392,3 +392,32 @@ def test_long_utterances_with_the_e4m3_kernels(fbank_tag_state, seconds):
         m.eval()
         assert m.hifigan.precision == "f16f8r"
         R.test_convert_long_utterances_fbank_tag(m, fbank_tag_state, seconds)
+
+
+@pytest.mark.parametrize("cin,cout,T,k,dil", [(32, 128, 333, 3, 1), (32, 256, 200, 7, 3), (64, 256, 161, 11, 5), (256, 128, 640, 3, 5)], ids=lambda v: str(v))
+def test_ring_conv_f16f8r_with_unequal_channel_counts(cin, cout, T, k, dil):
+    """one chunk pair only (C_in = 32: no second X tile, an odd number of elements at 3 taps), two (64), and C_in != C_out either way —
+    against the decomposition evaluated in float64 (as test_ring_conv_f16f8r_matches_its_decomposition)"""
+    ops, packing = _ops()
+    from satools_amd import _lib
+    B = 2
+    x, w, b = _rand(B, cin, T, seed=1).to(DEV), _rand(cout, cin, k, seed=2, scale=(k * cin) ** -0.5).to(DEV), _rand(cout, seed=3).to(DEV)
+    xs = ops.act_split(x, 0.1)
+    xs8 = ops.planes_f8_sidecar(xs)
+    w8 = packing.pack_conv_weight_f16f8r(w)
+    pl = dil * (k - 1) // 2
+    ys, y8 = ops.split_like(B, cout, T, DEV).zero_(), ops.sidecar_like(B, cout, T, DEV).zero_()
+    y = ops.conv1d(x, w8, cout, k, bias=b, dilation=dil, pad_left=pl, mode=3, x_split=xs, x_split8=xs8, y_split=ys, y_split8=y8, y_split_slope=0.1)
+    assert "F8" in _lib.lib().sat_last_dispatch_name().decode()
+    xh, xl = _planes_hi_lo(ops, xs)
+    e = packing.f16x3_scale_exponent(w)
+    ws = w.cpu() * 2.0 ** e
+    wh = ws.to(torch.float16).float()
+    wl = (ws - wh).to(torch.float16).float()
+    conv = lambda a, ww: F.conv1d(a.double(), ww.double(), None, dilation=dil, padding=pl)
+    emu = (conv(xh, wh) + conv(_e5m2(xh).float(), _e4m3(wl, 9).float() / 2 ** 9)
+           + conv(_e5m2(xl, 10).float() / 2 ** 10, _e4m3(wh, -2).float() * 4.0)) / 2.0 ** e + b.double().cpu()[None, :, None]
+    err = (y.cpu().double() - emu).abs().max().item()
+    print(f"C_in {cin} -> C_out {cout}, {k} taps: vs decomposition {err:.2e} (scale {float(emu.abs().max()):.2f})")
+    assert err < 4e-6 * max(1.0, float(emu.abs().max()))
+    assert torch.equal(ys, ops.act_split(y, 0.1)) and torch.equal(y8, ops.planes_f8_sidecar(ys))
