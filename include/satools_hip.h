@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 5
+#define SAT_ABI_VERSION 6
 
 typedef enum {
   SAT_OK = 0,
@@ -401,6 +401,19 @@ int sat_f0_apply_f32(float* f0, int n, const float* stats, int quant_bins, const
 int sat_f0_mean_reversion_f32(const float* f0, float* out, int T, float alpha, int n, void* stream);
 int sat_assemble_input_f32(const float* bn, const float* f0, const float* spk, float* x,
                            int B, int C_bn, int T, int T_f0, int n_spk, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sample formats of the batch job's data plane (ABI 6).  The reference reads its utterances with torchaudio.load
+ * (satools/satools/utils/kaldi.py:113-125: 16-bit PCM normalised to [-1, 1) = s / 32768) and writes the anonymized ones with
+ * torchaudio.save(..., encoding='PCM_S', bits_per_sample=16) (satools/satools/bin/pipeline.py:159).  Doing both conversions
+ * on the device halves the bytes that cross PCIe in either direction and takes them off the host threads.
+ *   sat_pcm16_to_f32:   y[i] = x[i] / 32768 (exact)
+ *   sat_pcm16_from_f32: y[i] = clamp(rint(x[i] * 32768), -32768, 32767), round-half-even — the bits of
+ *                       numpy.clip(numpy.rint(float64(x) * 32768), -32768, 32767) (sa-toolkit_amd/pipeline.py: save_pcm16)
+ * n elements, contiguous; x != y.
+ * ------------------------------------------------------------------------------------------ */
+int sat_pcm16_to_f32(const int16_t* x, float* y, long long n, void* stream);
+int sat_pcm16_from_f32(const float* x, int16_t* y, long long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * YAAPT pitch tracker (satools/satools/hifigan/yaapt.py:795-951), whole batch per call.

@@ -141,6 +141,8 @@ _PROTOS = {
     "sat_softmax_columns_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "sat_transpose_heads_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]),
+    "sat_pcm16_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "sat_pcm16_from_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "sat_assemble_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p]),
 }
@@ -171,7 +173,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.sat_abi_version() != 5:       # 5: SAT_CONV_F16F8R; sat_conv1d_desc grew x_split8 / y_split8 / y_split_hi_only
+        if l.sat_abi_version() != 6:       # 5: SAT_CONV_F16F8R; sat_conv1d_desc grew x_split8 / y_split8 / y_split_hi_only.  6: sat_pcm16_*
             raise SatError("libsatools_hip.so ABI version mismatch")
         # A/B switches of the conv dispatch for whole-program measurements (bench.py under different kernels):
         # SATOOLS_AMD_CONV_OPTIONS="pair32w=0,lean_balance=2" -> sat_conv_set_option(name, value) at load time

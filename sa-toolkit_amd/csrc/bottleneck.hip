@@ -264,6 +264,36 @@ __global__ void __launch_bounds__(256) assemble_kernel(const float* __restrict__
   x[((size_t)b * C + c) * T + t] = v;
 }
 
+
+// ---- PCM16 <-> f32 (the data plane of the batch job: what torchaudio.load / torchaudio.save(bits_per_sample=16) do to the samples)
+template <bool VEC>
+__global__ void __launch_bounds__(256) pcm16_from_f32_kernel(const float* __restrict__ x, short* __restrict__ y, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  auto cv = [](float v) { return (short)fminf(fmaxf(rintf(v * 32768.f), -32768.f), 32767.f); };
+  if (VEC && i + 3 < n) {
+    const float4 v = *(const float4*)(x + i);
+    const short s0 = cv(v.x), s1 = cv(v.y), s2 = cv(v.z), s3 = cv(v.w);
+    *(uint2*)(y + i) = make_uint2((unsigned)(unsigned short)s0 | ((unsigned)(unsigned short)s1 << 16),
+                                  (unsigned)(unsigned short)s2 | ((unsigned)(unsigned short)s3 << 16));
+  } else {
+    for (long long j = i; j < n && j < i + 4; ++j) y[j] = cv(x[j]);
+  }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) pcm16_to_f32_kernel(const short* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (VEC && i + 3 < n) {
+    const uint2 v = *(const uint2*)(x + i);
+    *(float4*)(y + i) = make_float4((float)(short)(v.x & 0xffffu) * (1.f / 32768.f), (float)(short)(v.x >> 16) * (1.f / 32768.f),
+                                    (float)(short)(v.y & 0xffffu) * (1.f / 32768.f), (float)(short)(v.y >> 16) * (1.f / 32768.f));
+  } else {
+    for (long long j = i; j < n && j < i + 4; ++j) y[j] = (float)x[j] * (1.f / 32768.f);
+  }
+}
+
 }  // namespace sat
 
 using namespace sat;
@@ -340,5 +370,25 @@ extern "C" int sat_log_softmax_channels_f32(float* x, int B, int C, int T, void*
   SAT_REQUIRE(x && B > 0 && C > 0 && T > 0, "log_softmax_channels: bad arguments");
   hipLaunchKernelGGL(log_softmax_channels_kernel, dim3(ceil_div(T, 16), B), dim3(256), 0, (hipStream_t)stream, x, C, T);
   SAT_LAUNCH_CHECK("log_softmax_channels_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_pcm16_from_f32(const float* x, int16_t* y, long long n, void* stream) {
+  SAT_REQUIRE(x && y && n > 0 && n < (1ll << 40), "pcm16_from_f32: bad arguments");
+  const bool vec = ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0);
+  const dim3 grid((unsigned)((n + 1023) / 1024));
+  if (vec) hipLaunchKernelGGL(pcm16_from_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (short*)y, n);
+  else hipLaunchKernelGGL(pcm16_from_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (short*)y, n);
+  SAT_LAUNCH_CHECK("pcm16_from_f32_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_pcm16_to_f32(const int16_t* x, float* y, long long n, void* stream) {
+  SAT_REQUIRE(x && y && n > 0 && n < (1ll << 40), "pcm16_to_f32: bad arguments");
+  const bool vec = ((uintptr_t)y % 16 == 0) && ((uintptr_t)x % 8 == 0);
+  const dim3 grid((unsigned)((n + 1023) / 1024));
+  if (vec) hipLaunchKernelGGL(pcm16_to_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const short*)x, y, n);
+  else hipLaunchKernelGGL(pcm16_to_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const short*)x, y, n);
+  SAT_LAUNCH_CHECK("pcm16_to_f32_kernel");
   return SAT_OK;
 }

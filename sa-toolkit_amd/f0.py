@@ -8,6 +8,7 @@ them) and builds the three tables (hann, kaiser, FFT twiddles); everything else 
 sat_yaapt_f32.  Unlike the reference (serial over the batch, forced to the CPU, yaapt.py:798-799)
 the whole batch is processed in one call on the GPU."""
 import ctypes as C
+import functools
 import math
 
 import numpy as np
@@ -37,6 +38,7 @@ class YaaptPlan(C.Structure):
         ("lp", C.c_float * 6), ("hp", C.c_float * 6)]
 
 
+@functools.lru_cache(maxsize=64)
 def biquad_constants(kind, sample_rate, cutoff, Q=0.707):
     """RBJ biquad as torchaudio.functional.{lowpass,highpass}_biquad computes it (f32 tensors), then
     the normalisation `_lfilter` applies FIRST to both coefficient vectors: {b0/a0, b1/a0, b2/a0, a0, a1/a0, a2/a0}
@@ -111,6 +113,16 @@ def make_plan(n, opts):
     return P
 
 
+def length_dims(P, n):
+    """[n, L, nframes, tda_nframes] of make_plan(n, opts) from a plan P of the same options at another length: the only fields of a
+    plan that depend on the length (a ragged batch of 32 lengths was 32 full plans, 4 ms of host time per batch in the batch job's
+    launching thread; tests/test_host_logic.py holds the two against each other)"""
+    L = n + 2 * P.pad
+    half = P.frame_size // 2
+    nframes = len(range(half, L - half, P.frame_jump))
+    return [n, L, nframes, min(int((L - (P.tda_len - P.frame_jump)) / P.frame_jump), nframes)]
+
+
 _tables = {}
 
 
@@ -172,14 +184,7 @@ def yaapt_ragged(wav, lengths, opts, defer_status=False):
     if len(lens) != B or max(lens) > n_max or min(lens) <= 0:
         raise _lib.SatError("yaapt_ragged: lengths do not fit the batch")
     P = make_plan(n_max, dict(opts))
-    dims, cache = [], {}
-    for n in lens:
-        if n not in cache:
-            q = make_plan(n, dict(opts))
-            if q.pad != P.pad or q.frame_jump != P.frame_jump:
-                raise _lib.SatError("yaapt_ragged: plan constants depend on the length")
-            cache[n] = [q.n, q.L, q.nframes, q.tda_nframes]
-        dims.append(cache[n])
+    dims = [length_dims(P, n) for n in lens]
     if max(d[2] for d in dims) > P.nframes or max(d[1] for d in dims) > P.Lz:
         raise _lib.SatError("yaapt_ragged: an utterance exceeds the batch plan")
     hann, kaiser, tw = _get_tables(P, wav.device)

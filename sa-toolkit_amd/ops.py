@@ -207,6 +207,31 @@ def assemble_input(bn, f0, spk_idx, n_spk):
     return x
 
 
+def pcm16_to_f32(pcm):
+    """int16 PCM on the device -> f32 in [-1, 1): s / 32768, what torchaudio.load hands the reference (utils/kaldi.py:113-125)"""
+    if pcm.dtype != torch.int16 or not pcm.is_cuda:
+        raise _lib.SatError("pcm16_to_f32: an int16 tensor on the GPU")
+    pcm = pcm.contiguous()
+    y = torch.empty(pcm.shape, dtype=torch.float32, device=pcm.device)
+    if pcm.numel():
+        check(lib().sat_pcm16_to_f32(ptr(pcm), ptr(y), pcm.numel(), stream()), "sat_pcm16_to_f32")
+    return y
+
+
+def pcm16_from_f32(x, out=None):
+    """f32 waveforms on the device -> the int16 samples torchaudio.save(encoding='PCM_S', bits_per_sample=16) writes (bin/pipeline.py:159):
+    round-half-even of x * 32768, clipped"""
+    x = _f32c(x)
+    if not x.is_cuda:
+        raise _lib.SatError("pcm16_from_f32: a tensor on the GPU")
+    y = torch.empty(x.shape, dtype=torch.int16, device=x.device) if out is None else out
+    if y.dtype != torch.int16 or y.shape != x.shape or not y.is_contiguous() or y.device != x.device:
+        raise _lib.SatError("pcm16_from_f32: `out` must be a contiguous int16 tensor of x's shape on x's device")
+    if x.numel():
+        check(lib().sat_pcm16_from_f32(ptr(x), ptr(y), x.numel(), stream()), "sat_pcm16_from_f32")
+    return y
+
+
 # ---- wav2vec2 support -------------------------------------------------------------------------------
 def w2v2_conv0(wav, w, bias, stride=5):
     wav = _f32c(wav)

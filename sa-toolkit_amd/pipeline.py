@@ -22,6 +22,7 @@ import logging
 import os
 import random
 import shutil
+import struct
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -108,15 +109,65 @@ def load_wav_from_scp(wav, frame_offset=0, num_frames=-1):
     return sample, sr
 
 
+def read_pcm16_mono(path):
+    """the plain case of `load_wav_from_scp` without the float conversion: a RIFF file holding one channel of 16-bit PCM ->
+    (int16 samples [n] viewing the file's bytes, sample rate); None for anything else (other sample formats, several channels,
+    WAVE_FORMAT_EXTENSIBLE, a data chunk that runs past the end of the file: `_decode_wav` handles or rejects those).  The batch
+    job keeps such utterances as int16 up to the device (`sat_pcm16_to_f32`: s / 32768, the value torchaudio.load gives)."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    n = len(buf)
+    if n < 44 or buf[:4] != b"RIFF" or buf[8:12] != b"WAVE":
+        return None
+    pos, fmt = 12, None
+    while pos + 8 <= n:
+        cid, size = buf[pos:pos + 4], int.from_bytes(buf[pos + 4:pos + 8], "little")
+        body = pos + 8
+        if cid == b"fmt ":
+            if size < 16 or body + 16 > n:
+                return None
+            tag, ch, sr, _rate, align, bits = struct.unpack_from("<HHIIHH", buf, body)
+            fmt = (tag, ch, sr, align, bits)
+        elif cid == b"data":
+            if fmt is None or fmt[0] != 1 or fmt[1] != 1 or fmt[3] != 2 or fmt[4] != 16 or size % 2 or body + size > n:
+                return None
+            return np.frombuffer(buf, dtype="<i2", count=size // 2, offset=body), int(fmt[2])
+        pos = body + size + (size & 1)
+    return None
+
+
+def pcm16_of(wav):
+    """f32 samples -> the int16 ones of torchaudio.save(..., encoding='PCM_S', bits_per_sample=16): round-half-even of x * 32768, clipped.
+    UNPINNED against torchaudio (third party, not installable here): a sox / ffmpeg backend that truncates or scales by 32767
+    differs by at most 1 LSB (3e-5 of full scale, below the path's 1e-4 RMS bar).  `sat_pcm16_from_f32` computes the same bits on
+    the device (x * 32768 is exact in f32 as in f64)."""
+    x = wav.detach().cpu().numpy() if isinstance(wav, torch.Tensor) else np.asarray(wav)
+    if x.dtype == np.int16:
+        return x
+    return np.clip(np.rint(x.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+
+
+def write_riff_pcm16(path, pcm, freq):
+    """int16 samples [n] or [channels, n] -> a RIFF file: the 44-byte header scipy.io.wavfile.write (and sox) produce for PCM — `fmt `
+    chunk of 16 bytes, format tag 1, no `fact` chunk — then the interleaved samples"""
+    pcm = np.asarray(pcm)
+    ch = 1 if pcm.ndim == 1 else int(pcm.shape[0])
+    data = np.ascontiguousarray(pcm.reshape(-1) if ch == 1 else pcm.T, dtype="<i2")
+    nbytes = data.size * 2
+    if nbytes + 36 > 0xFFFFFFFF:
+        raise ValueError("write_riff_pcm16: more than 4 GB of samples do not fit a RIFF file")
+    freq = int(freq)
+    header = (b"RIFF" + struct.pack("<I", 36 + nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, ch, freq, freq * ch * 2, ch * 2, 16)
+              + b"data" + struct.pack("<I", nbytes))
+    with open(str(path), "wb") as f:
+        f.write(header)
+        f.write(memoryview(data).cast("B"))
+
+
 def save_pcm16(path, wav, freq):
-    """torchaudio.save(path, wav, freq, encoding='PCM_S', bits_per_sample=16) restated: [channels, n] f32 -> RIFF.
-    UNPINNED against torchaudio (third party, not installable here): round-half-even of x * 32768 with clipping; a sox
-    / ffmpeg backend that truncates or scales by 32767 differs by at most 1 LSB (3e-5 of full scale, below the
-    path's 1e-4 RMS bar)"""
-    from scipy.io import wavfile
-    x = wav.detach().cpu().numpy().astype(np.float64)
-    pcm = np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16)
-    wavfile.write(str(path), int(freq), np.ascontiguousarray(pcm.T))
+    """torchaudio.save(path, wav, freq, encoding='PCM_S', bits_per_sample=16) restated: [channels, n] f32 (or int16 samples that are
+    already converted) -> RIFF (`pcm16_of`, `write_riff_pcm16`)"""
+    write_riff_pcm16(path, pcm16_of(wav), freq)
 
 
 # ---- pipeline.py:19-66 ---------------------------------------------------------------------------
@@ -144,6 +195,16 @@ def collate_fn(item_list):
         for i, f in enumerate(f0s):
             f0[i, :f.shape[-1]] = f.squeeze()
     return out, f0, lengths, [i["utid"] for i in item_list], [i["freq"] for i in item_list]
+
+
+def collate_pcm16(item_list):
+    """`collate_fn` for a batch whose utterances are all still int16 (`read_pcm16_mono`): zero-padded [B, n_max] int16 as a numpy
+    array instead of the f32 tensor — s / 32768 of it IS collate_fn's audio — with the same lengths, ids and rates"""
+    lengths = torch.tensor([int(i["pcm"].shape[0]) for i in item_list])
+    out = np.zeros((len(item_list), int(torch.max(lengths).item())), dtype=np.int16)
+    for k, i in enumerate(item_list):
+        out[k, :i["pcm"].shape[0]] = i["pcm"]
+    return out, None, lengths, [i["utid"] for i in item_list], [i["freq"] for i in item_list]
 
 
 class TargetSelector:
@@ -201,7 +262,7 @@ class _Shard:
         self.selector = selector
         self.stream = stream
         self.pos = 0
-        self.ring = [{"in": None, "out": None, "busy": None} for _ in range(3)]
+        self.ring = [{"buf": {}, "busy": None} for _ in range(3)]
         self.ring_pos = 0
 
     def next_keys(self):
@@ -224,6 +285,11 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
     result when the utterances of a batch have one length, faster otherwise).
     scp_out: where the `utt path` lines go (default `<out>/wav.scp`; the CLI gives every process its own part
     file and merges them — the reference lets its jobs overwrite each other's wav.scp)."""
+    with _TorchThreads(1 if torch.device(settings.device).type == "cuda" else None):
+        return _process_data(dataset_path, target_selection_algorithm, wavscps, settings, progress, model, rng_state, scp_out, f0_mode)
+
+
+def _process_data(dataset_path, target_selection_algorithm, wavscps, settings, progress, model, rng_state, scp_out, f0_mode):
     if isinstance(wavscps, dict):
         wavscps = [wavscps]
     dataset_path = Path(str(dataset_path))
@@ -248,6 +314,11 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
         rng_state = random.getstate()
 
     use_streams = device.type == "cuda"
+    # (process_data:) intra-op threads of torch's CPU kernels: ONE for the duration of the job, as in the reference (`torch.set_num_threads(1)` at the
+    # import of satools/hifigan/yaapt.py:27).  Measured on the 256-core host of an MI355X box (tools/scratch/pcm_in_probe5.py): a single
+    # parallel CPU op per batch — `pinned.copy_(batch)`, 10 MB — leaves torch's OpenMP team spinning on every core after the copy and the
+    # HIP runtime's own threads starved: the batch took 31 ms instead of 10.7 (the wait for the F0 status word 21-27 ms instead of 8.7),
+    # with a numpy copy or one torch thread 10.7-10.8.  The host-side work of this job is small copies: nothing here wants a thread team.
     shards = [_Shard(w, settings.batch_size,
                      TargetSelector(target_selection_algorithm, possible_targets, source_utt2spk,
                                     getattr(settings, "target_constant_spkid", "?"), rng_state),
@@ -261,22 +332,46 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
     writers = ThreadPoolExecutor(max_workers=4)
     depth = 2
 
+    # (SATOOLS_AMD_PIPELINE_PCM16=0: f32 on both sides of PCIe, conversions on the host threads — the A/B switch of tools/bench_pipeline.py)
+    _pcm_bits = int(os.environ.get("SATOOLS_AMD_PIPELINE_PCM16", "3"))
+    keep_pcm16, out_pcm16 = bool(_pcm_bits & 1), bool(_pcm_bits & 2)
+
     def read_one(item):
         utid, entry = item
-        audio, freq = load_wav_from_scp(str(entry))
-        return {"utid": utid, "audio": audio, "f0": None, "freq": freq}
+        entry = str(entry).strip()
+        if keep_pcm16 and not entry.endswith("|"):
+            fast = read_pcm16_mono(entry)
+            if fast is not None:
+                return {"utid": utid, "pcm": fast[0], "audio": None, "f0": None, "freq": fast[1]}
+        audio, freq = load_wav_from_scp(entry)
+        return {"utid": utid, "pcm": None, "audio": audio, "f0": None, "freq": freq}
 
     def read_batch(chunk):
-        return collate_fn(list(file_pool.map(read_one, chunk)))
+        items = list(file_pool.map(read_one, chunk))
+        if all(i["pcm"] is not None for i in items):
+            return collate_pcm16(items)             # the usual case: 16-bit mono files stay int16 up to the device
+        for i in items:
+            if i["audio"] is None:
+                i["audio"] = torch.from_numpy(i["pcm"].astype(np.float32) * np.float32(1.0 / 32768.0)).unsqueeze(0)
+        return collate_fn(items)
+
+    def staging(slot, kind, like_numel, dtype):
+        # page-locked staging buffers are expensive to create (~100 ms for 10 MB): a ring of three slots per job, a buffer per
+        # (direction, sample type) in each, reused once the writer that reads the slot's output has finished
+        buf = slot["buf"].get((kind, dtype))
+        if buf is None or buf.numel() < like_numel:
+            buf = slot["buf"][(kind, dtype)] = torch.empty(like_numel, dtype=dtype, pin_memory=True)
+        return buf[:like_numel]
 
     def write_batch(wav_conv, done_event, utid, freq, original_len):
         if done_event is not None:
             done_event.synchronize()
-        for i in range(wav_conv.shape[0]):
-            wav = wav_conv[i]
-            if len(wav.shape) == 1:
-                wav = wav.unsqueeze(0)
-            save_pcm16(results_dir / f"{utid[i]}.wav", wav[:, :int(original_len[i])], freq)
+        arr = wav_conv.detach().numpy()             # f32, or int16 already converted on the device (sat_pcm16_from_f32)
+        for i in range(arr.shape[0]):
+            wav = arr[i]
+            if wav.ndim == 1:
+                wav = wav[None, :]
+            write_riff_pcm16(results_dir / f"{utid[i]}.wav", pcm16_of(wav[:, :int(original_len[i])]), freq)
 
     pending_writes, n_done = [], 0
     scp_lines = [[] for _ in shards]
@@ -292,7 +387,7 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
         top_up(si)
     timing = os.environ.get("SATOOLS_AMD_PIPELINE_TIMING") == "1"     # diagnostic: where the launching thread waits
     import time as _time
-    t_wait_read = t_wait_slot = t_launch = 0.0
+    t_wait_read = t_wait_slot = t_launch = t_convert = 0.0
     with torch.no_grad():
         while any(prefetch):
             for si, sh in enumerate(shards):
@@ -307,8 +402,7 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
                 kw = {"target": targets} if len(targets) != 0 else {}
                 ctx = torch.cuda.stream(sh.stream) if sh.stream is not None else _null()
                 with ctx:
-                    # page-locked staging buffers are expensive to create (~100 ms for 10 MB): a ring of three per
-                    # job, reused once the writer that reads the slot's output has finished
+                    is_pcm = isinstance(audio, np.ndarray)          # (collate_pcm16: int16 [B, n_max])
                     slot = None
                     if use_streams:
                         slot = sh.ring[sh.ring_pos % len(sh.ring)]
@@ -317,13 +411,14 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
                             _t2 = _time.perf_counter()
                             slot["busy"].result()
                             t_wait_slot += _time.perf_counter() - _t2
-                        if slot["in"] is None or slot["in"].numel() < audio.numel():
-                            slot["in"] = torch.empty(audio.numel(), dtype=torch.float32, pin_memory=True)
-                        pin = slot["in"][:audio.numel()].view(audio.shape)
-                        pin.copy_(audio)
+                        src = audio if is_pcm else audio.numpy()
+                        pin = staging(slot, "in", src.size, torch.int16 if is_pcm else torch.float32).view(src.shape)
+                        np.copyto(pin.numpy(), src)      # (NOT pin.copy_(): see the note on intra-op threads above)
                         x = pin.to(device, non_blocking=True)
+                        if is_pcm:
+                            x = _ops().pcm16_to_f32(x)
                     else:
-                        x = audio.to(device)
+                        x = (torch.from_numpy(audio.astype(np.float32) * np.float32(1.0 / 32768.0)) if is_pcm else audio).to(device)
                     fused = f0_mode == "per_utterance" and hasattr(model, "convert_padded") and len(targets) != 0
                     if f0_mode == "per_utterance" and not fused:
                         if hasattr(model, "get_f0_ragged"):
@@ -343,11 +438,14 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
                         model.set_f0(f0.to(device))
                     elif f0_mode not in ("per_utterance", "batch"):
                         raise ValueError(f"unknown f0_mode {f0_mode!r}")
+                    _t3 = _time.perf_counter()
                     wav_conv = model.convert_padded(x, original_len.tolist(), targets) if fused else model.convert(x, **kw)
+                    t_convert += _time.perf_counter() - _t3
                     if use_streams:
-                        if slot["out"] is None or slot["out"].numel() < wav_conv.numel():
-                            slot["out"] = torch.empty(wav_conv.numel(), dtype=wav_conv.dtype, pin_memory=True)
-                        host = slot["out"][:wav_conv.numel()].view(wav_conv.shape)
+                        # the samples the files hold are made on the device: half the bytes to copy back, nothing to round on the host
+                        if out_pcm16 and wav_conv.is_cuda and wav_conv.dtype == torch.float32:
+                            wav_conv = _ops().pcm16_from_f32(wav_conv)
+                        host = staging(slot, "out", wav_conv.numel(), wav_conv.dtype).view(wav_conv.shape)
                         host.copy_(wav_conv, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(sh.stream)
@@ -368,7 +466,7 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
         w.result()
     if timing:
         print(f"[pipeline timing] launching thread: waited {t_wait_read:.3f} s for readers, {t_wait_slot:.3f} s for a free "
-              f"staging slot (writers / GPU), {t_launch - t_wait_slot:.3f} s in staging + launches, {n_done} utterances", flush=True)
+              f"staging slot (writers / GPU), {t_launch - t_wait_slot - t_convert:.3f} s in staging, {t_convert:.3f} s inside convert (launches), {n_done} utterances", flush=True)
     readers.shutdown()
     file_pool.shutdown()
     writers.shutdown()
@@ -378,6 +476,29 @@ def process_data(dataset_path, target_selection_algorithm, wavscps, settings, pr
         for lines in scp_lines:
             writer.writelines(lines)
     return n_done
+
+
+def _ops():
+    from . import ops          # (loads libsatools_hip.so: only a job on a GPU gets here)
+    return ops
+
+
+class _TorchThreads:
+    """torch.set_num_threads(n) for the duration of a block (n = None: leave it)"""
+
+    def __init__(self, n):
+        self.n, self.prev = n, None
+
+    def __enter__(self):
+        if self.n is not None and torch.get_num_threads() != self.n:
+            self.prev = torch.get_num_threads()
+            torch.set_num_threads(self.n)
+        return self
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            torch.set_num_threads(self.prev)
+        return False
 
 
 class _null:

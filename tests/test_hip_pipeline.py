@@ -110,3 +110,34 @@ def test_convert_padded_is_the_batch_jobs_set_f0_then_convert(tmp_path):
     ref = model.convert(x, target=tg)
     got = model.convert_padded(x, lens, tg)
     assert torch.equal(got, ref)
+
+
+def test_pcm16_conversions_on_the_device_are_the_host_ones():
+    """sat_pcm16_to_f32 / sat_pcm16_from_f32 (the batch job keeps int16 on both sides of PCIe) against the numpy formulas of
+    pipeline.pcm16_of / torchaudio.load's normalisation: every int16 value, ties, clipping, odd lengths, unaligned views"""
+    from satools_amd import ops, pipeline as pl
+    from satools_amd._lib import SatError
+    every = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16)
+    f = ops.pcm16_to_f32(every.cuda())
+    assert torch.equal(f.cpu(), every.to(torch.float32) / 32768.0)
+    assert torch.equal(ops.pcm16_from_f32(f).cpu(), every)
+    g = torch.Generator().manual_seed(0)
+    for shape in ((1, 1), (3, 80001), (32, 1, 8001), (5, 1023), (2, 4097)):
+        x = (torch.rand(shape, generator=g) * 2.4 - 1.2)
+        x.view(-1)[::7] = (torch.randint(-40000, 40000, x.view(-1)[::7].shape, generator=g).float() + 0.5) / 32768.0        # ties and overflows
+        exp = pl.pcm16_of(x)
+        got = ops.pcm16_from_f32(x.cuda())
+        assert got.dtype == torch.int16 and got.shape == x.shape and np.array_equal(got.cpu().numpy(), exp), shape
+        back = ops.pcm16_to_f32(got)
+        assert torch.equal(back.cpu(), torch.from_numpy(exp.astype(np.float32) / 32768.0))
+    # views that start off the vector alignment take the scalar form
+    base = torch.rand(4099, generator=g).cuda() - 0.5
+    for off in (1, 2, 3):
+        v = base[off:]
+        assert np.array_equal(ops.pcm16_from_f32(v).cpu().numpy(), pl.pcm16_of(v.cpu()))
+        p16 = ops.pcm16_from_f32(base)[off:]
+        assert torch.equal(ops.pcm16_to_f32(p16).cpu(), p16.cpu().float() / 32768.0)
+    with pytest.raises(SatError):
+        ops.pcm16_to_f32(torch.zeros(4, dtype=torch.float32, device="cuda"))
+    with pytest.raises(SatError):
+        ops.pcm16_from_f32(torch.zeros(4, device="cuda"), out=torch.zeros(5, dtype=torch.int16, device="cuda"))

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.lib()
     header = open(os.path.join(ROOT, "include", "satools_hip.h")).read()
-    assert lib.sat_abi_version() == int(re.search(r"#define SAT_ABI_VERSION (\d+)", header).group(1)) == 5
+    assert lib.sat_abi_version() == int(re.search(r"#define SAT_ABI_VERSION (\d+)", header).group(1)) == 6
     declared = set(re.findall(r"\b(sat_[a-z0-9_]+)\s*\(", header))
     declared -= {"sat_status"}
     assert declared, "no declarations parsed"
@@ -401,3 +401,14 @@ def test_gpu_count_without_the_hip_runtime(monkeypatch):
     assert anonymize.parse_ngpu("[0, 3]") == ["0", "3"]
     import inspect
     assert "torch" not in inspect.getsource(anonymize.parse_ngpu) and "torch" not in inspect.getsource(anonymize.visible_gpu_count)
+
+
+def test_ragged_yaapt_length_dims_are_the_plans():
+    """f0.length_dims(P, n) — what a ragged batch sends per utterance — equals the length-dependent fields of a full make_plan(n)"""
+    from satools_amd import f0
+    for opts in ({"frame_length": 35.0, "frame_space": 20.0, "nccf_thresh1": 0.25, "tda_frame_length": 25.0}, {}, {"frame_lengtht": 30.0, "frame_space": 5.0}):
+        P = f0.make_plan(80000, dict(opts))
+        for n in list(range(600, 1400)) + list(range(47990, 48330)) + [16000, 16001, 79999, 80000, 560001]:
+            q = f0.make_plan(n, dict(opts))
+            assert f0.length_dims(P, n) == [q.n, q.L, q.nframes, q.tda_nframes], (opts, n)
+            assert (q.pad, q.frame_jump, q.frame_size, q.tda_len) == (P.pad, P.frame_jump, P.frame_size, P.tda_len)

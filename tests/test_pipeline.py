@@ -109,3 +109,64 @@ def test_non_riff_audio_gives_a_clear_error(tmp_path):
         import pytest
         with pytest.raises(IOError, match="flac -c -d -s"):
             P.load_wav_from_scp(str(f))
+
+
+def _riff(fmt_body, data, extra=b""):
+    import struct
+    chunks = b"fmt " + struct.pack("<I", len(fmt_body)) + fmt_body + extra + b"data" + struct.pack("<I", len(data)) + data
+    return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+
+def test_fast_pcm16_reader_and_writer_agree_with_the_general_ones(tmp_path):
+    """the batch job keeps 16-bit mono files as int16 up to the device and writes its RIFF files itself: the same samples as
+    `load_wav_from_scp` (scipy) x 32768, the same BYTES as scipy.io.wavfile.write; anything but plain 16-bit mono PCM is left to the
+    general reader"""
+    import struct
+    import numpy as np
+    from scipy.io import wavfile
+    rng = np.random.RandomState(0)
+    pcm = rng.randint(-32768, 32768, size=4001).astype(np.int16)
+    fmt16 = struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16)
+    plain = tmp_path / "plain.wav"
+    plain.write_bytes(_riff(fmt16, pcm.tobytes()))
+    got, sr = pl.read_pcm16_mono(str(plain))
+    ref, sr_ref = pl.load_wav_from_scp(str(plain))
+    assert sr == sr_ref == 16000 and got.dtype == np.int16 and np.array_equal(got, pcm)
+    assert torch.equal(torch.from_numpy(got.astype(np.float32) * np.float32(1 / 32768)).unsqueeze(0), ref)
+    # a LIST chunk in front of the samples, a fmt chunk with an extension field, an odd-sized chunk with its pad byte
+    listed = tmp_path / "listed.wav"
+    listed.write_bytes(_riff(fmt16 + b"\0\0", pcm.tobytes(), extra=b"LIST" + struct.pack("<I", 5) + b"abcde\0"))
+    got2, _ = pl.read_pcm16_mono(str(listed))
+    assert np.array_equal(got2, pcm) and torch.equal(pl.load_wav_from_scp(str(listed))[0], ref)
+    # not the plain case -> None (the general reader decodes or rejects them)
+    stereo = _riff(struct.pack("<HHIIHH", 1, 2, 16000, 64000, 4, 16), pcm[:4000].tobytes())
+    eight = _riff(struct.pack("<HHIIHH", 1, 1, 16000, 16000, 1, 8), bytes(100))
+    f32 = _riff(struct.pack("<HHIIHH", 3, 1, 16000, 64000, 4, 32), np.zeros(10, np.float32).tobytes())
+    ext = _riff(struct.pack("<HHIIHH", 0xFFFE, 1, 16000, 32000, 2, 16) + struct.pack("<HHI", 22, 16, 4) + b"\x01\0" + bytes(14), pcm.tobytes())
+    cut = _riff(fmt16, pcm.tobytes())[:-100]
+    for name, blob in (("stereo", stereo), ("eight", eight), ("f32", f32), ("ext", ext), ("cut", cut), ("short", b"RIFF1234WAVE"), ("flac", b"fLaC" + bytes(60))):
+        f = tmp_path / (name + ".wav")
+        f.write_bytes(blob)
+        assert pl.read_pcm16_mono(str(f)) is None, name
+    assert pl.load_wav_from_scp(str(tmp_path / "stereo.wav"))[0].shape == (2, 2000)
+    # collate: s / 32768 of the int16 batch is collate_fn's audio
+    items = [{"utid": f"u{i}", "pcm": pcm[:n], "audio": None, "f0": None, "freq": 16000} for i, n in enumerate((7, 4001, 90))]
+    a16, f0, lens, utids, freqs = pl.collate_pcm16(items)
+    for i in items:
+        i["audio"] = torch.from_numpy(i["pcm"].astype(np.float32) / 32768.0).unsqueeze(0)
+    a, _, lens_ref, utids_ref, freqs_ref = pl.collate_fn(items)
+    assert f0 is None and a16.dtype == np.int16 and torch.equal(torch.from_numpy(a16.astype(np.float32) * np.float32(1 / 32768)), a)
+    assert torch.equal(lens, lens_ref) and utids == utids_ref and freqs == freqs_ref
+    # the writer: scipy's bytes, one and two channels; save_pcm16 of f32 = of its int16 conversion; ties round to even, clipping
+    for shape in ((4001,), (1, 4001), (2, 300)):
+        x = rng.randint(-32768, 32768, size=shape).astype(np.int16)
+        mine, theirs = tmp_path / "mine.wav", tmp_path / "theirs.wav"
+        pl.write_riff_pcm16(mine, x, 22050)
+        wavfile.write(str(theirs), 22050, np.ascontiguousarray(x.T))
+        assert mine.read_bytes() == theirs.read_bytes(), shape
+    x = torch.tensor([[0.5 / 32768, 1.5 / 32768, 2.5 / 32768, -0.5 / 32768, -1.5 / 32768, 1.0, -1.0, 1.5, -1.5, 0.99999, 32766.5 / 32768, 0.1]])
+    assert pl.pcm16_of(x).tolist() == [[0, 2, 2, 0, -2, 32767, -32768, 32767, -32768, 32767, 32766, 3277]]
+    pl.save_pcm16(tmp_path / "a.wav", x, 16000)
+    pl.save_pcm16(tmp_path / "b.wav", torch.from_numpy(pl.pcm16_of(x)), 16000)
+    assert (tmp_path / "a.wav").read_bytes() == (tmp_path / "b.wav").read_bytes()
+    assert read_wav(tmp_path / "a.wav")[0].tolist() == pl.pcm16_of(x)[0].tolist()

@@ -44,13 +44,32 @@ with tempfile.TemporaryDirectory() as tmp:
     pl.process_data(data, "random_per_spk", pl.split_dict(warm, jobs), settings, model=model)       # weights, tables
     # every process_data call sets up its streams, workspaces and page-locked staging buffers (~0.5 s per job):
     # a cost of the job, amortised over its thousands of utterances, so use enough of them here
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = pl.process_data(data, "random_per_spk", pl.split_dict(wavscp, jobs), settings, model=model)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def timed(scp):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = pl.process_data(data, "random_per_spk", pl.split_dict(scp, jobs), settings, model=model)
+        torch.cuda.synchronize()
+        return n, time.perf_counter() - t0
+
+    # a quarter of the utterances first: the difference of the two runs is the steady state (a job's set-up — streams, their workspaces,
+    # page-locked buffers, the drain of the last batches — is paid once per process_data call)
+    n_q, dt_q = timed(dict(list(wavscp.items())[:max(batch * jobs, n_utts // 4 // batch * batch)]))
+    if os.environ.get("PROFILE") == "1":        # where the launching thread of the job spends its time
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        n, dt = timed(wavscp)
+        pr.disable()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+    else:
+        n, dt = timed(wavscp)
     secs = sum((80000 - (i * 997) % 32000) if ragged else 80000 for i in range(n_utts)) / 16000.0
     if ragged:
         print(f"ragged lengths (3-5 s): {secs:.0f} s of audio -> {secs / dt:.0f} x real-time")
     print(f"{n} utterances x 5 s, batch {batch}, {jobs} jobs on one GPU: {dt:.2f} s wall = {n * 5.0 / dt:.0f} x real-time "
           f"(files in -> PCM16 files out; {dt / (n / batch) * 1e3:.1f} ms per batch)")
+    if n > n_q:
+        per_batch = (dt - dt_q) / ((n - n_q) / batch)
+        print(f"  {n_q} utterances: {dt_q:.2f} s -> {per_batch * 1e3:.2f} ms per further batch = {batch * 5.0 / per_batch:.0f} x real-time in the steady state, "
+              f"{dt - per_batch * n / batch:.2f} s of set-up and drain per job call")
