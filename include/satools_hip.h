@@ -509,6 +509,10 @@ int sat_transpose_heads_f32(const float* v, float* vt, int G, int D, int T, int 
  *   sat_tanh_inplace_f32, sat_attentive_stats_f32   AttentiveStatsPool (sidekit/pooling.py:148-155): softmax over time
  *                            of `logits`, weighted mean and std of x -> out [B][2C]
  *   sat_l2norm_rows_f32      F.normalize(x, dim=1) (ecapa_tdnn.py:76)
+ *   sat_linear_rows_f32      nn.Linear on pooled vectors (ABI 6): y[b][o] = (relu?)(w[o] . x[b] + bias[o]) (* ch_scale[o] + ch_shift[o]) —
+ *                            SE_Connect.linear1 / linear2 (sidekit/nn.py:133-139), before_speaker_embedding lin + bn2 in eval
+ *                            (ecapa_tdnn.py:40-43, :77).  x [B][Cin], w [Cout][Cin] row-major as the checkpoint holds it, y [B][Cout];
+ *                            bias / ch_scale / ch_shift may be null.  f32 FMAs, lane-strided partial sums reduced across the wave
  * ------------------------------------------------------------------------------------------ */
 int sat_melspec_logmel_f32(const float* wav, float* out, const float* window, const float* fb, const int32_t* fb_lo,
                            const int32_t* fb_hi, int B, int n, int n_mel, float coef, void* stream);
@@ -521,6 +525,8 @@ int sat_se_gate_add_f32(const float* z, const float* gate_logits, const float* s
 int sat_tanh_inplace_f32(float* x, size_t n, void* stream);
 int sat_attentive_stats_f32(const float* x, const float* logits, float* out, int B, int C, int T, void* stream);
 int sat_l2norm_rows_f32(const float* x, float* y, int R, int D, void* stream);
+int sat_linear_rows_f32(const float* x, const float* w, const float* bias, const float* ch_scale, const float* ch_shift, int relu,
+                        float* y, int B, int Cin, int Cout, void* stream);
 
 #ifdef __cplusplus
 }

@@ -510,6 +510,27 @@ def l2norm_rows(x):
     return y
 
 
+def linear_rows(x, w, bias=None, ch_scale=None, ch_shift=None, relu=False):
+    """nn.Linear on pooled vectors: x [B, Cin] (or [B, Cin, 1]), w [Cout, Cin] -> [B, Cout] (or [B, Cout, 1]);
+    (relu?)(x w^T + bias) * ch_scale + ch_shift (sidekit/nn.py:133-139, ecapa_tdnn.py:40-43)"""
+    col = x.dim() == 3
+    if col and x.shape[2] != 1:
+        raise _lib.SatError("linear_rows: [B, Cin] or [B, Cin, 1]")
+    x2 = _f32c(x.reshape(x.shape[0], x.shape[1]))
+    w = _f32c(w)
+    B, cin = x2.shape
+    cout = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != cin or not x2.is_cuda:
+        raise _lib.SatError(f"linear_rows: w {tuple(w.shape)} does not fit x {tuple(x2.shape)} on the GPU")
+    for t in (bias, ch_scale, ch_shift):
+        if t is not None and (t.numel() != cout or t.dtype != torch.float32 or not t.is_contiguous()):
+            raise _lib.SatError("linear_rows: bias / ch_scale / ch_shift are contiguous f32 vectors of Cout values")
+    y = torch.empty(B, cout, dtype=torch.float32, device=x2.device)
+    check(lib().sat_linear_rows_f32(ptr(x2), ptr(w), ptr(bias), ptr(ch_scale), ptr(ch_shift), int(bool(relu)), ptr(y), B, cin, cout, stream()),
+          "sat_linear_rows_f32")
+    return y.unsqueeze(2) if col else y
+
+
 # ---- ASR half of the bottleneck net (SURVEY 8 f4) ------------------------------------------------------
 def tdnnf_unfold15(x):
     """x [B, D, T] -> (windows, bypass) [B, D, (2(T-1))//3 + 1] of a TDNNF layer with subsampling_factor 1.5"""

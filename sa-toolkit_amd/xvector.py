@@ -163,8 +163,8 @@ def build(args=None):
                     res2.append({"w": packing.pack_conv_weight(f32(conv.weight)), "scale": sc, "shift": sh})
                 W["blocks"].append({
                     "in": crb(lay[0]), "res2": res2, "out": crb(lay[2]),
-                    "se1_w": packing.pack_conv_weight(f32(lay[3].linear1.weight).unsqueeze(-1)), "se1_b": f32(lay[3].linear1.bias),
-                    "se2_w": packing.pack_conv_weight(f32(lay[3].linear2.weight).unsqueeze(-1)), "se2_b": f32(lay[3].linear2.bias)})
+                    "se1_w": f32(lay[3].linear1.weight), "se1_b": f32(lay[3].linear1.bias),
+                    "se2_w": f32(lay[3].linear2.weight), "se2_b": f32(lay[3].linear2.bias)})
             sn = self.sequence_network
             W["cat"] = {"w": pack1(f32(sn.conv.weight)), "b": f32(sn.conv.bias)}
             W["mode1"] = m1
@@ -172,7 +172,7 @@ def build(args=None):
             W["asp1"] = {"w": pack1(f32(sp.linear1.weight)), "b": f32(sp.linear1.bias)}
             W["asp2"] = {"w": pack1(f32(sp.linear2.weight)), "b": f32(sp.linear2.bias)}
             sc, sh = bn_affine(self.before_speaker_embedding.bn2)
-            W["emb"] = {"w": packing.pack_conv_weight(f32(self.before_speaker_embedding.lin.weight).unsqueeze(-1)), "scale": sc, "shift": sh}
+            W["emb"] = {"w": f32(self.before_speaker_embedding.lin.weight), "scale": sc, "shift": sh}
             W["window"] = f32(self.preprocessor.MelSpec.spectrogram.window)
             W["fb"] = f32(self.preprocessor.MelSpec.mel_scale.fb).t().contiguous()      # [80][513]
             W["coef"] = float(-self.preprocessor.PreEmphasis.flipped_filter.reshape(-1)[0])
@@ -205,8 +205,8 @@ def build(args=None):
             z_in[:, 7 * width:].copy_(y[:, 7 * width:])
             z = self._crb(z_in, blk["out"])
             m = ops.row_mean(z)                                                    # [B, C, 1]
-            g = ops.conv1d(m, blk["se1_w"], C // 2, 1, bias=blk["se1_b"], relu=True)
-            g = ops.conv1d(g, blk["se2_w"], C, 1, bias=blk["se2_b"])
+            g = ops.linear_rows(m, blk["se1_w"], bias=blk["se1_b"], relu=True)          # (the pooled frame: matrix-vector products)
+            g = ops.linear_rows(g, blk["se2_w"], bias=blk["se2_b"])
             return ops.se_gate_add(z, g, skips, out=out)
 
         def embed(self, feats):
@@ -221,7 +221,7 @@ def build(args=None):
             a = ops.tanh_(ops.conv1d(h, W["asp1"]["w"], 128, 1, bias=W["asp1"]["b"], mode=W["mode1"]))
             logits = ops.conv1d(a, W["asp2"]["w"], 3 * C, 1, bias=W["asp2"]["b"], mode=W["mode1"])
             pooled = ops.attentive_stats(h, logits)                                 # [B, 2 * 3C, 1]
-            e = ops.conv1d(pooled, W["emb"]["w"], self.embedding_size, 1, ch_scale=W["emb"]["scale"], ch_shift=W["emb"]["shift"])
+            e = ops.linear_rows(pooled, W["emb"]["w"], ch_scale=W["emb"]["scale"], ch_shift=W["emb"]["shift"])
             return ops.l2norm_rows(e.reshape(B, self.embedding_size))
 
         def forward(self, x, target=None):

@@ -86,3 +86,28 @@ def test_reference_checkpoint_format_loads(tmp_path, net):
     m = satools_amd.load_model(str(tmp_path / "final.pt")).to(DEV)
     wav = synthetic.harm_batch([0], 16000)[0].to(DEV)
     assert torch.equal(m(wav)[1], net(wav)[1])
+
+
+def test_linear_rows_is_the_linear_layer_on_pooled_vectors():
+    """sat_linear_rows_f32 (SE_Connect's two Linear layers, the embedding layer with its eval BatchNorm as an affine) against float64:
+    vector and scalar forms, batch groups with a ragged tail, every epilogue option"""
+    from satools_amd import ops
+    from satools_amd._lib import SatError
+    g = torch.Generator().manual_seed(3)
+    for B, cin, cout in ((1, 512, 256), (32, 256, 512), (37, 3072, 192), (9, 130, 7), (8, 4, 1)):
+        x = torch.randn(B, cin, generator=g)
+        w = torch.randn(cout, cin, generator=g) * cin ** -0.5
+        b, sc, sh = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        ref = x.double() @ w.double().t()
+        for kw, exp in (({}, ref), ({"bias": b}, ref + b.double()), ({"bias": b, "relu": True}, torch.relu(ref + b.double())),
+                        ({"ch_scale": sc, "ch_shift": sh}, ref * sc.double() + sh.double()),
+                        ({"bias": b, "relu": True, "ch_scale": sc}, torch.relu(ref + b.double()) * sc.double())):
+            dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+            got = ops.linear_rows(x.cuda(), w.cuda(), **dev)
+            assert got.shape == (B, cout) and float((got.cpu().double() - exp).abs().max()) < 2e-6 * max(1.0, float(exp.abs().max())), (B, cin, cout, list(kw))
+        col = ops.linear_rows(x.cuda().unsqueeze(2), w.cuda(), bias=b.cuda())
+        assert col.shape == (B, cout, 1) and torch.equal(col[:, :, 0], ops.linear_rows(x.cuda(), w.cuda(), bias=b.cuda()))
+    with pytest.raises(SatError):
+        ops.linear_rows(torch.zeros(2, 8, device="cuda"), torch.zeros(4, 9, device="cuda"))
+    with pytest.raises(SatError):
+        ops.linear_rows(torch.zeros(2, 8, device="cuda"), torch.zeros(4, 8, device="cuda"), ch_shift=torch.zeros(4, device="cuda"))
