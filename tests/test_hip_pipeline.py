@@ -141,3 +141,36 @@ def test_pcm16_conversions_on_the_device_are_the_host_ones():
         ops.pcm16_to_f32(torch.zeros(4, dtype=torch.float32, device="cuda"))
     with pytest.raises(SatError):
         ops.pcm16_from_f32(torch.zeros(4, device="cuda"), out=torch.zeros(5, dtype=torch.int16, device="cuda"))
+
+
+def test_int16_data_plane_writes_the_files_of_the_f32_one(tmp_path, monkeypatch):
+    """SATOOLS_AMD_PIPELINE_PCM16 = 3 (default: int16 from the file to the device and back, conversions by sat_pcm16_*) against 0 (f32 on
+    both sides of PCIe, scipy's parser and numpy's rounding on the host): the same bytes in every output file, ragged lengths, two jobs,
+    a stereo-free mix of plain files and one file only the general reader takes (a LIST chunk is fine for both; an 8-bit file is not
+    int16: its batch falls back to the f32 collate)"""
+    import struct
+    import satools_amd
+    from satools_amd import pipeline as pl
+    data = str(tmp_path / "data" / "toy")
+    _dataset(data, [16000, 12800, 9600, 16000, 14400, 11200, 16000])
+    # utt06 becomes an 8-bit PCM file (unsigned, 128 = zero): the general reader's case
+    from pipeline_toy import read_wav
+    pcm, _ = read_wav(os.path.join(data, "clear", "utt06.wav"))
+    u8 = (np.clip(pcm // 256, -128, 127) + 128).astype(np.uint8).tobytes()
+    fmt = struct.pack("<HHIIHH", 1, 1, 16000, 16000, 1, 8)
+    blob = b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(u8)) + u8
+    open(os.path.join(data, "clear", "utt06.wav"), "wb").write(b"RIFF" + struct.pack("<I", 4 + len(blob)) + b"WAVE" + blob)
+    model = satools_amd.load_model("synthetic:" + TAG)
+    model.to("cuda")
+    model.eval()
+    scp = pl.read_wav_scp(os.path.join(data, "wav.scp"))
+    out = {}
+    for mode in ("3", "0"):
+        monkeypatch.setenv("SATOOLS_AMD_PIPELINE_PCM16", mode)
+        settings = types.SimpleNamespace(model="-", f0_modification="", target_constant_spkid=model.spk[2], results_dir="wav", batch_size=3,
+                                         data_loader_nj=2, new_datadir_suffix="_anon" + mode, device="cuda")
+        assert pl.process_data(data, "constant", pl.split_dict(scp, 2), settings, model=model) == 7
+        out[mode] = {u: open(os.path.join(data + "_anon" + mode, "wav", u + ".wav"), "rb").read() for u in scp}
+    assert out["3"] == out["0"]
+    assert [len(v) for v in out["3"].values()] == [44 + 2 * n for n in (16000, 12800, 9600, 16000, 14400, 11200, 16000)]
+    assert torch.get_num_threads() >= 1
