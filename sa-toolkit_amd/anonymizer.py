@@ -105,11 +105,14 @@ def build(args):
             xd = self._to_device(wav.detach())
             return f0_hip.yaapt_ragged(xd, lengths, self.f0_yaapt_opts)
 
-        def convert_padded(self, x, lengths, target):
+        def convert_padded(self, x, lengths, target, defer_status=False):
             """convert() of a zero-padded batch whose F0 tracks are taken per utterance at its own length — the
             result of the reference's batch job (`set_f0` of the data loader's zero-padded per-utterance tracks,
             then `convert`; bin/pipeline.py:35-62, :107-149) — with the ragged YAAPT launch on the F0 side stream
-            next to the bottleneck extractor and its status checked after the generator is enqueued."""
+            next to the bottleneck extractor and its status checked after the generator is enqueued.
+            defer_status=True: returns (y, status) without waiting for YAAPT's status word; the caller runs `status.check()` before it
+            uses y (it raises what this call would have raised: the batch job does so in the thread that writes the files, so that the
+            launching thread never waits for the GPU)."""
             from . import f0 as f0_hip
             xd = self._to_device(x.detach())
             cur = torch.cuda.current_stream(xd.device)
@@ -127,6 +130,8 @@ def build(args):
             cur.wait_stream(side)
             f0.record_stream(cur)
             y = self._forward(f0, bn, self.get_spk_id(x, target)).squeeze(0)
+            if defer_status:
+                return y, st
             st.check()
             return y
 

@@ -10,6 +10,7 @@ the whole batch is processed in one call on the GPU."""
 import ctypes as C
 import functools
 import math
+import threading
 
 import numpy as np
 import torch
@@ -137,18 +138,65 @@ def _get_tables(P, device):
     return _tables[key]
 
 
-class F0Status:
-    """deferred error report of one yaapt launch (checked without stalling the launch stream)"""
+class _PinnedInts:
+    """rows of ONE page-locked int32 block for the words that travel with a yaapt launch (its status, the per-utterance dimensions of a
+    ragged batch).  A `tensor.pin_memory()` per call asks torch's host allocator for a block whose previous copy has completed; a
+    launching thread that runs ahead of the GPU (the batch job with deferred status) finds none and pays a hipHostMalloc per launch,
+    ~50 ms each at the start of a job (0.67 s for the first four batches)."""
+    ROWS, COLS = 64, 1024
 
-    def __init__(self, dev_status, B):
-        self.host = torch.empty(B, dtype=torch.int32).pin_memory()
+    def __init__(self):
+        self.buf, self.free, self.lock = None, list(range(self.ROWS)), threading.Lock()
+
+    def take(self, n):
+        """-> (pinned int32 view of n words, row to give back or None)"""
+        with self.lock:
+            if self.buf is None:
+                self.buf = torch.empty(self.ROWS, self.COLS, dtype=torch.int32, pin_memory=True)
+            row = self.free.pop() if (self.free and n <= self.COLS) else None
+        if row is None:
+            return torch.empty(n, dtype=torch.int32).pin_memory(), None
+        return self.buf[row, :n], row
+
+    def give(self, row):
+        if row is not None:
+            with self.lock:
+                self.free.append(row)
+
+
+_pinned_ints = _PinnedInts()
+
+
+class F0Status:
+    """deferred error report of one yaapt launch (checked without stalling the launch stream); `also` = rows of _pinned_ints that the
+    launch read (a ragged batch's dimensions), free once the status has arrived"""
+
+    def __init__(self, dev_status, B, also=()):
+        self.host, row = _pinned_ints.take(B)
+        self.rows = [row] + list(also)
         self.host.copy_(dev_status, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
 
+    def _release(self):
+        rows, self.rows = self.rows, []
+        for r in rows:
+            _pinned_ints.give(r)
+
+    def __del__(self):
+        try:
+            if self.rows:
+                self.event.synchronize()        # (never checked: the copies must have landed before the rows are reused)
+                self._release()
+        except Exception:
+            pass
+
     def check(self):
-        self.event.synchronize()
-        st = self.host
+        if self.host is not None:
+            self.event.synchronize()
+            self.words, self.host = self.host.clone(), None
+            self._release()
+        st = self.words
         if (st == 1).any():
             # the reference fails inside medfilt/unfold when no frame of an utterance is voiced
             raise RuntimeError("yaapt: no voiced frame in utterance(s) %s (the reference's spec_track fails on an "
@@ -192,10 +240,12 @@ def yaapt_ragged(wav, lengths, opts, defer_status=False):
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=wav.device)
     f0 = torch.empty(B, P.nframes, dtype=torch.float32, device=wav.device)
     status = torch.empty(B, dtype=torch.int32, device=wav.device)
-    ud = torch.tensor(dims, dtype=torch.int32).pin_memory().to(wav.device, non_blocking=True)
+    ud_host, ud_row = _pinned_ints.take(4 * B)
+    ud_host.copy_(torch.tensor(dims, dtype=torch.int32).reshape(-1))
+    ud = ud_host.to(wav.device, non_blocking=True).view(B, 4)
     check(lib().sat_yaapt_ragged_f32(C.byref(P), ptr(wav), ptr(ud), ptr(f0), ptr(status), ptr(hann), ptr(kaiser), ptr(tw),
                                      ptr(ws), ws_bytes, B, stream()), "sat_yaapt_ragged_f32")
-    st = F0Status(status, B)
+    st = F0Status(status, B, also=(ud_row,))
     if defer_status:
         return f0, st
     st.check()

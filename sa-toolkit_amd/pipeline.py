@@ -333,6 +333,7 @@ def _process_data(dataset_path, target_selection_algorithm, wavscps, settings, p
     depth = 2
 
     # (SATOOLS_AMD_PIPELINE_PCM16=0: f32 on both sides of PCIe, conversions on the host threads — the A/B switch of tools/bench_pipeline.py)
+    defer_f0_status = use_streams and os.environ.get("SATOOLS_AMD_PIPELINE_DEFER_STATUS", "1") != "0"
     _pcm_bits = int(os.environ.get("SATOOLS_AMD_PIPELINE_PCM16", "3"))
     keep_pcm16, out_pcm16 = bool(_pcm_bits & 1), bool(_pcm_bits & 2)
 
@@ -363,9 +364,11 @@ def _process_data(dataset_path, target_selection_algorithm, wavscps, settings, p
             buf = slot["buf"][(kind, dtype)] = torch.empty(like_numel, dtype=dtype, pin_memory=True)
         return buf[:like_numel]
 
-    def write_batch(wav_conv, done_event, utid, freq, original_len):
+    def write_batch(wav_conv, done_event, utid, freq, original_len, f0_status=None):
         if done_event is not None:
             done_event.synchronize()
+        if f0_status is not None:
+            f0_status.check()                       # what convert() raises for a batch YAAPT cannot track (deferred: see below)
         arr = wav_conv.detach().numpy()             # f32, or int16 already converted on the device (sat_pcm16_from_f32)
         for i in range(arr.shape[0]):
             wav = arr[i]
@@ -439,7 +442,14 @@ def _process_data(dataset_path, target_selection_algorithm, wavscps, settings, p
                     elif f0_mode not in ("per_utterance", "batch"):
                         raise ValueError(f"unknown f0_mode {f0_mode!r}")
                     _t3 = _time.perf_counter()
-                    wav_conv = model.convert_padded(x, original_len.tolist(), targets) if fused else model.convert(x, **kw)
+                    f0_status = None
+                    if fused and defer_f0_status:
+                        # the launching thread does not wait for YAAPT's status word of every batch (a round trip to the GPU that kept
+                        # two kernels in flight where bench.py's loop keeps four): the writer checks it before it writes the files, the
+                        # ring of staging slots is what bounds how far the launches run ahead
+                        wav_conv, f0_status = model.convert_padded(x, original_len.tolist(), targets, defer_status=True)
+                    else:
+                        wav_conv = model.convert_padded(x, original_len.tolist(), targets) if fused else model.convert(x, **kw)
                     t_convert += _time.perf_counter() - _t3
                     if use_streams:
                         # the samples the files hold are made on the device: half the bytes to copy back, nothing to round on the host
@@ -452,7 +462,7 @@ def _process_data(dataset_path, target_selection_algorithm, wavscps, settings, p
                     else:
                         host, ev = wav_conv.cpu(), None
                 t_launch += _time.perf_counter() - _t1
-                fut = writers.submit(write_batch, host, ev, utid, freq[0], original_len)
+                fut = writers.submit(write_batch, host, ev, utid, freq[0], original_len, f0_status)
                 if slot is not None:
                     slot["busy"] = fut
                 pending_writes.append(fut)

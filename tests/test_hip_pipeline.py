@@ -174,3 +174,34 @@ def test_int16_data_plane_writes_the_files_of_the_f32_one(tmp_path, monkeypatch)
     assert out["3"] == out["0"]
     assert [len(v) for v in out["3"].values()] == [44 + 2 * n for n in (16000, 12800, 9600, 16000, 14400, 11200, 16000)]
     assert torch.get_num_threads() >= 1
+
+
+def test_an_untrackable_batch_fails_the_job_with_deferred_status(tmp_path):
+    """the batch job does not wait for YAAPT's status word in its launching thread (the writer checks it): a batch with an utterance
+    that has no voiced frame still fails the job with the error convert() raises — the reference's job dies inside spec_track"""
+    import satools_amd
+    from satools_amd import pipeline as pl
+    from pipeline_toy import write_wav
+    data = str(tmp_path / "data" / "toy")
+    _dataset(data, [16000] * 6)
+    write_wav(os.path.join(data, "clear", "utt04.wav"), np.zeros(16000))
+    model = satools_amd.load_model("synthetic:" + TAG)
+    model.to("cuda")
+    model.eval()
+    settings = types.SimpleNamespace(model="-", f0_modification="", target_constant_spkid=model.spk[0], results_dir="wav", batch_size=2,
+                                     data_loader_nj=2, new_datadir_suffix="_anon", device="cuda")
+    scp = pl.read_wav_scp(os.path.join(data, "wav.scp"))
+    with pytest.raises(RuntimeError, match="no voiced frame"):
+        pl.process_data(data, "constant", scp, settings, model=model)
+    x = torch.cat([pl.load_wav_from_scp(scp[u])[0] for u in ("utt04", "utt05")]).to("cuda")
+    with pytest.raises(RuntimeError, match="no voiced frame"):
+        model.convert(x, target=[model.spk[0]] * 2)
+    # the rows of the page-locked status block all come back (checked, or dropped with their launch)
+    from satools_amd import f0
+    import gc
+    gc.collect()
+    assert len(f0._pinned_ints.free) == f0._PinnedInts.ROWS
+    y, st = model.convert_padded(x[1:], [16000], [model.spk[0]], defer_status=True)
+    st.check()
+    st.check()
+    assert torch.equal(y, model.convert_padded(x[1:], [16000], [model.spk[0]]))
