@@ -35,6 +35,6 @@ def threaded(jobs, steps):
     run(steps // jobs)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / (steps // jobs * jobs) * 1e3
-for rnd in range(2):
-    for jobs in (4, 6, 8):
-        print(f"jobs {jobs}: one thread {single(jobs, 48):6.2f} ms per step   a thread per job {threaded(jobs, 48):6.2f} ms per step", flush=True)
+for rnd in range(3):
+    for jobs in (4, 6):
+        print(f"jobs {jobs}: one thread {single(jobs, 240):6.2f} ms per step   a thread per job {threaded(jobs, 240):6.2f} ms per step", flush=True)
