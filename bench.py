@@ -215,10 +215,15 @@ def load(tag, f0_transformation, dev):
     return m
 
 
-def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each, repeats=1):
+def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each, repeats=1, status="sync"):
     """N = 1 mode: K independent convert() batches, `jobs` deep in flight on separate HIP streams (the reference's
     jobs_per_compute_device, satools/satools/bin/anonymize:85-93), timed `repeats` times back to back (each window = exactly K steps
-    between two device synchronisations).  Returns (list of window seconds, setup_steps)."""
+    between two device synchronisations).  Returns (list of window seconds, setup_steps).
+    status "sync" (default): the plain convert() call — YAAPT's status word of the batch (the error path: an utterance without a voiced
+    frame) is waited for inside every call; "deferred": convert(..., defer_status=True), the word checked before the same job launches its
+    NEXT batch and at the end of the window, as the batch job does (pipeline.process_data).  Measured level in this loop (8.91 / 8.93 /
+    8.94 against 8.93 / 8.96 / 8.96 ms per step, interleaved on one box): what a 40-step window loses against the job's steady state is
+    its fill and drain, not the round trip."""
     import torch
     from satools_amd import synthetic
     seeds = [rank * BATCH + i for i in range(BATCH)]
@@ -230,28 +235,44 @@ def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each, repeats=1
     setup_steps = max(0, jobs - warmup)
     n = [0]
 
+    pending = [None] * jobs
+
     def step():
-        s = streams[n[0] % jobs]
+        j = n[0] % jobs
         n[0] += 1
         if seed_before_each:
             torch.manual_seed(1234)          # the awgn draw of every batch is reproducible
-        with torch.cuda.stream(s):
-            return model.convert(wav, target=targets)
+        if pending[j] is not None:
+            pending[j].check()
+            pending[j] = None
+        with torch.cuda.stream(streams[j]):
+            if status == "sync":
+                return model.convert(wav, target=targets)
+            y, pending[j] = model.convert(wav, target=targets, defer_status=True)
+            return y
+
+    def drain():
+        for j in range(jobs):
+            if pending[j] is not None:
+                pending[j].check()
+                pending[j] = None
 
     for _ in range(setup_steps + warmup):
         step()
+    drain()
     windows = []
     for _ in range(max(1, repeats)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        drain()                              # every status of the window is checked inside it
         torch.cuda.synchronize()
         windows.append(time.perf_counter() - t0)
     return windows, setup_steps
 
 
-def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, gather="f32", repeats=1, chunk_batches=4):
+def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, gather="f32", repeats=1, chunk_batches=4, status="sync"):
     """N > 1 mode (and SAT_BENCH_FORCE_PG=1 with one rank): world x steps x 32 utterances sharded through
     satools_amd.dist.convert_sharded, all inside the timed region.  The exchange of the anonymized waveforms is issued in chunks of
     `chunk_batches` batches on a communication stream while the rest of the shard is computed (dist.ChunkedGather: the bytes of the
@@ -275,14 +296,22 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
     cur = torch.cuda.current_stream(dev)
     n = [0]
     produced = {}           # first utterance of a batch -> event behind its last kernel
+    pending = [None] * jobs  # status "deferred" (run_steps): YAAPT's status word of a job's batch, checked before its next batch and before the shard is joined
 
     def convert_fn(a, b):
         s = streams[n[0] % jobs]
         n[0] += 1
         if seed_before_each:
             torch.manual_seed(1234)
+        j = (n[0] - 1) % jobs
+        if pending[j] is not None:
+            pending[j].check()
+            pending[j] = None
         with torch.cuda.stream(s):
-            y = model.convert(wav[a - lo:b - lo], target=targets[a - lo:b - lo])
+            if status == "sync":
+                y = model.convert(wav[a - lo:b - lo], target=targets[a - lo:b - lo])
+            else:
+                y, pending[j] = model.convert(wav[a - lo:b - lo], target=targets[a - lo:b - lo], defer_status=True)
             local[a - lo:b - lo].copy_(y.reshape(b - a, 1, -1))
             e = torch.cuda.Event()
             e.record(s)
@@ -296,6 +325,10 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
         return torch.cuda.stream(comm)
 
     def join_streams():
+        for j in range(jobs):
+            if pending[j] is not None:
+                pending[j].check()
+                pending[j] = None
         for s in streams:
             cur.wait_stream(s)
         ev[1].record(cur)           # this rank's compute is done
@@ -304,6 +337,10 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for i in range(setup_steps + warmup):
         convert_fn(lo + (i % steps) * BATCH, lo + (i % steps) * BATCH + BATCH)
+    for j in range(jobs):
+        if pending[j] is not None:
+            pending[j].check()
+            pending[j] = None
     for s in streams:
         cur.wait_stream(s)
     transform = sdist.pcm16_rows if gather == "pcm16" else None
@@ -545,7 +582,7 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
     seed_each = "awgn" in f0_tr
     extra = {}
     if use_pg:
-        r = run_sharded(model, dev, rank, world, steps, warmup, a.jobs, seed_each, a.gather, repeats, a.gather_chunk)
+        r = run_sharded(model, dev, rank, world, steps, warmup, a.jobs, seed_each, a.gather, repeats, a.gather_chunk, status=a.f0_status)
         windows, setup = r["windows"], r["setup_steps"]
         gb = 2 if a.gather == "pcm16" else 4
         mid = sorted(range(len(windows)), key=lambda i: windows[i])[len(windows) // 2]
@@ -560,7 +597,7 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
                                + ("issued on a communication stream as the batches complete, inside the timed region; all_gather_ms = what is left "
                                   "exposed behind the slowest rank's last batch" if r["chunk_batches"] else "at the end, inside the timed region")}
     else:
-        windows, setup = run_steps(model, dev, rank, steps, warmup, a.jobs, seed_each, repeats)
+        windows, setup = run_steps(model, dev, rank, steps, warmup, a.jobs, seed_each, repeats, status=a.f0_status)
     if rank != 0:
         return None
     w2 = tag == TAG_W2V2
@@ -578,6 +615,9 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
                                        f"batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
                            "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
                            "f0": "YAAPT computed on-path on the GPU inside convert()", "jobs_per_gpu": a.jobs,
+                           "f0_status": ("YAAPT's status word of a batch (convert()'s error path) is checked before the same job launches its next batch "
+                                         "and at the end of every timed window: convert(..., defer_status=True), as the batch job does"
+                                         if a.f0_status == "deferred" else "checked inside every convert() call (a host round trip to the GPU per step)"),
                            "setup_steps": setup, "generator_precision": model.hifigan.precision,
                            "reference_default_tag": f"{TAG_W2V2} (hubconf.py:69): its lines are configs[2] / configs[3] / configs[4] of this same run; "
                                                     f"the headline is BASELINE.json's configs[1], the tag the metric is quoted on",
@@ -656,6 +696,9 @@ def main():
     ap.add_argument("--gather-chunk", type=int, default=4,
                     help="sharded mode: the waveform exchange is issued in chunks of this many batches on a communication stream while "
                          "the shard is still being computed (0 = one all_gather_into_tensor at the end)")
+    ap.add_argument("--f0-status", choices=("sync", "deferred"), default="sync",
+                    help="when YAAPT's status word of a batch is checked: inside every convert() call (default: the plain call) or before the "
+                         "same job's next batch (convert(..., defer_status=True), what the batch job does)")
     ap.add_argument("--gen-precision", default=None,
                     help="generator arithmetic of every line (default: the package default, SATOOLS_AMD_GEN_PRECISION); when that is "
                          "f16f8r the headline tag is also measured as f16x3 and kept in `configs`")

@@ -266,15 +266,20 @@ def build(args):
             spk_id = self.get_spk_id(x, target)
             return (f0, bn, spk_id)
 
-        def convert(self, x, target):
+        def convert(self, x, target, defer_status=False):
+            """hifigan.py:58-71.  defer_status=True (not in the reference): returns (y, status) without waiting for YAAPT's status word —
+            `status.check()` raises what this call would have raised (None when the F0 came from `set_f0`); a caller that keeps several
+            batches in flight checks a batch's status before it uses y instead of making a round trip to the GPU per call"""
             self._defer_f0_status, self._f0_status = True, None
             try:
                 (f0, bn, spk_id) = self.extract_features(x, target)
             finally:
                 self._defer_f0_status = False
             y = self._forward(f0, bn, spk_id).squeeze(0)
-            if self._f0_status is not None:
-                st, self._f0_status = self._f0_status, None
+            st, self._f0_status = self._f0_status, None
+            if defer_status:
+                return y, st
+            if st is not None:
                 st.check()
             return y
 
