@@ -509,6 +509,11 @@ int sat_transpose_heads_f32(const float* v, float* vt, int G, int D, int T, int 
  *   sat_tanh_inplace_f32, sat_attentive_stats_f32   AttentiveStatsPool (sidekit/pooling.py:148-155): softmax over time
  *                            of `logits`, weighted mean and std of x -> out [B][2C]
  *   sat_l2norm_rows_f32      F.normalize(x, dim=1) (ecapa_tdnn.py:76)
+ *   sat_res2_chain_f32       Res2Conv1dReluBn (sidekit/nn.py:74-110; ABI 6) on pieces of 64 channels in ONE launch: piece i of z =
+ *                            bn_i(relu(conv_i(piece i of y + piece i - 1 of z))) for i < nums (three taps, `dilation`, zero padding, no bias;
+ *                            the BatchNorm in eval as scale / shift [nums][64]), the last piece copied.  y, z [B][(nums + 1) 64][T], y != z;
+ *                            w [nums][3 taps][64 ci][64 co] (Conv1d.weight permuted (2, 1, 0)); dilation <= 4, dilation * nums <= 32.
+ *                            Exact f32 on the f32 MFMA
  *   sat_linear_rows_f32      nn.Linear on pooled vectors (ABI 6): y[b][o] = (relu?)(w[o] . x[b] + bias[o]) (* ch_scale[o] + ch_shift[o]) —
  *                            SE_Connect.linear1 / linear2 (sidekit/nn.py:133-139), before_speaker_embedding lin + bn2 in eval
  *                            (ecapa_tdnn.py:40-43, :77).  x [B][Cin], w [Cout][Cin] row-major as the checkpoint holds it, y [B][Cout];
@@ -525,6 +530,8 @@ int sat_se_gate_add_f32(const float* z, const float* gate_logits, const float* s
 int sat_tanh_inplace_f32(float* x, size_t n, void* stream);
 int sat_attentive_stats_f32(const float* x, const float* logits, float* out, int B, int C, int T, void* stream);
 int sat_l2norm_rows_f32(const float* x, float* y, int R, int D, void* stream);
+int sat_res2_chain_f32(const float* y, float* z, const float* w, const float* scale, const float* shift, int B, int C, int T, int nums,
+                       int dilation, void* stream);
 int sat_linear_rows_f32(const float* x, const float* w, const float* bias, const float* ch_scale, const float* ch_shift, int relu,
                         float* y, int B, int Cin, int Cout, void* stream);
 

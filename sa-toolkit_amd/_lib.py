@@ -141,6 +141,7 @@ _PROTOS = {
     "sat_softmax_columns_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "sat_transpose_heads_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]),
+    "sat_res2_chain_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sat_linear_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]),
     "sat_pcm16_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),

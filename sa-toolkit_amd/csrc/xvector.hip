@@ -262,6 +262,133 @@ __global__ void __launch_bounds__(256) linear_rows_kernel(const float* __restric
   }
 }
 
+// ---- Res2Conv1dReluBn (sidekit/nn.py:74-110) of 64-channel pieces as ONE launch: sp_i = bn_i(relu(conv_i(sp_{i-1} + x_i))), i = 0 .. nums - 1,
+// the last piece copied.  Launched conv by conv the chain is 7 x (add3 + a 64 -> 64 three-tap conv of 31 us, latency-bound) per block of the
+// net.  Here a block keeps a window of W = 64 NT columns of ONE utterance in LDS — the piece's input (x_i + previous output) and its output,
+// 32 columns of halo on either side (the receptive field of the chain grows by one dilation per piece: 7 x 4 <= 32) — and walks the pieces:
+// exact f32 on v_mfma_f32_32x32x2_f32 (A = the piece's weights [tap][ci][co] staged in LDS, B = input columns shifted by the tap), four waves =
+// two 32-row tiles x two halves of the window.  Only the W - 64 centre columns are stored; fringe columns compute on zeros and are dropped.
+constexpr int R2_MARG = 4, R2_HALO = 32;
+typedef float r2_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NT>
+__global__ void __launch_bounds__(256) res2_chain_kernel(const float* __restrict__ y, float* __restrict__ z, const float* __restrict__ w,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, int C, int T, int nums,
+                                                         int dil) {
+  extern __shared__ __attribute__((aligned(16))) float r2_lds[];
+  constexpr int W = 64 * NT, WP = W + 2 * R2_MARG, TT = W - 2 * R2_HALO;
+  float* bufA = r2_lds;                   // [64][WP] input of the current piece
+  float* bufB = bufA + 64 * WP;           // [64][WP] its output (zero outside the utterance)
+  float* wl = bufB + 64 * WP;             // [3][64][64] weights of the current piece
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT, t_lo = t0 - R2_HALO;
+  const float* yb = y + (size_t)b * C * T;
+  float* zb = z + (size_t)b * C * T;
+  const int mt = wave >> 1, n0 = (wave & 1) * NT;      // this wave: rows 32 mt .., column tiles n0 .. n0 + NT - 1
+
+  for (int i = tid; i < 64 * 2 * R2_MARG; i += 256) {  // the margins the shifted fragment reads touch: zero, never written again
+    const int c = i / (2 * R2_MARG), m = i % (2 * R2_MARG);
+    const int col = m < R2_MARG ? m : W + m;
+    bufA[c * WP + col] = 0.f;
+  }
+  {
+    float y0[64 * W / 256];
+#pragma unroll
+    for (int k = 0; k < 64 * W / 256; ++k) {
+      const int i = tid + 256 * k, c = i / W, j = i - c * W, t = t_lo + j;
+      y0[k] = (t >= 0 && t < T) ? yb[(size_t)c * T + t] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 64 * W / 256; ++k) {
+      const int i = tid + 256 * k, c = i / W, j = i - c * W;
+      bufA[c * WP + R2_MARG + j] = y0[k];
+    }
+  }
+  constexpr int NIN = 64 * W / 256;                    // input elements per thread
+  for (int p = 0; p < nums; ++p) {
+    // (every global load of the piece is in flight before anything waits for one: a block is one wave per SIMD, nothing else hides them.
+    // Requesting the weights one piece ahead, to wait in registers behind the MFMAs: 135 us against 116, not kept)
+    float4 wv[12];
+    const float4* w4 = (const float4*)(w + (size_t)p * 3 * 64 * 64);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) wv[k] = w4[tid + 256 * k];
+    float yn[NIN];                                     // piece p + 1 of y, added to this piece's output below
+    const bool more = p + 1 < nums;
+    {
+      const float* yp = yb + (size_t)(p + 1) * 64 * T;
+#pragma unroll
+      for (int k = 0; k < NIN; ++k) {
+        const int i = tid + 256 * k, c = i / W, j = i - c * W, t = t_lo + j;
+        yn[k] = (more && t >= 0 && t < T) ? yp[(size_t)c * T + t] : 0.f;
+      }
+    }
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      sc[r] = scale[p * 64 + co], sh[r] = shift[p * 64 + co];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) ((float4*)wl)[tid + 256 * k] = wv[k];
+    __syncthreads();
+    r2_f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    // 96 steps (tap, channel pair), four at a time: their fragment reads are issued together, so that one LDS round trip stands in front
+    // of 4 NT MFMAs instead of NT
+    const float* xa = bufA + R2_MARG + 32 * n0 + l31 + lh * WP;
+    const float* wa = wl + 32 * mt + l31 + lh * 64;
+    for (int tap = 0; tap < 3; ++tap) {
+      const float* xt = xa + (tap - 1) * dil;
+      const float* wt = wa + tap * 64 * 64;
+#pragma unroll 2
+      for (int ci = 0; ci < 64; ci += 8) {
+        float a4[4], b4[4][NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a4[u] = wt[(ci + 2 * u) * 64];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b4[u][n] = xt[(ci + 2 * u) * WP + 32 * n];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], b4[u][n], acc[n], 0, 0, 0);
+      }
+    }
+    // relu, BatchNorm affine; the centre columns to memory, every column (zero outside the utterance) to bufB for the next piece
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int j = 32 * (n0 + n) + l31, t = t_lo + j;
+      const bool inside = t >= 0 && t < T, keep = inside && j >= R2_HALO && j < R2_HALO + TT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = fmaxf(acc[n][r], 0.f) * sc[r] + sh[r];
+        bufB[co * WP + R2_MARG + j] = inside ? v : 0.f;
+        if (keep) zb[(size_t)(p * 64 + co) * T + t] = v;
+      }
+    }
+    __syncthreads();
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < NIN; ++k) {
+        const int i = tid + 256 * k, c = i / W, j = i - c * W;
+        bufA[c * WP + R2_MARG + j] = yn[k] + bufB[c * WP + R2_MARG + j];
+      }
+    }
+  }
+  // the piece the chain leaves untouched
+  const float* yl = yb + (size_t)nums * 64 * T;
+  float* zl = zb + (size_t)nums * 64 * T;
+  for (int i = tid; i < 64 * TT; i += 256) {
+    const int c = i / TT, t = t0 + (i - c * TT);
+    if (t < T) zl[(size_t)c * T + t] = yl[(size_t)c * T + t];
+  }
+}
+
 }  // namespace sat
 
 using namespace sat;
@@ -344,5 +471,37 @@ extern "C" int sat_linear_rows_f32(const float* x, const float* w, const float* 
   if (vec) hipLaunchKernelGGL((linear_rows_kernel<NB, true>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, ch_scale, ch_shift, y, B, Cin, Cout, relu);
   else hipLaunchKernelGGL((linear_rows_kernel<NB, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, ch_scale, ch_shift, y, B, Cin, Cout, relu);
   SAT_LAUNCH_CHECK("linear_rows_kernel");
+  return SAT_OK;
+}
+
+extern "C" int sat_res2_chain_f32(const float* y, float* z, const float* w, const float* scale, const float* shift, int B, int C, int T,
+                                  int nums, int dilation, void* stream) {
+  SAT_REQUIRE(y && z && y != z && w && scale && shift && B > 0 && T > 0 && B < 65536, "res2_chain: bad arguments");
+  SAT_REQUIRE(nums >= 1 && C == (nums + 1) * 64, "res2_chain: pieces of 64 channels, C = (nums + 1) * 64");
+  SAT_REQUIRE(dilation >= 1 && dilation <= R2_MARG && dilation * nums <= R2_HALO, "res2_chain: dilation x pieces exceeds the staged halo");
+  // 128-column centres when that fills the CUs, else 64
+  const bool wide = (long long)B * ceil_div(T, 128) >= 256;
+  if (wide) {
+    constexpr int NT = 3;
+    const size_t lds = ((size_t)2 * 64 * (64 * NT + 2 * R2_MARG) + 3 * 64 * 64) * sizeof(float);
+    static std::atomic<uint64_t> attr_done{0};      // per device
+    int dev;
+    if (attr_needed_on_current_device(attr_done, &dev)) {
+      SAT_HIP(hipFuncSetAttribute((const void*)res2_chain_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done_on_device(attr_done, dev);
+    }
+    hipLaunchKernelGGL(res2_chain_kernel<NT>, dim3(ceil_div(T, 64 * NT - 2 * R2_HALO), B), dim3(256), lds, (hipStream_t)stream, y, z, w, scale, shift, C, T, nums, dilation);
+  } else {
+    constexpr int NT = 2;
+    const size_t lds = ((size_t)2 * 64 * (64 * NT + 2 * R2_MARG) + 3 * 64 * 64) * sizeof(float);
+    static std::atomic<uint64_t> attr_done{0};      // per device
+    int dev;
+    if (attr_needed_on_current_device(attr_done, &dev)) {
+      SAT_HIP(hipFuncSetAttribute((const void*)res2_chain_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done_on_device(attr_done, dev);
+    }
+    hipLaunchKernelGGL(res2_chain_kernel<NT>, dim3(ceil_div(T, 64 * NT - 2 * R2_HALO), B), dim3(256), lds, (hipStream_t)stream, y, z, w, scale, shift, C, T, nums, dilation);
+  }
+  SAT_LAUNCH_CHECK("res2_chain_kernel");
   return SAT_OK;
 }

@@ -510,6 +510,22 @@ def l2norm_rows(x):
     return y
 
 
+def res2_chain(y, w, scale, shift, dilation, out=None):
+    """Res2Conv1dReluBn on 64-channel pieces in one launch (sidekit/nn.py:74-110): y [B, (nums + 1) * 64, T], w [nums, 3, 64, 64]
+    (Conv1d.weight permuted (2, 1, 0) per piece), scale / shift [nums, 64] (the BatchNorm in eval) -> z like y"""
+    y = _f32c(y)
+    B, C, T = y.shape
+    nums = w.shape[0]
+    if tuple(w.shape) != (nums, 3, 64, 64) or tuple(scale.shape) != (nums, 64) or tuple(shift.shape) != (nums, 64) or C != (nums + 1) * 64:
+        raise _lib.SatError(f"res2_chain: w {tuple(w.shape)} / scale {tuple(scale.shape)} do not fit y {tuple(y.shape)}")
+    z = torch.empty_like(y) if out is None else out
+    if z.shape != y.shape or not z.is_contiguous() or z.data_ptr() == y.data_ptr():
+        raise _lib.SatError("res2_chain: `out` must be a contiguous tensor of y's shape, not y itself")
+    check(lib().sat_res2_chain_f32(ptr(y), ptr(z), ptr(_f32c(w)), ptr(_f32c(scale)), ptr(_f32c(shift)), B, C, T, nums, int(dilation), stream()),
+          "sat_res2_chain_f32")
+    return z
+
+
 def linear_rows(x, w, bias=None, ch_scale=None, ch_shift=None, relu=False):
     """nn.Linear on pooled vectors: x [B, Cin] (or [B, Cin, 1]), w [Cout, Cin] -> [B, Cout] (or [B, Cout, 1]);
     (relu?)(x w^T + bias) * ch_scale + ch_shift (sidekit/nn.py:133-139, ecapa_tdnn.py:40-43)"""

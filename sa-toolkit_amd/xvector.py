@@ -113,6 +113,8 @@ def build(args=None):
     class Net(nn.Module):
         #: arithmetic of the wide 1x1 convs: "f16x3" (split-f16 on the f16 matrix cores) or "f32" (exact f32 MFMA)
         precision = os.environ.get("SATOOLS_AMD_XVECTOR_PRECISION", "f16x3")
+        #: the Res2Net chain of a block as one launch (ops.res2_chain) instead of conv by conv
+        res2_chain = os.environ.get("SATOOLS_AMD_XVECTOR_RES2_CHAIN", "1") != "0"
 
         def __init__(self, num_speakers=1):
             super().__init__()
@@ -161,8 +163,14 @@ def build(args=None):
                 for conv, bn in zip(lay[1].convs, lay[1].bns):
                     sc, sh = bn_affine(bn)
                     res2.append({"w": packing.pack_conv_weight(f32(conv.weight)), "scale": sc, "shift": sh})
+                chain = None
+                if all(tuple(c.weight.shape) == (64, 64, 3) and c.bias is None for c in lay[1].convs):
+                    # the whole Res2Conv1dReluBn in one launch (ops.res2_chain): weights [piece][tap][ci][co], the BatchNorms as affines
+                    aff = [bn_affine(bn) for bn in lay[1].bns]
+                    chain = {"w": torch.stack([f32(c.weight).permute(2, 1, 0) for c in lay[1].convs]).contiguous(),
+                             "scale": torch.stack([a[0] for a in aff]).contiguous(), "shift": torch.stack([a[1] for a in aff]).contiguous()}
                 W["blocks"].append({
-                    "in": crb(lay[0]), "res2": res2, "out": crb(lay[2]),
+                    "in": crb(lay[0]), "res2": res2, "chain": chain, "out": crb(lay[2]),
                     "se1_w": f32(lay[3].linear1.weight), "se1_b": f32(lay[3].linear1.bias),
                     "se2_w": f32(lay[3].linear2.weight), "se2_b": f32(lay[3].linear2.bias)})
             sn = self.sequence_network
@@ -195,14 +203,17 @@ def build(args=None):
             y = self._crb(x, blk["in"])
             B, C, T = y.shape
             width = C // 8
-            z_in = torch.empty_like(y)
-            prev = None
-            for i, e in enumerate(blk["res2"]):
-                piece = y[:, i * width:(i + 1) * width]
-                inp = piece if i == 0 else ops.add3(prev, piece)
-                prev = ops.conv1d(inp, e["w"], width, 3, pad_left=dil, dilation=dil, ch_scale=e["scale"], ch_shift=e["shift"],
-                                  relu=True, relu_first=True, out=z_in[:, i * width:(i + 1) * width])
-            z_in[:, 7 * width:].copy_(y[:, 7 * width:])
+            if blk["chain"] is not None and self.res2_chain and dil * len(blk["res2"]) <= 32 and dil <= 4:
+                z_in = ops.res2_chain(y, blk["chain"]["w"], blk["chain"]["scale"], blk["chain"]["shift"], dil)
+            else:
+                z_in = torch.empty_like(y)
+                prev = None
+                for i, e in enumerate(blk["res2"]):
+                    piece = y[:, i * width:(i + 1) * width]
+                    inp = piece if i == 0 else ops.add3(prev, piece)
+                    prev = ops.conv1d(inp, e["w"], width, 3, pad_left=dil, dilation=dil, ch_scale=e["scale"], ch_shift=e["shift"],
+                                      relu=True, relu_first=True, out=z_in[:, i * width:(i + 1) * width])
+                z_in[:, 7 * width:].copy_(y[:, 7 * width:])
             z = self._crb(z_in, blk["out"])
             m = ops.row_mean(z)                                                    # [B, C, 1]
             g = ops.linear_rows(m, blk["se1_w"], bias=blk["se1_b"], relu=True)          # (the pooled frame: matrix-vector products)

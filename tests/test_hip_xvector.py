@@ -111,3 +111,45 @@ def test_linear_rows_is_the_linear_layer_on_pooled_vectors():
         ops.linear_rows(torch.zeros(2, 8, device="cuda"), torch.zeros(4, 9, device="cuda"))
     with pytest.raises(SatError):
         ops.linear_rows(torch.zeros(2, 8, device="cuda"), torch.zeros(4, 8, device="cuda"), ch_shift=torch.zeros(4, device="cuda"))
+
+
+def test_res2_chain_is_the_chain_of_convs():
+    """sat_res2_chain_f32 (Res2Conv1dReluBn of 64-channel pieces in one launch) against the module's arithmetic in float64 — lengths around
+    the window edges (64- and 128-column centres), utterances shorter than a window, every dilation the staged halo allows — and the net's
+    embedding with and without it"""
+    from satools_amd import ops
+    from satools_amd._lib import SatError
+    g = torch.Generator().manual_seed(5)
+    for B, T, nums, dil in ((2, 500, 7, 2), (3, 64, 7, 4), (1, 65, 7, 3), (2, 129, 7, 4), (1, 7, 7, 4), (33, 260, 3, 1), (64, 1030, 7, 4)):
+        C = (nums + 1) * 64
+        y = torch.randn(B, C, T, generator=g)
+        w = torch.randn(nums, 64, 64, 3, generator=g) * (64 * 3) ** -0.5          # Conv1d.weight layout per piece: [co][ci][tap]
+        sc, sh = torch.rand(nums, 64, generator=g) + 0.5, torch.randn(nums, 64, generator=g) * 0.1
+        ref, sp = [], None
+        for i in range(nums):
+            xin = y[:, 64 * i:64 * (i + 1)].double() + (sp if sp is not None else 0)
+            sp = F.conv1d(xin, w[i].double(), padding=dil, dilation=dil)
+            sp = torch.relu(sp) * sc[i].double().view(1, -1, 1) + sh[i].double().view(1, -1, 1)
+            ref.append(sp)
+        ref.append(y[:, 64 * nums:].double())
+        ref = torch.cat(ref, 1)
+        got = ops.res2_chain(y.cuda(), w.permute(0, 3, 2, 1).contiguous().cuda(), sc.cuda(), sh.cuda(), dil)
+        err = float((got.cpu().double() - ref).abs().max())
+        assert got.shape == y.shape and err < 5e-6 * max(1.0, float(ref.abs().max())), (B, T, nums, dil, err)
+        assert torch.equal(got[:, 64 * nums:].cpu(), y[:, 64 * nums:])
+    with pytest.raises(SatError):
+        ops.res2_chain(torch.zeros(1, 512, 40, device="cuda"), torch.zeros(7, 3, 64, 64, device="cuda"), torch.zeros(7, 64, device="cuda"),
+                       torch.zeros(7, 64, device="cuda"), 5)
+
+
+def test_embedding_with_and_without_the_fused_chain(net):
+    from satools_amd import synthetic
+    wav = synthetic.harm_batch([0, 1, 2], 48000).to("cuda")
+    try:
+        net.res2_chain = True
+        a = net(wav)[1]
+        net.res2_chain = False
+        b = net(wav)[1]
+    finally:
+        net.res2_chain = True
+    assert float((a - b).abs().max()) < 2e-6
