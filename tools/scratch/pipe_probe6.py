@@ -53,11 +53,6 @@ for m in ("convert", "padded", "padded ragged", "padded h2d d2h write", "padded 
     lens = lens_rg if "ragged" in m else lens_eq
     loop(m)
 lens = lens_eq
-import cProfile, pstats
-lens = lens_rg
-pr = cProfile.Profile(); pr.enable(); loop("padded ragged", 12); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(12)
-sys.exit(0)
 
 # ---- with reader threads like process_data's (8 file threads, one batch-assembling thread per job, two batches ahead)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
