@@ -1684,8 +1684,8 @@ static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* 
     a.f8 = d->mode == SAT_CONV_F16F8;
     a.f8r = d->mode == SAT_CONV_F16F8R;
     SAT_REQUIRE(!a.f8 || d->x_split, "conv1d(f16f8): the input must be split planes (SAT_SPLIT_F8)");
-    SAT_REQUIRE(!a.f8r || (d->x_split && d->x_split8 && d->y_split_format <= 1 && d->ksize >= 2 && !d->up_grouped && d->up == 1),
-                "conv1d(f16f8r): needs x_split (SAT_SPLIT_F16 planes) with its e4m3 sidecar x_split8, SAT_SPLIT_F16 output planes, ksize >= 2, up 1");
+    SAT_REQUIRE(!a.f8r || (d->x_split && d->x_split8 && d->y_split_format <= 1 && d->ksize >= 3 && !d->up_grouped && d->up == 1),
+                "conv1d(f16f8r): needs x_split (SAT_SPLIT_F16 planes) with its e4m3 sidecar x_split8, SAT_SPLIT_F16 output planes, ksize >= 3 (the ring kernel's taps), up 1");
     SAT_REQUIRE(!d->y_split8 || (d->y_split && d->mode != SAT_CONV_F16F8 && d->y_split_format <= 1), "conv1d: y_split8 is the sidecar of SAT_SPLIT_F16 planes y_split");
     SAT_REQUIRE(!d->y_split_hi_only || d->y_split8, "conv1d: y_split_hi_only goes with y_split8");
     a.x8 = d->x_split8;
