@@ -1,6 +1,6 @@
 """random batch sizes and lengths through convert(): the default arithmetic (split-f16, 8-bit cross terms where the ring kernel serves the
 batch) against the exact-f32 kernels of the same model — a cross-check of the dispatch (which kernel serves which shape) over shapes the
-tests do not name.  python tools/fuzz_convert.py [n] [seed]"""
+tests do not name.  python tools/fuzz_convert.py [n] [seed] [tag]"""
 import os, random, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R, os.path.join(R, "tests")]
@@ -10,15 +10,17 @@ from satools_amd import synthetic
 from test_hip_f8r import gen_precision
 
 n, seed = int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0
+tag = sys.argv[3] if len(sys.argv) > 3 else "hifigan_bn_tdnnf_600h_vq_48_v1"
 rng = random.Random(seed)
-model = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1"); model.to("cuda"); model.eval()
+model = satools_amd.load_model("synthetic:" + tag); model.to("cuda"); model.eval()
 ext = model.bn_extractor
 worst, bad, flips, frames = 0.0, [], 0, 0
 for i in range(n):
     B = rng.choice([1, 1, 2, 3, 5, 8, 13, 24, 32, 40])
     nsamp = rng.choice([rng.randint(4000, 12000), rng.randint(12000, 40000), rng.randint(40000, 90000), 320 * rng.randint(20, 250), 16000 * rng.randint(1, 5)])
-    if B * nsamp > 48 * 80000:
-        B = max(1, 48 * 80000 // nsamp)
+    cap = (16 if "wav2vec2" in tag else 48) * 80000
+    if B * nsamp > cap:
+        B = max(1, cap // nsamp)
     wav = synthetic.harm_batch([rng.randint(0, 10 ** 6) for _ in range(B)], nsamp).to("cuda")
     tg = synthetic.targets(model.spk, [rng.randint(0, 10 ** 6) for _ in range(B)])
     try:
@@ -27,15 +29,18 @@ for i in range(n):
             idx = ext.extract_bn(wav.clone(), want_aux=True)[1][1]
             model.set_f0(f0.clone())
             y = model.convert(wav, target=tg)
-            keep = ext.precision
+            keys = [k for k in ("precision", "w2v2_precision") if hasattr(ext, k)]
+            keep = {k: getattr(ext, k) for k in keys}
             try:
-                ext.precision = "f32"
+                for k in keys:
+                    setattr(ext, k, "f32")
                 idx32 = ext.extract_bn(wav.clone(), want_aux=True)[1][1]
                 with gen_precision(model.hifigan, "f32"):
                     model.set_f0(f0.clone())
                     y32 = model.convert(wav, target=tg)
             finally:
-                ext.precision = keep
+                for k, v in keep.items():
+                    setattr(ext, k, v)
         same = bool(torch.equal(idx, idx32))
         d = (y - y32).double()
         rms = float(d.pow(2).mean().sqrt())
