@@ -2019,6 +2019,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "trim_halo")) { g_trim_halo = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32w")) { pair32w_set(value); return SAT_OK; }
   if (!strcmp(name, "pair64w")) { pair64w_set(value); return SAT_OK; }
+  if (!strcmp(name, "pair64_rpre")) { pair64_rpre_set(value); return SAT_OK; }
   if (!strcmp(name, "convring")) { convring_set(value); return SAT_OK; }
   if (!strcmp(name, "convring_blocks")) { convring_set_blocks(value); return SAT_OK; }
   if (!strcmp(name, "convring_wr")) { convring_set_wr(value); return SAT_OK; }

@@ -663,6 +663,7 @@ void lean_set_balance(int v);   // conv_lean.hip
 void pair32s_set_waves(int n);
 void pair32w_set(int v);
 void pair64w_set(int v);
+void pair64_rpre_set(int v);   // pair64.hip: residual words requested a conv ahead of the epilogue
 int pair32_debug_stamps(long long* buf);
 // three-blocks-per-CU form of the 3 / 7 / 11-tap conv tile on split planes (conv_lean.hip)
 int launch_f16x3_lean(const ConvArgs& a, int B, hipStream_t s);

@@ -32,7 +32,7 @@ __device__ __forceinline__ void p64_static_for(F&& f) {
   }
 }
 
-template <int KS, int TG>
+template <int KS, int TG, bool RPRE>
 __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   constexpr int NCH = 4, W1 = P64_W1, TO = W1 - (KS - 1), H2 = (KS - 1) / 2, XWI = 3, XWP = 64 * XWI, W_UNITS = TG * 4 * 64, W_IT = TG;
@@ -144,6 +144,9 @@ __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs 
       }
   };
 
+  // RPRE: the residual words of the wave's output tile (the block's own input planes) are requested when conv1 is done, a whole conv2 of
+  // matrix work ahead of the epilogue that adds them (32 registers; the same loads, earlier: the same bits)
+  float rpre[2][1][16];
   zero_acc();
   issue(std::integral_constant<int, 0>{});
   issue(std::integral_constant<int, 1>{});
@@ -161,10 +164,12 @@ __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs 
       lds_barrier();                        // every wave is done reading the input chunk: t1 goes over it
       write_t1();
       zero_acc();
+      if constexpr (RPRE) epilogue_prefetch_res<2, 1>(p, rpre, b, 0, 0, t0 + wave * 32, l31, lh, 32, t0 + TO);
     }
   });
   // residual = the block input (from its planes), bias, MRF accumulate, f32 and / or planes out; the last KS - 1 columns dropped
-  conv_epilogue<2, 1, false, false>(p, acc, b, 0, 0, t0 + wave * 32, l31, lh, 32, t0 + TO);
+  if constexpr (RPRE) conv_epilogue<2, 1, true, false>(p, acc, b, 0, 0, t0 + wave * 32, l31, lh, 32, t0 + TO, rpre);
+  else conv_epilogue<2, 1, false, false>(p, acc, b, 0, 0, t0 + wave * 32, l31, lh, 32, t0 + TO);
 }
 
 bool pair64_supports(const ConvArgs& a) {
@@ -172,12 +177,16 @@ bool pair64_supports(const ConvArgs& a) {
          !a.ch_scale && a.co_pad == 64 && P64_W1 + (a.ksize - 1) * a.dil <= 192;
 }
 
+static int g_pair64_rpre = 1;      // option "pair64_rpre"
+void pair64_rpre_set(int v) { g_pair64_rpre = v != 0; }
+
 template <int KS, int TG>
 static int launch_p64(const ConvArgs& a, int B, hipStream_t s) {
   // (+ KS - 1 units: conv2's last, unstored, columns read t1 columns 128 ..)
   const size_t lds_bytes = ((size_t)TG * 4 * 64 + (size_t)4 * 4 * P64_W1 + KS - 1) * 16;
   dim3 grid(ceil_div(a.T_q, P64_W1 - (KS - 1)), 1, B);
-  hipLaunchKernelGGL((resblock_pair64_kernel<KS, TG>), grid, dim3(256), lds_bytes, s, a);
+  if (g_pair64_rpre && a.res16 && !a.res) hipLaunchKernelGGL((resblock_pair64_kernel<KS, TG, true>), grid, dim3(256), lds_bytes, s, a);
+  else hipLaunchKernelGGL((resblock_pair64_kernel<KS, TG, false>), grid, dim3(256), lds_bytes, s, a);
   SAT_LAUNCH_CHECK("resblock_pair64_kernel");
   return SAT_OK;
 }
