@@ -298,20 +298,32 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
     produced = {}           # first utterance of a batch -> event behind its last kernel
     pending = [None] * jobs  # status "deferred" (run_steps): YAAPT's status word of a job's batch, checked before its next batch and before the shard is joined
 
+    def check_pending(j):
+        # a deferred status may replace rows of y (near-tie utterances of the VQ decided again on the exact kernels): copied again
+        if pending[j] is not None:
+            st, y, a, b, s = pending[j]
+            pending[j] = None
+            st.check()
+            if getattr(st, "rows", None):
+                with torch.cuda.stream(s):
+                    local[a - lo:b - lo].copy_(y.reshape(b - a, 1, -1))
+                    e = torch.cuda.Event()
+                    e.record(s)
+                    produced[a] = e
+
     def convert_fn(a, b):
         s = streams[n[0] % jobs]
         n[0] += 1
         if seed_before_each:
             torch.manual_seed(1234)
         j = (n[0] - 1) % jobs
-        if pending[j] is not None:
-            pending[j].check()
-            pending[j] = None
+        check_pending(j)
         with torch.cuda.stream(s):
             if status == "sync":
                 y = model.convert(wav[a - lo:b - lo], target=targets[a - lo:b - lo])
             else:
-                y, pending[j] = model.convert(wav[a - lo:b - lo], target=targets[a - lo:b - lo], defer_status=True)
+                y, st = model.convert(wav[a - lo:b - lo], target=targets[a - lo:b - lo], defer_status=True)
+                pending[j] = (st, y, a, b, s)
             local[a - lo:b - lo].copy_(y.reshape(b - a, 1, -1))
             e = torch.cuda.Event()
             e.record(s)
@@ -320,15 +332,16 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
 
     def before_chunk(c, ra, rb):
         # the communication stream waits for the job streams that produced this chunk's batches; the collective is issued behind it
+        for j in range(jobs):                      # (deferred statuses of the chunk's batches first: they may rewrite rows)
+            if pending[j] is not None and lo + ra <= pending[j][2] < lo + rb:
+                check_pending(j)
         for a in range(lo + ra, lo + rb, BATCH):
             comm.wait_event(produced[a])
         return torch.cuda.stream(comm)
 
     def join_streams():
         for j in range(jobs):
-            if pending[j] is not None:
-                pending[j].check()
-                pending[j] = None
+            check_pending(j)
         for s in streams:
             cur.wait_stream(s)
         ev[1].record(cur)           # this rank's compute is done
@@ -338,9 +351,7 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
     for i in range(setup_steps + warmup):
         convert_fn(lo + (i % steps) * BATCH, lo + (i % steps) * BATCH + BATCH)
     for j in range(jobs):
-        if pending[j] is not None:
-            pending[j].check()
-            pending[j] = None
+        check_pending(j)
     for s in streams:
         cur.wait_stream(s)
     transform = sdist.pcm16_rows if gather == "pcm16" else None
@@ -348,7 +359,7 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
     ranks_seen = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(ranks_seen, torch.tensor([rank], dtype=torch.int64, device=dev))
     ranks_seen = [int(t.item()) for t in ranks_seen]
-    windows, gather_ms, compute_ms, stats = [], [], [], {}
+    windows, gather_ms, compute_ms, stats, chunk_ms = [], [], [], {}, []
     out = None
     for _ in range(max(1, repeats)):
         del out
@@ -370,6 +381,13 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
         windows.append(float(t[0].item()))
         gather_ms.append(float(t[1].item()))
         compute_ms.append([round(float(c.item()), 3) for c in comp])
+        # per chunk of the exchange: host time of its issue and of the wait for it in finish(), MAX over ranks — a rank that delays a
+        # chunk shows up at that chunk (dist.ChunkedGather.stats)
+        ch = stats.get("chunks", []) if chunk_batches else []
+        if ch:
+            cw = torch.tensor([[c.get("issue_ms", 0.0), c.get("wait_ms", 0.0)] for c in ch], dtype=torch.float64, device=dev)
+            dist.all_reduce(cw, op=dist.ReduceOp.MAX)
+            chunk_ms.append([[round(float(v), 3) for v in row] for row in cw.tolist()])
     assert out.shape == (n_items, 1, N_SAMPLES + 1)
     mine = transform(local) if transform else local
     # the checked reference: ONE all_gather_into_tensor of the same shards (same inputs -> same waveforms as the warm-up pass it gathered)
@@ -379,7 +397,7 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
     del ref, ref2
     return {"windows": windows, "all_gather_ms": gather_ms, "compute_ms_per_rank": compute_ms, "ranks_seen": ranks_seen, "setup_steps": setup_steps,
             "gathered_equals_shard": ok[0].item() == 0.0, "chunked_equals_single_collective": ok[1].item() == 0.0,
-            "chunks": len(stats.get("chunks", [])), "chunk_batches": chunk_batches}
+            "chunks": len(stats.get("chunks", [])), "chunk_batches": chunk_batches, "chunk_issue_wait_ms": chunk_ms}
 
 
 def last_dispatch():
@@ -474,7 +492,7 @@ def roofline_generator(model, dev, reps):
     _, peak, arithmetic = gen_arithmetic(model)
     hbm = GEN_BYTES_PER_UTT * BATCH / (gen_ms * 1e-3) / 1e12
     traffic, note = None, None
-    for name in (["r05_generator_f16f8r_traffic.json"] if f8 else []) + ["r05_generator_traffic.json", "r04_generator_traffic.json", "r03_generator_traffic.json"]:
+    for name in (["r06_generator_f16f8r_traffic.json", "r05_generator_f16f8r_traffic.json"] if f8 else []) + ["r06_generator_traffic.json", "r05_generator_traffic.json", "r04_generator_traffic.json", "r03_generator_traffic.json"]:
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))["per_forward"]
@@ -484,10 +502,12 @@ def roofline_generator(model, dev, reps):
             note = (f"HBM bytes per generator forward (batch 32), separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                     f"(profiles/{name}): fetch {tj['fetch_GB_doubled']} GB (FETCH_SIZE x 2, the gfx950 wide-load correction) "
                     f"+ write {tj['write_GB']} GB; per-layer streaming model {tj['algorithmic_GB_per_layer_model']} GB"
-                    + ("" if (name.startswith("r05_generator_f16f8r") or not f8) else " — counters of the f16x3 generator: the f16f8r forward also moves the e4m3 sidecars of the thick stages"))
+                    + ("" if ("generator_f16f8r" in name or not f8) else " — counters of the f16x3 generator: the f16f8r forward also moves the e4m3 sidecars of the thick stages"))
             break
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note,
+            # north_star's quantity for the upsample stack: counted HBM bytes of a forward / its measured time / the HBM peak
+            "hbm_frac_counters": (round(traffic / (gen_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4) if traffic else None),
             "kernel": (("split-f16 conv family of the generator" + (" (8-bit cross terms on the thick stages)" if f8 else "")) if split else "conv1d_mfma_kernel (exact f32)")
                       + f": all launches of one forward, {gen_ms:.3f} ms per batch of {BATCH}",
             "timing_ms": dict(gen_t, median=round(gen_ms, 4)),
@@ -522,7 +542,7 @@ def roofline_w2v2(model, dev, reps):
     model_bytes = W2V2_ACT_BYTES_PER_UTT * BATCH + W2V2_WEIGHT_BYTES
     hbm = model_bytes / (ext_ms * 1e-3) / 1e12
     traffic, note = None, None
-    for tname in ("r04_w2v2_traffic.json", "r03_w2v2_traffic.json"):
+    for tname in ("r06_w2v2_traffic.json", "r04_w2v2_traffic.json", "r03_w2v2_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if not os.path.exists(tpath):
             continue
@@ -534,6 +554,7 @@ def roofline_w2v2(model, dev, reps):
         break
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": note,
+            "hbm_frac_counters": (round(traffic / (ext_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4) if traffic else None),
             "hbm_model": {"achieved_TBps": round(hbm, 3), "peak_TBps": PEAK_HBM_TBS, "frac": round(hbm / PEAK_HBM_TBS, 4),
                           "bytes_per_launch_group": model_bytes},
             "kernel": f"wav2vec2-large + TDNNF tail bottleneck extractor (get_bn): all launches, {ext_ms:.3f} ms per batch of {BATCH}",
@@ -543,6 +564,36 @@ def roofline_w2v2(model, dev, reps):
                                 "frac": round(flop / us / 1e6 / peak, 4)},
             "arithmetic": "f32 operands split hi+lo f16, 3 f16 MFMA products per product, f32 accumulate; peak = dense f16 MFMA peak / 3",
             "algorithmic_flop_per_launch_group": W2V2_FLOP_PER_UTT * BATCH}
+
+
+def aux_forwards(dev):
+    """SURVEY 8 f3 / f4 — the forwards beside the anonymization path that are built and parity-tested but are not BASELINE configs:
+    the x-vector extractor (ECAPA-TDNN, egs/asv/voxceleb/local/tuning/ecapa_tdnn.py:36-81) and the full ASR forward up to the
+    chain / xent log-likelihoods of both bottleneck nets (tdnnf_vq.py:259-284, tdnnf_wav2vec2_vq.py:316-345), batch 32 x 5 s,
+    timed with events on the launch stream (median of five timings of ten calls, warmed like every roofline leg)."""
+    import torch
+    from satools_amd import synthetic, xvector
+    import satools_amd
+    out = {}
+    wav = synthetic.harm_batch(list(range(BATCH))).to(dev)
+    rt = lambda ms: round(BATCH * UTT_SECONDS / (ms * 1e-3), 1)
+    with torch.no_grad():
+        net = xvector.build()(num_speakers=10)
+        net.load_state_dict(synthetic.xvector_state(0, 10))
+        net = net.to(dev)
+        ms, t = time_events(lambda: net(wav), 10)
+        out["f3 x-vector extractor"] = {"workload": "ECAPA-TDNN x-vector extractor forward (MelSpectrogram front end included), batch 32 x 5 s, " + str(net.precision),
+                                        "value": rt(ms), "unit": "x real-time", "ms_per_batch": round(ms, 3), "timing_ms": t}
+        del net
+        for name, tag in (("f4 ASR forward (fbank tag)", TAG), ("f4 ASR forward (wav2vec2 tag)", TAG_W2V2)):
+            model = load(tag, "", dev)
+            ext = model.bn_extractor
+            ms, t = time_events(lambda: ext(wav.clone()), 10)          # (the fbank net scales its argument in place, like the reference)
+            out[name] = {"workload": f"Net.forward of the bottleneck net of {tag} up to the chain / xent log-likelihoods, batch 32 x 5 s, {ext.precision}",
+                         "value": rt(ms), "unit": "x real-time", "ms_per_batch": round(ms, 3), "timing_ms": t}
+            del model, ext
+            torch.cuda.empty_cache()
+    return out
 
 
 def gen_arithmetic(model):
@@ -591,6 +642,7 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
                  "utterances": world * steps * BATCH, "gather_dtype": "int16" if a.gather == "pcm16" else "float32",
                  "gathered_equals_shard": r["gathered_equals_shard"], "chunked_equals_single_collective": r["chunked_equals_single_collective"],
                  "compute_ms_per_rank": comp, "compute_ms_min_max": [min(comp), max(comp)],
+                 "chunk_issue_wait_ms_max_over_ranks": (r["chunk_issue_wait_ms"][mid] if r["chunk_issue_wait_ms"] else None),
                  "all_gather": (f"{r['chunks']} asynchronous all-gathers of {r['chunk_batches']} batches each ([{r['chunk_batches'] * BATCH}, 1, {N_SAMPLES + 1}] "
                                 if r["chunk_batches"] else f"one all_gather_into_tensor of [{steps * BATCH}, 1, {N_SAMPLES + 1}] ")
                                + f"{'int16 PCM' if a.gather == 'pcm16' else 'f32'} per rank; {steps * BATCH * (N_SAMPLES + 1) * gb / 1e6:.0f} MB per rank in all), "
@@ -802,6 +854,8 @@ def main():
                         d["cpu_baseline"]["processes"] = {"value": cb["processes"]["value"], "processes": cb["processes"]["processes"]}
                 return d
             head["configs"] = {o["config"]["workload"].split(":")[0]: brief(o) for o in lines[:-1]}
+            if not use_pg and not a.tag:
+                head["configs"].update(aux_forwards(dev))
             for o in lines[:-1]:
                 print("CONFIG_LINE " + json.dumps(o), file=sys.stderr, flush=True)
     if use_pg:

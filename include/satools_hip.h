@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 6
+#define SAT_ABI_VERSION 7
 
 typedef enum {
   SAT_OK = 0,
@@ -328,6 +328,17 @@ void sat_hifigan_destroy(sat_hifigan* h);
  * "planes_residual", "branch_streams"; "f8_stages" (round 5, default 0): bit i set = the ResBlock convs of stage i run as
  * SAT_CONV_F16F8R where sat_hifigan_set_conv_f8r installed their packing and the ring kernel serves the batch */
 int sat_hifigan_set_option(sat_hifigan* h, const char* name, int value);
+/* ABI 7.  "force_f8" (default 0): the SAT_CONV_F16F8R stages run that way at EVERY batch size (a calibration batch of one utterance is too
+ * small for the ring kernel's default dispatch; the load-time guard `Net.check_precision`, which stands where the reference's
+ * infer_helper.load_model, satools/satools/infer_helper.py:10-59, hands out a model, sets it on its own handle).
+ * sat_hifigan_get_option reads an option back; read-only "last_f8_stages": bit i = stage i of the handle's LAST forward ran its
+ * ResBlock convs with 8-bit cross terms (a batch too small for the ring kernel runs them in SAT_CONV_F16X3: the caller can see which). */
+int sat_hifigan_get_option(const sat_hifigan* h, const char* name, int* value);
+/* ABI 7.  Range probe of the split planes a forward writes (diagnostic of the guard; off unless installed): `buf` = 2 * n_ups device
+ * words, zeroed by the caller; per stage i, buf[2 i] += number of hi halves past 57 344 (the largest e5m2: where the 8-bit sidecar of
+ * SAT_CONV_F16F8R saturates; f16 itself ends at 65 504) or not finite, buf[2 i + 1] = max |hi| as the bit pattern of an f32.  Probed:
+ * the ResBlock input of every stage and, on the stages with C > 64, every inner activation and step output.  nullptr = off. */
+int sat_hifigan_set_range_probe(sat_hifigan* h, uint64_t* buf);
 
 /* final stage alone: leaky_relu(0.01) -> ReflectionPad1d((1,0)) -> Conv1d(C,1,7,pad 3) -> tanh
  * (archi.py:87-90).  x [B][C][T] -> y [B][1][T+1];  w [C][7], bias [1]. */
@@ -359,6 +370,14 @@ int sat_fbank_cmvn_pad_f32(const float* wav, float* feats, const float* window, 
  * ------------------------------------------------------------------------------------------ */
 int sat_vq_argmin_gather_f32(const float* z, const float* codebook, float* q, int32_t* idx,
                              float* dist, int B, int D, int T, int n_codes, void* stream);
+/* ABI 7.  The same, and tie_count[b] += the frames of utterance b whose two best codes a, a' are a NEAR-TIE of this arithmetic:
+ * d[a'] - d[a] <= tie_scale * |z_t| * pair_dist[a][a'] (pair_dist [n_codes][n_codes] = |e_a - e_a'|; tie_scale = 2 K sigma_rel / sqrt(D),
+ * K standard deviations of the calibrated per-component feature error of the split-f16 extractor against its exact-f32 twin).  The
+ * host re-decides flagged utterances on the exact-f32 kernels (asrbn.py), so that the indices of the default arithmetic are the
+ * exact ones (chain/nn.py:424-459 is index work).  tie_count [B] int32, zeroed by the caller. */
+int sat_vq_argmin_gather_tie_f32(const float* z, const float* codebook, float* q, int32_t* idx, float* dist,
+                                 const float* pair_dist, float tie_scale, int32_t* tie_count,
+                                 int B, int D, int T, int n_codes, void* stream);
 
 /* pad frames at both ends: x [B][C][T] -> y [B][C][left+T+right].  Left = first frame replicated.
  * Right: interleave_right = 0 -> last frame replicated (F.pad(...,"replicate"),

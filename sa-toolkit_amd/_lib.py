@@ -78,6 +78,8 @@ _PROTOS = {
                                           C.c_int, C.c_void_p]),
     "sat_hifigan_destroy": (None, [C.c_void_p]),
     "sat_hifigan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "sat_hifigan_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "sat_hifigan_set_range_probe": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sat_resblock_pair_f16x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "sat_mrf_debug_stamps": (C.c_int, [C.c_void_p]),
@@ -105,6 +107,8 @@ _PROTOS = {
                                          C.c_int, C.c_void_p]),
     "sat_vq_argmin_gather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sat_vq_argmin_gather_tie_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sat_pad_replicate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]),
     "sat_f0_stats_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -176,7 +180,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.sat_abi_version() != 6:       # 5: SAT_CONV_F16F8R; sat_conv1d_desc grew x_split8 / y_split8 / y_split_hi_only.  6: sat_pcm16_*
+        if l.sat_abi_version() != 7:       # 5: SAT_CONV_F16F8R; sat_conv1d_desc grew x_split8 / y_split8 / y_split_hi_only.  6: sat_pcm16_*.  7: VQ near-tie count, hifigan get_option / range probe
             raise SatError("libsatools_hip.so ABI version mismatch")
         # A/B switches of the conv dispatch for whole-program measurements (bench.py under different kernels):
         # SATOOLS_AMD_CONV_OPTIONS="pair32w=0,lean_balance=2" -> sat_conv_set_option(name, value) at load time

@@ -29,6 +29,32 @@ class SimpleNamespace:
         return "SimpleNamespace({})".format(", ".join(f"{k}={v!r}" for k, v in self.__dict__.items()))
 
 
+class ConvertStatus:
+    """what `convert(..., defer_status=True)` hands back beside y: `check()` raises what the plain call would have raised (YAAPT's
+    status word) and finishes the call's deferred work — utterances whose VQ decision was a near-tie of the split-f16 arithmetic are
+    decided again on the exact-f32 kernels and their rows of y replaced (asrbn._TdnnfBase.vq_tie_sigmas).  The caller uses y after
+    `check()`; when rows were replaced, `check()` returns after they have been written."""
+
+    def __init__(self, f0_status, fix, patch, stream, deferred):
+        self.f0_status, self.fix, self.patch, self.stream, self.deferred = f0_status, fix, patch, stream, deferred
+        self.rows = None
+
+    def check(self):
+        if self.f0_status is not None:
+            self.f0_status.check()
+        if self.rows is None:
+            self.rows = []
+            if self.fix is not None:
+                with torch.cuda.stream(self.stream):
+                    rows = self.fix()
+                    if rows:
+                        self.patch(rows)
+                        self.rows = rows
+                if self.rows and self.deferred:      # (the plain call returns y with the rows' launches enqueued in order on its stream)
+                    self.stream.synchronize()
+            self.fix = self.patch = None
+
+
 def build(args):
     """factory with the reference's signature: build(args) -> Net class (hifigan.py:18-131)"""
     from . import infer_helper
@@ -50,6 +76,7 @@ def build(args):
             self.spk = sorted(set([v for v in utt2spk.values()]))
             self.f0: Optional[torch.Tensor] = None
             self._defer_f0_status, self._f0_status, self._f0_stream = False, None, None
+            self._bn_fix, self._keep_ctx, self._fwd_ctx = None, False, None
             self.hifigan = CoreHifiGan(
                 imput_dim=256 + 1 + len(self.spk),
                 upsample_rates=[5, 4, 4, 2, 2],
@@ -65,6 +92,25 @@ def build(args):
             super().train(mode)
             self.bn_extractor.eval()
 
+        def _apply(self, fn, *a, **k):
+            # `.to("cuda")` of a model that infer_helper.load_model built from a real checkpoint: the precision guard runs ONCE, on
+            # the first move to the device (SATOOLS_AMD_CHECK_PRECISION=0 skips it) — the reduced-precision defaults ("f16f8r" generator,
+            # split-f16 extractor) were measured on seeded-random weights; a trained checkpoint gets its own calibration run, the
+            # report is logged and kept (`precision_report`), and a part that fails it falls back (check_precision)
+            out = super()._apply(fn, *a, **k)
+            if self.__dict__.get("_precision_check_pending") and self._device().type == "cuda":
+                self.__dict__["_precision_check_pending"] = False
+                import logging
+                import os
+                if os.environ.get("SATOOLS_AMD_CHECK_PRECISION", "1") not in ("0", "false", "no"):
+                    was_training = self.training
+                    rep = self.check_precision()
+                    self.__dict__["precision_report"] = rep
+                    logging.getLogger("satools_amd").info("precision guard on the loaded checkpoint: %s", rep)
+                    if was_training:
+                        super().train(True)
+            return out
+
         def _device(self):
             return next(self.hifigan.parameters()).device
 
@@ -77,14 +123,20 @@ def build(args):
 
         # ---- feature extractors (decorators are pass-through under SA_JIT_TWEAK=true,
         #      utils/feature_extractor_decorator.py:60-71; parse_wavinfo_wav clones) -------------
-        def get_bn(self, wavinfo):
+        def get_bn(self, wavinfo, defer_ties=False):
+            """defer_ties=True (inside convert()): -> (bn, fix) — `fix()` waits for the batch's VQ launch and decides near-tie utterances
+            again on the exact kernels (rows of bn are rewritten in place; returns them), to be run once the generator is enqueued"""
             wav = self._to_device(getattr(wavinfo, "wav", wavinfo).detach())
             # parse_wavinfo_wav clones because the extractor scales its argument in place (wav_scp_dataset.py:48-53);
             # the private entry leaves the input untouched instead (no clone, no scaling pass)
             private = getattr(self.bn_extractor, "_extract_bn_private", None)
             if private is not None:
+                if defer_ties:
+                    bn, fix = private(wav, defer_ties=True)
+                    return bn.permute(0, 2, 1), fix
                 return private(wav).permute(0, 2, 1)
-            return self.bn_extractor.extract_bn(wav.clone()).permute(0, 2, 1)
+            bn = self.bn_extractor.extract_bn(wav.clone()).permute(0, 2, 1)
+            return (bn, None) if defer_ties else bn
 
         def set_f0(self, f0):
             self.f0 = f0
@@ -126,14 +178,33 @@ def build(args):
                 f0, st = f0_hip.yaapt_ragged(xd, lengths, self.f0_yaapt_opts, defer_status=True)
                 f0 = f0.unsqueeze(0)
             xd.record_stream(side)
-            bn = self.get_bn(x)
+            bn, fix = self.get_bn(x, defer_ties=True)
             cur.wait_stream(side)
             f0.record_stream(cur)
-            y = self._forward(f0, bn, self.get_spk_id(x, target)).squeeze(0)
+            self._keep_ctx = fix is not None
+            try:
+                y = self._forward(f0, bn, self.get_spk_id(x, target))
+            finally:
+                self._keep_ctx = False
+            return self._finish(y, st, fix, defer_status)
+
+        def _finish(self, y, f0_status, fix, defer_status):
+            """y [B, 1, n'] of _forward -> what convert() returns; the deferred work (YAAPT's status word, the near-tie utterances of the
+            VQ) done here or handed to the caller as a ConvertStatus"""
+            ctx, self._fwd_ctx = self._fwd_ctx, None
+            out = y.squeeze(0)
+
+            def patch(rows):
+                bn, f0_d, spk = ctx
+                xs = ops.assemble_input(bn[rows].contiguous(), f0_d[rows].reshape(len(rows), -1).contiguous(), spk[rows].contiguous(), spk.shape[1])
+                ys, _ = self.hifigan(xs)
+                y[rows] = ys.to(torch.float32)
+
+            st = ConvertStatus(f0_status, fix, patch if fix is not None else None, torch.cuda.current_stream(y.device), bool(defer_status))
             if defer_status:
-                return y, st
+                return out, st
             st.check()
-            return y
+            return out
 
         def check_precision(self, wav=None, tol=2e-5, fallback=True):
             """Load-time guard for the split-f16 arithmetic (f32 operands carried as hi + lo f16): run a
@@ -199,17 +270,22 @@ def build(args):
                         gen.precision = "f32"
                         y32 = gen(x)[0]
                         if keep == "f16f8r":
-                            # e4m3 cross terms on the thick stages (csrc/conv_ring16.hip): a calibration batch is too small for the ring
-                            # kernel's default dispatch, so it is sent there explicitly; a checkpoint whose activations or weights leave
-                            # the range the e4m3 operands carry (|x| > 448 saturates) falls back to "f16x3" FIRST
+                            # 8-bit cross terms on the thick stages (csrc/conv_ring16.hip): a calibration batch is too small for the ring
+                            # kernel's default dispatch, so THIS handle is told to run them at every batch size (option force_f8; the
+                            # process-wide dispatch options are not touched); a checkpoint whose activations or weights leave the
+                            # range the 8-bit operands carry falls back to "f16x3" FIRST.  The planes the forward writes are probed
+                            # on the way (sat_hifigan_set_range_probe: values past the largest e5m2 / f16, per stage)
                             gen.precision = "f16f8r"
-                            _lib.check(_lib.lib().sat_conv_set_option(b"convring", 33), "sat_conv_set_option")
+                            gen.set_force_f8(1)
                             try:
                                 y8 = gen(x)[0]
+                                out["generator_arithmetic_f16f8r_ran"] = gen.last_arithmetic
+                                out["generator_range"] = gen.range_probe(x)
                             finally:
-                                _lib.check(_lib.lib().sat_conv_set_option(b"convring", 1), "sat_conv_set_option")
+                                gen.set_force_f8(0)
                             out["generator_f16f8r"] = relrms(y8, y32)
-                            if out["generator_f16f8r"] > 10 * tol and fallback:
+                            out["generator_f8_weights"] = gen.f8_weight_stats()
+                            if (out["generator_f16f8r"] > 10 * tol or sum(out["generator_range"]["past_e5m2_max"]) > 0) and fallback:
                                 fell.append("generator: f16f8r -> f16x3")
                                 final = "f16x3"
                             gen.precision = "f16x3"
@@ -255,14 +331,17 @@ def build(args):
                     f0, self._f0_status = f0_hip.yaapt(xd, self.f0_yaapt_opts, defer_status=True)
                     f0 = f0.unsqueeze(0)
                 xd.record_stream(side)
-                bn = self.get_bn(x)
+                bn, self._bn_fix = self.get_bn(x, defer_ties=True)
                 cur.wait_stream(side)
                 f0.record_stream(cur)
                 spk_id = self.get_spk_id(x, target)
                 return (f0, bn, spk_id)
             else:
                 f0 = self.get_f0(x).unsqueeze(0)
-            bn = self.get_bn(x)
+            if self._defer_f0_status:          # inside convert() (F0 from set_f0): near-tie utterances are decided again behind the generator
+                bn, self._bn_fix = self.get_bn(x, defer_ties=True)
+            else:
+                bn = self.get_bn(x)
             spk_id = self.get_spk_id(x, target)
             return (f0, bn, spk_id)
 
@@ -270,18 +349,19 @@ def build(args):
             """hifigan.py:58-71.  defer_status=True (not in the reference): returns (y, status) without waiting for YAAPT's status word —
             `status.check()` raises what this call would have raised (None when the F0 came from `set_f0`); a caller that keeps several
             batches in flight checks a batch's status before it uses y instead of making a round trip to the GPU per call"""
-            self._defer_f0_status, self._f0_status = True, None
+            self._defer_f0_status, self._f0_status, self._bn_fix = True, None, None
             try:
                 (f0, bn, spk_id) = self.extract_features(x, target)
             finally:
                 self._defer_f0_status = False
-            y = self._forward(f0, bn, spk_id).squeeze(0)
+            fix, self._bn_fix = self._bn_fix, None
+            self._keep_ctx = fix is not None
+            try:
+                y = self._forward(f0, bn, spk_id)
+            finally:
+                self._keep_ctx = False
             st, self._f0_status = self._f0_status, None
-            if defer_status:
-                return y, st
-            if st is not None:
-                st.check()
-            return y
+            return self._finish(y, st, fix, defer_status)
 
         def f0_transformation(self, f0):
             """host-level entry kept for API parity (hifigan.py:73-81); [B,1,T] device tensor"""
@@ -347,6 +427,8 @@ def build(args):
             assert B == spk.shape[0], \
                 "len(target) != len(input_wav), check if the waveform batch size == target=len(['6081','4214'])"
             x = ops.assemble_input(bn, f0_d.reshape(B, -1), spk, spk.shape[1])
+            if self._keep_ctx:            # convert(): the rows of near-tie utterances are assembled and generated again (_finish)
+                self._fwd_ctx = (bn, f0_d, spk)
             y, _ = self.hifigan(x)
             return y.to(torch.float32)
 

@@ -76,6 +76,38 @@ def vq_flip_stats(z, idx, z_exact, idx_exact, dist_exact):
     return out
 
 
+class TieStatus:
+    """Deferred near-tie report of one VQ launch (`sat_vq_argmin_gather_tie_f32`): the per-utterance counts travel to a page-locked
+    row behind the launch, `rows()` waits for them (the VQ runs before the generator: by the time a caller has enqueued the rest of
+    `convert()` they have usually landed) and names the utterances to decide again on the exact-f32 kernels."""
+
+    def __init__(self, counts_dev):
+        from .f0 import _pinned_ints
+        self._pool = _pinned_ints
+        self.host, self.row = _pinned_ints.take(counts_dev.numel())
+        self.host.copy_(counts_dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.counts = None
+
+    def rows(self):
+        if self.counts is None:
+            self.event.synchronize()
+            self.counts = self.host.clone()
+            self.host = None
+            self._pool.give(self.row)
+            self.row = None
+        return torch.nonzero(self.counts).flatten().tolist()
+
+    def __del__(self):
+        try:
+            if self.row is not None:
+                self.event.synchronize()
+                self._pool.give(self.row)
+        except Exception:
+            pass
+
+
 class _LayerCache:
     """device-side, kernel-ready form of one TDNNFBatchNorm layer"""
     __slots__ = ("wB", "bB", "wA", "bA", "scale", "shift", "codebook", "modeA", "modeB")
@@ -89,6 +121,13 @@ class _TdnnfBase(nn.Module):
     #: what decides a VQ arg-min near a tie either way; VQ indices identical to the reference's on every fixture
     #: frame with both settings, tests/test_hip_parity.py) or "f32" (exact f32 MFMA, 0.8 ms per batch slower)
     precision = os.environ.get("SATOOLS_AMD_TDNNF_PRECISION", "f16x3")
+
+    #: near-tie guard of the VQ decision (chain/nn.py:424-459 is INDEX work: the bar is exact).  In split-f16 arithmetic a frame whose
+    #: two best codes lie closer than this many standard deviations of the arithmetic's own (calibrated) feature error is counted
+    #: on the device, and its utterance is decided again on the exact-f32 kernels — so the default arithmetic returns the exact
+    #: kernels' indices (536-utterance sweep per tag: tests/test_hip_robust.py).  0 switches the guard off; frozen models (no f32
+    #: parameters to fall back on) run without it.
+    vq_tie_sigmas = float(os.environ.get("SATOOLS_AMD_VQ_TIE_SIGMAS", "6"))
 
     def _init_cache(self):
         self._cache = None
@@ -144,14 +183,23 @@ class _TdnnfBase(nn.Module):
         key = (self.precision,) + self._param_key()
         if self._cache_key == key:
             return
+        # one cache per precision is kept (the near-tie guard runs a few utterances of most batches on the exact kernels: the
+        # switch must not fold and pack the weights again)
+        store = self.__dict__.setdefault("_cache_store", {})
+        if self._cache_key is not None:
+            store[self._cache_key[0]] = (self._cache_key, self._cache, self._cache_full)
+        hit = store.get(self.precision)
+        if hit is not None and hit[0] == key:
+            self._cache_key, self._cache, self._cache_full = hit
+            return
         split = self.precision == "f16x3"
-        _lib.cache_rebuild_begin(device, self._cache is not None)
+        _lib.cache_rebuild_begin(device, hit is not None)
         self._cache = [self._layer_cache(lay, device, split) for lay in self._stack_layers()]
         self._cache_full = None
         self._cache_key = key
         _lib.cache_rebuild_end(device)
 
-    def _tdnnf_layer(self, lay, c, x, xs=None, return_bottleneck=False, want_aux=False, row_frames=None):
+    def _tdnnf_layer(self, lay, c, x, xs=None, return_bottleneck=False, want_aux=False, row_frames=None, tie=None):
         """x [B, feat, T] -> [B, out, T'] (or the bottleneck [B, bott, T']).  In split-f16 mode the layers
         hand their activations on as split planes as well (`xs`, csrc/conv1d_mfma.hip): linearB then
         stages its 1024 x 3 input with 16-byte copies and linearA reads the bottleneck from planes; the
@@ -188,7 +236,7 @@ class _TdnnfBase(nn.Module):
                            x_split=xs if planes_in else None)
         aux = None
         if c.codebook is not None:
-            zq, idx, dist = ops.vq(z, c.codebook, want_dist=want_aux)
+            zq, idx, dist = ops.vq(z, c.codebook, want_dist=want_aux, tie=tie)
             aux = (z, idx, dist)
             z = zq
         if return_bottleneck:
@@ -206,6 +254,15 @@ class _TdnnfBase(nn.Module):
                        x_split=zs, y_split=ys, y_split_slope=1.0, **kw)
         return y, ys
 
+    def vq_indices(self, wav):
+        """VQ indices [N, T'] of `wav` [N, n] (device tensor; left untouched) as the extractor DELIVERS them: the configured
+        arithmetic with the near-tie guard, flagged utterances decided again on the exact kernels.  -> (idx, rows decided again)"""
+        with self._lock():
+            feats = self._features_of(wav.clone())
+            (zq, (_, idx, _)), status = self._run_stack_guarded(feats, want_aux=True)
+            rows = self.resolve_ties(status, zq.permute(0, 2, 1), feats, wav, idx=idx)
+        return idx, rows
+
     def vq_flip_report(self, wav):
         """`vq_flip_stats` of this extractor as configured against its exact-f32 kernels on `wav` [N, n] (device tensor; left
         untouched): how many VQ indices the split-f16 arithmetic decides differently, and whether every one of them is a near-tie."""
@@ -221,14 +278,110 @@ class _TdnnfBase(nn.Module):
                 setattr(self, k, v)
         return vq_flip_stats(z, idx, z32, idx32, d32)
 
-    def _run_stack(self, x, want_aux=False):
+    def _run_stack(self, x, want_aux=False, tie=None):
         """x [B, C, T] (already padded) through tdnn1, tdnnfs[:-2], and the bottleneck of tdnnfs[-2]"""
         self._prepare(x.device)
         layers = self._stack_layers()
         xs = None
         for lay, c in zip(layers[:-1], self._cache[:-1]):
             x, xs = self._tdnnf_layer(lay, c, x, xs)
-        return self._tdnnf_layer(layers[-1], self._cache[-1], x, xs, return_bottleneck=True, want_aux=want_aux)
+        return self._tdnnf_layer(layers[-1], self._cache[-1], x, xs, return_bottleneck=True, want_aux=want_aux, tie=tie)
+
+    # ---- exact VQ indices in the default arithmetic: near-ties counted on the device, their utterances decided again ----------
+    def _precision_keys(self):
+        return [k for k in ("precision", "w2v2_precision") if hasattr(self, k)]
+
+    def _lock(self):
+        """the precision attributes select the kernels at launch time: a thread that decides flagged utterances again on the exact
+        kernels (the batch job checks deferred statuses in its writer thread) must not meet the launching thread half way"""
+        lk = self.__dict__.get("_arith_lock")
+        if lk is None:
+            import threading
+            lk = self.__dict__.setdefault("_arith_lock", threading.RLock())
+        return lk
+
+    class _exact:
+        """context: the extractor on its exact-f32 kernels (both packings stay cached)"""
+
+        def __init__(self, net):
+            self.net = net
+
+        def __enter__(self):
+            self.net._lock().acquire()
+            self.keep = {k: getattr(self.net, k) for k in self.net._precision_keys()}
+            for k in self.keep:
+                setattr(self.net, k, "f32")
+
+        def __exit__(self, *a):
+            for k, v in self.keep.items():
+                setattr(self.net, k, v)
+            self.net._lock().release()
+
+    def _tie_guard(self, device):
+        """-> (pair distances of the codebook [n, n], tie_scale) for sat_vq_argmin_gather_tie_f32, or None when the guard is off.
+        tie_scale = 2 K sigma_rel / sqrt(D): sigma_rel = |z - z_exact| / |z_exact| of this extractor's split-f16 arithmetic against its
+        exact-f32 twin on two synthetic 2 s utterances, measured once per (weights, precision) — the error of d[a] - d[a'] is
+        2 dz . (e_a' - e_a), i.e. ~ N(0, (2 sigma_c |e_a - e_a'|)^2) with sigma_c = sigma_rel |z_t| / sqrt(D) per component."""
+        if not self.vq_tie_sigmas or self.__dict__.get("_frozen") or self.__dict__.get("_tie_busy"):
+            return None
+        if all(getattr(self, k) == "f32" for k in self._precision_keys()):
+            return None
+        key = tuple(getattr(self, k) for k in self._precision_keys()) + self._param_key() + (str(device),)
+        g = self.__dict__.get("_tie")
+        if g is None or g[0] != key:
+            from . import synthetic
+            self.__dict__["_tie_busy"] = True
+            try:
+                with torch.no_grad():
+                    wav = synthetic.harm_batch([9001, 9002], 32000).to(device)
+                    _, (z, _, _) = self.extract_bn(wav.clone(), want_aux=True)
+                    with self._exact(self):
+                        _, (z32, _, _) = self.extract_bn(wav.clone(), want_aux=True)
+                    sigma_rel = float((z.double() - z32.double()).norm() / z32.double().norm().clamp_min(1e-30))
+                    cb = self._cache[-1].codebook
+                    pair = torch.cdist(cb.double(), cb.double()).to(torch.float32).contiguous()
+            finally:
+                self.__dict__["_tie_busy"] = False
+            g = self.__dict__["_tie"] = (key, pair, sigma_rel, z.shape[1])
+        _, pair, sigma_rel, D = g
+        return pair, 2.0 * self.vq_tie_sigmas * sigma_rel / math.sqrt(D)
+
+    def _run_stack_guarded(self, feats, want_aux=False):
+        """`_run_stack` with the near-tie count: -> (result, TieStatus or None)"""
+        guard = self._tie_guard(feats.device)
+        if guard is None:
+            return self._run_stack(feats, want_aux=want_aux), None
+        counts = torch.zeros(feats.shape[0], dtype=torch.int32, device=feats.device)
+        out = self._run_stack(feats, want_aux=want_aux, tie=(guard[0], guard[1], counts))
+        return out, TieStatus(counts)
+
+    def _exact_rows(self, rows, feats, wav, want_aux=False):
+        """the quantised bottleneck [len(rows), D, T'] of utterances `rows` on the exact-f32 kernels, from the batch's padded features
+        `feats` (f32 front end: the fbank tag) — the wav2vec2 tag overrides this to recompute its encoder for those rows"""
+        with self._exact(self):
+            return self._run_stack(feats[rows].contiguous(), want_aux=want_aux)
+
+    def resolve_ties(self, status, bn, feats, wav, idx=None):
+        """decide the flagged utterances of `status` again on the exact kernels and write their rows into `bn` ([B, T', D] view of the
+        stack's output, as extract_bn returns it) and, when given, their VQ indices into `idx` [B, T']; -> the rows (empty list:
+        nothing to do).  Waits for the VQ launch of the batch."""
+        if status is None:
+            return []
+        rows = status.rows()
+        if rows:
+            self.__dict__["_tie_busy"] = True
+            try:
+                if idx is None:
+                    bn[rows] = self._exact_rows(rows, feats, wav).permute(0, 2, 1)
+                else:
+                    zq, (_, idx_x, _) = self._exact_rows(rows, feats, wav, want_aux=True)
+                    bn[rows] = zq.permute(0, 2, 1)
+                    idx[rows] = idx_x
+            finally:
+                self.__dict__["_tie_busy"] = False
+            st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0})
+            st["rerun"] += len(rows)
+        return rows
 
     # ---- the ASR half: Net.forward up to the chain / xent outputs (SURVEY 8 f4) --------------------------
     def _prepare_full(self, device):
@@ -375,14 +528,30 @@ class TdnnfVqNet(_TdnnfBase):
         win, mel, lo, hi = self._fbank_tables(x.device)
         return ops.fbank_cmvn_pad(x, win, mel, lo, hi, scale=scale, pad=self.padding, cmvn=True)
 
-    def _extract_bn_private(self, x):
+    def _features_of(self, x):
+        return self.features(x.to(torch.float32).contiguous(), scale=32768.0)
+
+    def _extract_bn_private(self, x, defer_ties=False):
         """extract_bn for a caller that owns no view of `x` afterwards (Net.get_bn, whose reference version clones
         its input only because extract_bn scales in place): the 32768 scaling happens inside the framing kernel,
         the input is left untouched and neither the clone nor the scaling pass is launched.  Same values: the
         kernel multiplies each sample by the scale before anything else."""
         if not x.is_cuda or x.dim() != 2:
             raise _lib.SatError("extract_bn expects a 2-dimensional tensor [N, samples] on the HIP device")
-        return self._run_stack(self.features(x.to(torch.float32).contiguous(), scale=32768.0)).permute(0, 2, 1)
+        with self._lock():
+            return self._bn_guarded(self.features(x.to(torch.float32).contiguous(), scale=32768.0), x, defer_ties)
+
+    def _bn_guarded(self, feats, wav, defer_ties=False):
+        """stack + VQ with the near-tie guard: -> bn [N, T', D], or (bn, fix) with `fix()` -> rows decided again (the caller runs it
+        once the rest of its launches are enqueued, and repeats what it derived from those rows of bn)"""
+        out, status = self._run_stack_guarded(feats)
+        bn = out.permute(0, 2, 1)
+        st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0})
+        st["utterances"] += bn.shape[0] if status is not None else 0
+        if defer_ties:
+            return bn, (lambda: self.resolve_ties(status, bn, feats, wav))
+        self.resolve_ties(status, bn, feats, wav)
+        return bn
 
     def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
         """inputs [N, n] -> [N, T, 256]   (tdnnf_vq.py:236-257; like the reference this scales
@@ -393,10 +562,11 @@ class TdnnfVqNet(_TdnnfBase):
             raise _lib.SatError("extract_bn expects a 2-dimensional tensor [N, samples]")
         x *= 32768
         feats = self.features(x.to(torch.float32))
-        out = self._run_stack(feats, want_aux=want_aux)
-        if want_aux:
+        if want_aux:                       # diagnostics: the arithmetic as configured, no second decision
+            out = self._run_stack(feats, want_aux=True)
             return out[0].permute(0, 2, 1), out[1]
-        return out.permute(0, 2, 1)
+        with self._lock():
+            return self._bn_guarded(feats, x)
 
     def forward(self, x):
         """waveforms [N, n] in [-1, 1] -> (chain_out, log_softmax(xent_out)), each [N, T', output_dim]

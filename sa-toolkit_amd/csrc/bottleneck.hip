@@ -17,16 +17,19 @@ constexpr int VQ_MAX_CODES = 64;
 // Block = 64 frames x 4 code groups (one wave per group): every (frame, code) distance is still one thread's
 // d-ordered fma chain, the groups only share the work of a frame; the arg-min is combined in code order with
 // a strict '<', i.e. the first minimum wins as in torch.argmin.
-template <int NC>
+template <int NC, bool TIE>
 __global__ void __launch_bounds__(256) vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                  float* __restrict__ q, int* __restrict__ idx_out,
-                                                 float* __restrict__ dist_out, int D, int T, int n_codes) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [D][NC] codebook^T, then [NC] norms, then [4][64] (d, idx)
+                                                 float* __restrict__ dist_out, int D, int T, int n_codes,
+                                                 const float* __restrict__ pair_dist, float tie_scale, int* __restrict__ tie_count) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [D][NC] codebook^T, then [NC] norms, then [4][64] (d, idx, d2, idx2)
   constexpr int G = 4, CPG = NC / G;
   float* et = lds;
   float* ee = lds + (size_t)D * NC;
   float* bd = ee + NC;               // [G][64] best distance of the group
   int* bi = (int*)(bd + G * 64);     // [G][64] its code
+  float* bd2 = (float*)(bi + G * 64);  // [G][64] runner-up of the group (TIE only)
+  int* bi2 = (int*)(bd2 + G * 64);
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane;
@@ -58,32 +61,51 @@ __global__ void __launch_bounds__(256) vq_kernel(const float* __restrict__ z, co
 #pragma unroll
     for (int e = 0; e < CPG; ++e) dot[e] = fmaf(x, er[e], dot[e]);
   }
-  int best = -1;
-  float bestd = 0.f;
+  int best = -1, second = -1;
+  float bestd = 0.f, secondd = 0.f;
 #pragma unroll
   for (int e = 0; e < CPG; ++e) {
     if (e0 + e < n_codes) {
       const float dd = (xx + ee[e0 + e]) - 2.f * dot[e];
       if (dist_out && live) dist_out[((size_t)b * T + t) * n_codes + e0 + e] = dd;
       if (best < 0 || dd < bestd) {
+        if (TIE) second = best, secondd = bestd;
         bestd = dd;
         best = e0 + e;
+      } else if (TIE && (second < 0 || dd < secondd)) {
+        second = e0 + e, secondd = dd;
       }
     }
   }
   bd[grp * 64 + lane] = bestd;
   bi[grp * 64 + lane] = best;
+  if (TIE) bd2[grp * 64 + lane] = secondd, bi2[grp * 64 + lane] = second;
   __syncthreads();
   best = bi[lane];
   bestd = bd[lane];
+  if (TIE) second = bi2[lane], secondd = bd2[lane];
 #pragma unroll
   for (int g = 1; g < G; ++g) {
     const int cand = bi[g * 64 + lane];
     const float cd = bd[g * 64 + lane];
     if (cand >= 0 && cd < bestd) {
+      if (TIE) {          // the displaced best, or the group's own runner-up, is the runner-up so far
+        const int c2 = bi2[g * 64 + lane];
+        const float d2 = bd2[g * 64 + lane];
+        if (c2 >= 0 && d2 < bestd) second = c2, secondd = d2;
+        else second = best, secondd = bestd;
+      }
       bestd = cd;
       best = cand;
+    } else if (TIE && cand >= 0 && (second < 0 || cd < secondd)) {
+      second = cand, secondd = cd;
     }
+  }
+  if (TIE && live && grp == 0 && second >= 0) {
+    // near-tie of the two best codes: their gap is inside what the arithmetic's feature error (tie_scale * |z_t| per unit of
+    // code distance: asrbn.py calibrates it) can move the two distances against each other -> the utterance is decided again on the exact kernels
+    const float gap = secondd - bestd;
+    if (!(gap > tie_scale * sqrtf(xx) * pair_dist[best * n_codes + second])) atomicAdd(tie_count + b, 1);
   }
   if (!live) return;
   if (grp == 0) idx_out[(size_t)b * T + t] = best;
@@ -298,27 +320,33 @@ __global__ void __launch_bounds__(256) pcm16_to_f32_kernel(const short* __restri
 
 using namespace sat;
 
-extern "C" int sat_vq_argmin_gather_f32(const float* z, const float* codebook, float* q, int32_t* idx, float* dist,
-                                        int B, int D, int T, int n_codes, void* stream) {
+static int vq_launch(const float* z, const float* codebook, float* q, int32_t* idx, float* dist, const float* pair_dist, float tie_scale,
+                     int32_t* tie_count, int B, int D, int T, int n_codes, void* stream) {
   SAT_REQUIRE(z && codebook && q && idx, "vq: null pointer");
   SAT_REQUIRE(B > 0 && D > 0 && T > 0 && n_codes > 0 && n_codes <= VQ_MAX_CODES, "vq: unsupported sizes (n_codes <= %d)",
               VQ_MAX_CODES);
   dim3 grid(ceil_div(T, 64), B);
-  if (n_codes <= 48) {
-    const size_t lds = ((size_t)D * 48 + 48 + 512) * sizeof(float);
-    SAT_REQUIRE(lds <= 160 * 1024, "vq: codebook does not fit LDS");
-    if (lds > 64 * 1024)
-      SAT_HIP(hipFuncSetAttribute((const void*)vq_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(vq_kernel<48>, grid, dim3(256), lds, (hipStream_t)stream, z, codebook, q, idx, dist, D, T, n_codes);
-  } else {
-    const size_t lds = ((size_t)D * 64 + 64 + 512) * sizeof(float);
-    SAT_REQUIRE(lds <= 160 * 1024, "vq: codebook does not fit LDS");
-    if (lds > 64 * 1024)
-      SAT_HIP(hipFuncSetAttribute((const void*)vq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(vq_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, z, codebook, q, idx, dist, D, T, n_codes);
-  }
+  const bool tie = tie_count != nullptr;
+  const int nc = n_codes <= 48 ? 48 : 64;
+  const size_t lds = ((size_t)D * nc + nc + 1024) * sizeof(float);
+  SAT_REQUIRE(lds <= 160 * 1024, "vq: codebook does not fit LDS");
+  auto kern = nc == 48 ? (tie ? vq_kernel<48, true> : vq_kernel<48, false>) : (tie ? vq_kernel<64, true> : vq_kernel<64, false>);
+  if (lds > 64 * 1024) SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, z, codebook, q, idx, dist, D, T, n_codes, pair_dist, tie_scale, tie_count);
   SAT_LAUNCH_CHECK("vq_kernel");
   return SAT_OK;
+}
+
+extern "C" int sat_vq_argmin_gather_f32(const float* z, const float* codebook, float* q, int32_t* idx, float* dist,
+                                        int B, int D, int T, int n_codes, void* stream) {
+  return vq_launch(z, codebook, q, idx, dist, nullptr, 0.f, nullptr, B, D, T, n_codes, stream);
+}
+
+extern "C" int sat_vq_argmin_gather_tie_f32(const float* z, const float* codebook, float* q, int32_t* idx, float* dist,
+                                            const float* pair_dist, float tie_scale, int32_t* tie_count,
+                                            int B, int D, int T, int n_codes, void* stream) {
+  SAT_REQUIRE(pair_dist && tie_count && tie_scale >= 0.f, "vq(tie): pair_dist [n_codes][n_codes], tie_count [B] and a tie_scale >= 0");
+  return vq_launch(z, codebook, q, idx, dist, pair_dist, tie_scale, tie_count, B, D, T, n_codes, stream);
 }
 
 extern "C" int sat_f0_stats_f32(const float* f0, int n, float* stats, void* stream) {

@@ -1,6 +1,7 @@
 // HiFi-GAN generator forward on gfx950: orchestration over the fused conv1d kernel plus the
 // streaming output stage.  Reference: CoreHifiGan.forward_resnet, satools/satools/hifigan/
 // archi.py:77-91; ResBlock1.forward, satools/satools/hifigan/nn.py:179-186.
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -109,6 +110,52 @@ __global__ void __launch_bounds__(256) convpost_kernel(const float* __restrict__
   }
 }
 
+// planes S[b][c/16][4][t][16 B]: units 0, 1 of a chunk are the hi halves.  out[0] += values past `limit` or non-finite, out[1] = max bits of |hi|
+__global__ void __launch_bounds__(256) planes_range_kernel(const uint4* __restrict__ x, long long n_rows, int T, float limit,
+                                                           unsigned long long* __restrict__ out) {
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  unsigned long long cnt = 0;
+  float mx = 0.f;
+  const long long total = n_rows * T;          // rows = (utterance, chunk, hi unit)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / T;
+    const int t = (int)(i - row * T);
+    const long long chunk = row >> 1, unit = row & 1;
+    const h8v v = __builtin_bit_cast(h8v, x[(chunk * 4 + unit) * T + t]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float a = fabsf((float)v[k]);
+      if (!(a <= limit)) ++cnt;
+      if (a == a && a > mx) mx = a;
+    }
+  }
+  __shared__ unsigned long long sc[256];
+  __shared__ float sm[256];
+  sc[threadIdx.x] = cnt, sm[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sc[threadIdx.x] += sc[threadIdx.x + s];
+      sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (sc[0]) atomicAdd(out, sc[0]);
+    atomicMax(out + 1, (unsigned long long)__float_as_uint(sm[0]));
+  }
+}
+
+constexpr float SAT_RANGE_LIMIT = 57344.f;
+
+static int planes_range_probe(const void* planes, int B, int C, int T, unsigned long long* out, void* stream) {
+  const long long rows = (long long)B * (C / 16) * 2;
+  const int grid = (int)std::min<long long>(2048, (rows * T + 255) / 256);
+  hipLaunchKernelGGL(planes_range_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)planes, rows, T, SAT_RANGE_LIMIT, out);
+  SAT_LAUNCH_CHECK("planes_range_kernel");
+  return SAT_OK;
+}
+
 }  // namespace sat
 
 using namespace sat;
@@ -148,6 +195,10 @@ struct sat_hifigan {
   int fuse_mrf = 1;          // a whole MRF block (all branches, all steps, the mean) as one launch where mrf.hip supports the stage (C = 16)
   int split_acts = 1;
   int planes_residual = 1;
+  int force_f8 = 0;          // SAT_CONV_F16F8R stages at EVERY batch size (a calibration batch is too small for the ring kernel's default dispatch:
+                             // check_precision sets it on its own handle's forward instead of touching the process-wide "convring" option)
+  mutable std::atomic<int> last_f8_stages{0};   // bit i: stage i of the LAST forward ran its ResBlock convs with 8-bit cross terms
+  unsigned long long* range_probe = nullptr;    // device words [n_ups][2] (caller's): per stage, plane values past the 8-bit operand's range | max |hi| bits
   int n_ups() const { return (int)up_rates.size(); }
   int n_rbk() const { return (int)rb_kernels.size(); }
   int id_up(int i) const { return 1 + i; }
@@ -291,8 +342,40 @@ extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int valu
   if (std::string(name) == "split_acts") { h->split_acts = value; return SAT_OK; }
   if (std::string(name) == "planes_residual") { h->planes_residual = value; return SAT_OK; }
   if (std::string(name) == "branch_streams") { h->branch_streams = value; return SAT_OK; }
+  if (std::string(name) == "force_f8") { h->force_f8 = value; return SAT_OK; }
   set_error("hifigan_set_option: unknown option %s", name);
   return SAT_ERR_INVALID;
+}
+
+extern "C" int sat_hifigan_get_option(const sat_hifigan* h, const char* name, int* value) {
+  SAT_REQUIRE(h && name && value, "hifigan_get_option: null pointer");
+  const std::string n(name);
+  if (n == "last_f8_stages") { *value = h->last_f8_stages.load(std::memory_order_relaxed); return SAT_OK; }
+  if (n == "fuse_pairs") { *value = h->fuse_pairs; return SAT_OK; }
+  if (n == "fuse_pair64") { *value = h->fuse_pair64; return SAT_OK; }
+  if (n == "fuse_mrf") { *value = h->fuse_mrf; return SAT_OK; }
+  if (n == "multi_branch") { *value = h->multi_branch; return SAT_OK; }
+  if (n == "f8_stages") { *value = h->f8_stages; return SAT_OK; }
+  if (n == "mrf_exact") { *value = h->mrf_exact; return SAT_OK; }
+  if (n == "ups2") { *value = h->ups2; return SAT_OK; }
+  if (n == "ups_ring") { *value = h->ups_ring; return SAT_OK; }
+  if (n == "split_acts") { *value = h->split_acts; return SAT_OK; }
+  if (n == "planes_residual") { *value = h->planes_residual; return SAT_OK; }
+  if (n == "branch_streams") { *value = h->branch_streams; return SAT_OK; }
+  if (n == "force_f8") { *value = h->force_f8; return SAT_OK; }
+  set_error("hifigan_get_option: unknown option %s", name);
+  return SAT_ERR_INVALID;
+}
+
+// Range probe of the split planes a forward writes (diagnostic, off unless a buffer is installed): per stage i the words
+// buf[2 i] += number of hi values whose magnitude is past `SAT_RANGE_LIMIT` (57 344, the largest e5m2 = what the 8-bit sidecar saturates at;
+// f16 itself ends at 65 504) or not finite, buf[2 i + 1] = max over the bit patterns of |hi| as f32.  `buf` = 2 * n_ups device words the
+// caller zeroes; nullptr switches the probe off.  Probed: the ResBlock input of every stage, and in the thick stages every inner
+// activation and step output that exists as planes.
+extern "C" int sat_hifigan_set_range_probe(sat_hifigan* h, uint64_t* buf) {
+  SAT_REQUIRE(h, "hifigan_set_range_probe: null handle");
+  h->range_probe = (unsigned long long*)buf;
+  return SAT_OK;
 }
 
 extern "C" int sat_hifigan_convpost_f32(const float* x, const float* w, const float* bias, float* y, int B,
@@ -385,6 +468,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
     }
     int C = h->c0, Tc = T;
     const int nk = h->n_rbk();
+    int f8_mask = 0;
     for (int i = 0; i < h->n_ups(); ++i) {
       const int u = h->up_rates[i], k = h->up_kernels[i];
       const int Cn = C / 2, Tn = Tc * u;
@@ -392,11 +476,33 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
       // this stage's ResBlock convs with 8-bit cross terms (SAT_CONV_F16F8R): the one-launch-per-conv path of the thick stages, every
       // conv's second packing installed, and a batch the ring kernel would serve anyway (small batches keep the f16x3 tiles)
       bool use_f8 = ((h->f8_stages >> i) & 1) && h->multi_branch && planes_res_all && !(side && i < h->branch_streams) && nk >= 2 && nk <= 3 &&
-                    Cn > 64 && Cn % 32 == 0 && convring_wanted(Cn, Tn, B);
+                    Cn > 64 && Cn % 32 == 0 && (h->force_f8 || convring_wanted(Cn, Tn, B));
       for (int j = 0; j < nk && use_f8; ++j)
         for (int pair = 0; pair < 3; ++pair)
           use_f8 = use_f8 && h->convs[h->id_rb(i, j, pair, 0)].w8 && h->convs[h->id_rb(i, j, pair, 1)].w8 &&
                    (h->rb_kernels[j] - 1) * h->rb_dil[j * 3 + pair] <= 64 && h->rb_kernels[j] >= 3;
+      // ... and every descriptor of the stage asked of the ring kernel itself (convring_supports has more conditions than
+      // convring_wanted — 31-bit output slabs for the fast epilogue, an even step count, ...): a stage one of whose convs it would
+      // refuse keeps the f16x3 packing, whose dispatch has the register-staged tiles to fall back on (round-5 advisor item)
+      for (int j = 0; j < nk && use_f8; ++j)
+        for (int pair = 0; pair < 3 && use_f8; ++pair)
+          for (int which = 0; which < 2 && use_f8; ++which) {
+            const int rk = h->rb_kernels[j], dil = which ? 1 : h->rb_dil[j * 3 + pair];
+            const auto& cv = h->convs[h->id_rb(i, j, pair, which)];
+            sat_conv1d_desc d = base_desc(Cn, Cn, Tn, Tn, 1);
+            d.ksize = rk, d.dilation = dil, d.pad_left = (rk * dil - dil) / 2;
+            d.bias = cv.bias, d.w_descale = cv.descale, d.mode = SAT_CONV_F16F8R;
+            d.x_split = ws, d.x_split8 = ws, d.y_split = ws, d.y_split8 = ws, d.y_split_slope = 0.1f;   // (placeholders: nothing is launched)
+            d.no_y = 1;
+            if (which) {
+              d.in_lrelu = 1, d.in_slope = 0.1f, d.res_split = ws, d.res_split_slope = 0.1f, d.res_scale = 1.f;
+              if (pair == 2) d.no_y = 0, d.accum = j > 0, d.accum_div = j == nk - 1 ? (float)nk : 0.f, d.y_split8 = nullptr, d.y_split = (j == nk - 1 && !last_stage) ? ws : nullptr;
+            } else {
+              d.y_split_hi_only = 1;
+            }
+            use_f8 = sat_conv1d_f8r_supported(&d) != 0;
+          }
+      if (use_f8) f8_mask |= 1 << i;
       // 8-bit (e5m2) sidecars (half a slot each: 2 bytes per element) in the slots of the f32 twins this pipeline does not write
       void* Hs8 = ws + 0 * slot;
       auto br8 = [&](int j, int which) { return ws + (size_t)(5 + j * 5 + (which < 2 ? 1 : 3)) * slot + (which == 1 ? slot / 2 : 0); };   // 0 T1, 1 RA, 2 RB
@@ -446,6 +552,10 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
         }
         if (use_f8 && !d.y_split8) {
           s = sat_planes_f8_sidecar(Hs, Hs8, B, Cn, Tn, stream);      // (Hf is dead behind the split pass)
+          if (s != SAT_OK) return s;
+        }
+        if (h->range_probe) {
+          s = planes_range_probe(Hs, B, Cn, Tn, h->range_probe + 2 * i, stream);
           if (s != SAT_OK) return s;
         }
       }
@@ -565,6 +675,11 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             if (s != SAT_OK) return s;
             s = sat_conv1d_multi_f32(d2, xnull, w2, y2, nk, stream);
             if (s != SAT_OK) return s;
+            for (int j = 0; j < nk && h->range_probe; ++j) {
+              s = planes_range_probe(br(j, 0), B, Cn, Tn, h->range_probe + 2 * i, stream);
+              if (s == SAT_OK && dst_s[j]) s = planes_range_probe(dst_s[j], B, Cn, Tn, h->range_probe + 2 * i, stream);
+              if (s != SAT_OK) return s;
+            }
             for (int j = 0; j < nk; ++j) rs[j] = dst_s[j], rs8[j] = dst8[j];
           }
           void* t = XS;
@@ -673,8 +788,10 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
       C = Cn;
       Tc = Tn;
     }
+    h->last_f8_stages.store(f8_mask, std::memory_order_relaxed);
     return sat_hifigan_convpost_f32(ACCf, (const float*)h->convs[h->id_post()].w, h->convs[h->id_post()].bias, y, B, C, Tc, stream);
   }
+  h->last_f8_stages.store(0, std::memory_order_relaxed);
 
   // conv_pre (archi.py:78)
   {

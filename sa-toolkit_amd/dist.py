@@ -102,7 +102,7 @@ class ChunkedGather:
         if all(n == lens[0] for n in lens):
             views = [self.out[self.starts[r] + spans[r][0]: self.starts[r] + spans[r][1]] for r in range(self.world)]
             work = dist.all_gather(views, local_chunk.contiguous(), group=self.group, async_op=True)
-            self.pending.append((work, None))
+            self.pending.append((work, None, ()))
         else:
             mx = max(lens)
             mine = local_chunk
@@ -115,19 +115,29 @@ class ChunkedGather:
                 for r in range(self.world):
                     if lens[r]:
                         self.out[self.starts[r] + spans[r][0]: self.starts[r] + spans[r][1]].copy_(parts[r][:lens[r]])
-            self.pending.append((work, place))
+            self.pending.append((work, place, tuple(parts)))
         self.stats.append({"chunk": c, "rows": lens[self.rank], "issue_ms": (time.perf_counter() - t0) * 1e3})
 
     def finish(self):
         """wait for every chunk (the current stream waits for the collectives), place padded chunks; -> [n_items, ...]"""
         import time
-        for i, (work, place) in enumerate(self.pending):
+        # `out` and the padded chunks' `parts` were allocated under the caller's `before_chunk` context, i.e. (on the GPUs) on the
+        # communication stream; from here on they are read and written on the CURRENT stream.  The caching allocator knows a block
+        # only by the stream it was allocated on: without `record_stream` it could hand the block to the next allocation on the
+        # communication stream (a later `transform(piece)`) while the current stream still works on it.
+        cur = torch.cuda.current_stream() if self.out is not None and self.out.is_cuda else None
+        for i, (work, place, parts) in enumerate(self.pending):
             t0 = time.perf_counter()
             work.wait()
+            if cur is not None:
+                for p in parts:
+                    p.record_stream(cur)
             if place is not None:
                 place()
             self.stats[i]["wait_ms"] = (time.perf_counter() - t0) * 1e3
         self.pending = []
+        if cur is not None:
+            self.out.record_stream(cur)
         return self.out.view(torch.int16) if self._int16 else self.out
 
 

@@ -55,6 +55,9 @@ class CoreHifiGan(CoreHifiGanParams):
     #: what is needed; raise SATOOLS_AMD_GEN_MAX_WORKSPACES for more concurrent streams
     max_workspaces = int(os.environ.get("SATOOLS_AMD_GEN_MAX_WORKSPACES", "8"))
 
+    #: "f16f8r" at EVERY batch size (the calibration batch of Net.check_precision is too small for the ring kernel's default dispatch)
+    force_f8 = 0
+
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._handle = None
@@ -162,6 +165,7 @@ class CoreHifiGan(CoreHifiGanParams):
         check(l.sat_hifigan_set_option(self._handle, b"fuse_mrf", int(self.fuse_mrf)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"multi_branch", int(self.multi_branch)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"ups2", int(self.ups2)), "sat_hifigan_set_option")
+        check(l.sat_hifigan_set_option(self._handle, b"force_f8", int(self.force_f8)), "sat_hifigan_set_option")
         # (a frozen model brings the row order its weights were packed in)
         self._packed_ups_grouped = self._ups_grouped() if ups_grouped is None else bool(ups_grouped)
         check(l.sat_hifigan_set_option(self._handle, b"ups_ring", int(self._packed_ups_grouped)), "sat_hifigan_set_option")
@@ -194,6 +198,54 @@ class CoreHifiGan(CoreHifiGanParams):
             ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
             self._ws[key] = ws
         return ws, need
+
+    # -- which arithmetic ran / what range it saw ------------------------------------------------
+    def set_force_f8(self, value):
+        """option force_f8 of the C handle (no re-packing: the second packings are installed whenever `precision` is "f16f8r")"""
+        self.force_f8 = int(bool(value))
+        if self._handle is not None:
+            check(lib().sat_hifigan_set_option(self._handle, b"force_f8", self.force_f8), "sat_hifigan_set_option")
+
+    @property
+    def last_arithmetic(self):
+        """arithmetic of the ResBlock convs in this generator's LAST forward: "f32", "f16x3", "f16f8", or "f16f8r(stages i,j)" when
+        stages i, j ran with 8-bit cross terms (a batch too small for the ring kernel runs "f16x3" although `precision` says
+        "f16f8r": the same utterance alone and inside a batch of 32 differ by the mode, ~1e-6 on the waveform)"""
+        if self._handle is None:
+            return None
+        if self.precision in ("f32", "f16f8", "f16x3"):
+            return self.precision
+        v = C.c_int(0)
+        check(lib().sat_hifigan_get_option(self._handle, b"last_f8_stages", C.byref(v)), "sat_hifigan_get_option")
+        if not v.value:
+            return "f16x3"
+        return "f16f8r(stages " + ",".join(str(i + 1) for i in range(len(self.upsample_rates)) if (v.value >> i) & 1) + ")"     # (stage 1 = C 256)
+
+    def range_probe(self, x):
+        """one forward of x with the planes it writes probed (sat_hifigan_set_range_probe): per stage the number of hi halves past
+        57 344 (the largest e5m2, where the 8-bit sidecar of "f16f8r" saturates; f16 ends at 65 504) or not finite, and the largest
+        |hi| seen.  -> {"past_e5m2_max": [per stage], "max_abs": [per stage]}.  Diagnostic of Net.check_precision."""
+        n = len(self.upsample_rates)
+        buf = torch.zeros(2 * n, dtype=torch.int64, device=x.device)
+        self._prepare(x.device)
+        check(lib().sat_hifigan_set_range_probe(self._handle, ptr(buf)), "sat_hifigan_set_range_probe")
+        try:
+            self.forward_resnet(x)
+        finally:
+            check(lib().sat_hifigan_set_range_probe(self._handle, None), "sat_hifigan_set_range_probe")
+        w = buf.cpu()
+        mx = (w[1::2] & 0xFFFFFFFF).to(torch.int32).view(torch.float32)
+        return {"past_e5m2_max": [int(v) for v in w[0::2]], "max_abs": [float(v) for v in mx]}
+
+    def f8_weight_stats(self):
+        """what the e4m3 cross-term operands of the installed "f16f8r" packings lose: {"values", "clipped" (|v| > 448: none by
+        construction of the layer scale), "flushed" (non-zero values below e4m3's smallest subnormal), "subnormal" (kept with fewer
+        than 4 significant bits: rows whose gain lies far below the layer's largest)} summed over the convs (packing.pack_conv_weight_f16f8r)"""
+        tot = {"values": 0, "clipped": 0, "flushed": 0, "subnormal": 0}
+        for w8 in (getattr(self, "_packed8", None) or {}).values():
+            for k, v in getattr(w8, "f8_stats", {}).items():
+                tot[k] += v
+        return tot
 
     # -- reference interface ----------------------------------------------------------------
     def forward_resnet(self, x):

@@ -101,4 +101,7 @@ def load_model(file, load_weight=True, version="v1", from_file=None, option_args
     net = build(SimpleNamespace(**model_args))(**model_state["base_model_params"])
     if load_weight:
         net.load_state_dict(model_state["base_model_state_dict"])
+        if hasattr(net, "check_precision"):
+            # a real checkpoint (not `synthetic:`): its first `.to("cuda")` runs the precision guard once (anonymizer.Net._apply)
+            net.__dict__["_precision_check_pending"] = True
     return net

@@ -132,6 +132,22 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
                                 f"({'no record on the packed tensor' if have is None else hex(int(have))}: pack with packing.pack_conv_weight_f16x3(..., up=4) "
                                 "from packing.convtranspose_as_phase_conv(..., grouped=True))")
     d.up_grouped, d.up_zero_taps = int(bool(up_grouped)), int(up_zero_taps)
+    if int(mode) == _lib.CONV_F16F8R:
+        # the ring kernel moves these buffers by LDS-DMA at offsets derived from the SHAPES: a packing of the other kind (half the
+        # bytes) or a short sidecar would be read / written past its end, not refused (round-5 advisor item)
+        ci = int(d.C_in)
+        nq = (-(-ci // 32) * ksize + 1) // 2
+        co_pad = -(-c_out // 64) * 64
+        want = 2 * nq * 8 * co_pad * 16
+        if w_packed.dtype != torch.uint8 or w_packed.numel() != want:
+            raise _lib.SatError(f"conv1d(f16f8r): w_packed must be the packing of packing.pack_conv_weight_f16f8r for [{c_out}, {ci}, {ksize}] "
+                                f"({want} bytes of uint8), got {w_packed.numel()} elements of {w_packed.dtype}")
+        if x_split is None or x_split.numel() * x_split.element_size() < B * ci * t_in * 4:
+            raise _lib.SatError(f"conv1d(f16f8r): x_split must hold the planes of [{B}, {ci}, {t_in}] ({B * ci * t_in * 4} bytes)")
+        if x_split8 is None or x_split8.numel() * x_split8.element_size() < B * ci * t_in * 2:
+            raise _lib.SatError(f"conv1d(f16f8r): x_split8 must hold the sidecar of [{B}, {ci}, {t_in}] ({B * ci * t_in * 2} bytes: ops.sidecar_like)")
+    if y_split8 is not None and y_split8.numel() * y_split8.element_size() < B * c_out * t_q * up * 2:
+        raise _lib.SatError(f"conv1d: y_split8 must hold the sidecar of [{B}, {c_out}, {t_q * up}] ({B * c_out * t_q * up * 2} bytes: ops.sidecar_like)")
     d.x_split8, d.y_split8, d.y_split_hi_only = ptr(x_split8), ptr(y_split8), int(bool(y_split_hi_only))
     return d, x, out, res      # (res: the possibly re-laid-out residual must outlive the launch)
 
@@ -159,13 +175,22 @@ def fbank_cmvn_pad(wav, window, mel, mel_lo, mel_hi, *, scale=32768.0, pad=0, cm
     return out
 
 
-def vq(z, codebook, want_dist=False):
+def vq(z, codebook, want_dist=False, tie=None):
+    """`tie` = (pair_dist [n_codes, n_codes], tie_scale, tie_count [B] int32): also count, per utterance, the frames whose two best
+    codes are a near-tie (sat_vq_argmin_gather_tie_f32)"""
     z = _f32c(z)
     B, D, T = z.shape
     n_codes = codebook.shape[0]
     q = torch.empty_like(z)
     idx = torch.empty(B, T, dtype=torch.int32, device=z.device)
     dist = torch.empty(B, T, n_codes, dtype=torch.float32, device=z.device) if want_dist else None
+    if tie is not None:
+        pair, scale, count = tie
+        if tuple(pair.shape) != (n_codes, n_codes) or pair.dtype != torch.float32 or count.dtype != torch.int32 or count.numel() != B:
+            raise _lib.SatError("vq: tie = (pair_dist [n_codes, n_codes] f32, tie_scale, tie_count [B] int32)")
+        check(lib().sat_vq_argmin_gather_tie_f32(ptr(z), ptr(codebook), ptr(q), ptr(idx), ptr(dist), ptr(pair), float(scale), ptr(count),
+                                                 B, D, T, n_codes, stream()), "sat_vq_argmin_gather_tie_f32")
+        return q, idx, dist
     check(lib().sat_vq_argmin_gather_f32(ptr(z), ptr(codebook), ptr(q), ptr(idx), ptr(dist), B, D, T, n_codes,
                                          stream()), "sat_vq_argmin_gather_f32")
     return q, idx, dist

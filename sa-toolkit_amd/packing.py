@@ -207,12 +207,23 @@ def pack_conv_weight_f16f8r(w: torch.Tensor) -> torch.Tensor:
     e_img = linear(hi).reshape(nq, 2, 2, 2, 8, co_pad).permute(0, 1, 2, 3, 5, 4).contiguous()
     e_img = e_img.view(torch.uint8).reshape(nq, 8, co_pad, 16)
 
+    stats = {"values": 0, "clipped": 0, "flushed": 0, "subnormal": 0}
+
     def e4m3(t, exp):                                                # -> [q][j][c][co][16] bytes
-        q = (linear(t).to(torch.float32) * float(2.0 ** exp)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        v = linear(t).to(torch.float32) * float(2.0 ** exp)
+        q8 = v.clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+        # what the 8-bit operand loses (Net.check_precision reports it): clipped at 448, flushed to zero, kept as a subnormal (< 2^-6)
+        a = v.abs()
+        stats["values"] += int((a > 0).sum())
+        stats["clipped"] += int((a > 448.0).sum())
+        stats["flushed"] += int(((a > 0) & (q8.to(torch.float32) == 0)).sum())
+        stats["subnormal"] += int(((a > 0) & (a < 2.0 ** -6)).sum())
+        q = q8.view(torch.uint8)
         return q.reshape(nq, 2, 2, 16, co_pad).permute(0, 1, 2, 4, 3).contiguous()
 
     o_img = torch.stack([e4m3(lo, F8R_W_LO_EXP), e4m3(hi, F8R_W_HI_EXP)], dim=2)       # [q][j][term][c][co][16]
     o_img = o_img.reshape(nq, 8, co_pad, 16)
     out = torch.stack([e_img, o_img], dim=1).reshape(2 * nq, 8, co_pad, 16).contiguous()
     out.w_descale = float(2.0 ** -e)
+    out.f8_stats = stats
     return out

@@ -172,7 +172,15 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             return self._w2
         if self.w2v2_precision not in ("f16x3", "f32"):
             raise _lib.SatError(f"unknown wav2vec2 precision {self.w2v2_precision!r}")
-        _lib.cache_rebuild_begin(device, self._w2 is not None)
+        # one packing per precision is kept (asrbn._TdnnfBase._prepare: the near-tie guard switches to the exact kernels for single utterances)
+        store = self.__dict__.setdefault("_w2_store", {})
+        if self._w2_key is not None:
+            store[self._w2_key[0]] = (self._w2_key, self._w2, self._mm_mode)
+        hit = store.get(self.w2v2_precision)
+        if hit is not None and hit[0] == key:
+            self._w2_key, self._w2, self._mm_mode = hit
+            return self._w2
+        _lib.cache_rebuild_begin(device, hit is not None)
         split = self.w2v2_precision == "f16x3"
         pack_mm = packing.pack_conv_weight_f16x3 if split else packing.pack_conv_weight
         self._mm_mode = _lib.CONV_F16X3 if split else _lib.CONV_F32
@@ -353,16 +361,46 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         feats = ops.pad_replicate(feats, 0, 1)                                      # F.pad(.., (0, 1), "replicate")
         return ops.pad_replicate(feats, self.padding, self.padding, interleave_right=True)   # pad_input
 
-    def _extract_bn_private(self, x):
-        return self.extract_bn(x)            # this tag never mutates its input
+    def _extract_bn_private(self, x, defer_ties=False):
+        with self._lock():
+            return self._bn_guarded(self.features(x), x, defer_ties)            # this tag never mutates its input
+
+    def _bn_guarded(self, feats, wav, defer_ties=False):
+        """stack + VQ with the near-tie guard (asrbn.TdnnfVqNet._bn_guarded)"""
+        out, status = self._run_stack_guarded(feats)
+        bn = out.permute(0, 2, 1)
+        st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0})
+        st["utterances"] += bn.shape[0] if status is not None else 0
+        if defer_ties:
+            return bn, (lambda: self.resolve_ties(status, bn, feats, wav))
+        self.resolve_ties(status, bn, feats, wav)
+        return bn
+
+    def _features_of(self, x):
+        return self.features(x)
+
+    def _exact_rows(self, rows, feats, wav, want_aux=False):
+        """flagged utterances again on the exact-f32 kernels: the encoder is recomputed for those rows; their frames and their own
+        replicated frames (left pad, the 250th frame) replace the split-f16 ones in a copy of the batch's padded features, the
+        right-hand pad frames — `pad_input` tiles the last frames of ALL utterances of the batch there (tdnnf_vq.py:228-234) — stay the
+        batch's (another row's frames are not recomputed)"""
+        with self._exact(self):
+            f = self.w2v2_features(wav[rows].to(torch.float32).contiguous())      # [n, 1024, 249]
+            sub = feats[rows].contiguous()
+            p, T = self.padding, f.shape[2]
+            sub[:, :, p:p + T] = f
+            sub[:, :, p + T] = f[:, :, -1]
+            sub[:, :, :p] = f[:, :, :1]
+            return self._run_stack(sub, want_aux=want_aux)
 
     def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
         """inputs [N, n] in [-1, 1] (no 32768 scaling on this tag) -> [N, T, 256]
         (tdnnf_wav2vec2_vq.py:289-314)"""
-        out = self._run_stack(self.features(x), want_aux=want_aux)
-        if want_aux:
+        if want_aux:                           # diagnostics: the arithmetic as configured, no second decision
+            out = self._run_stack(self.features(x), want_aux=True)
             return out[0].permute(0, 2, 1), out[1]
-        return out.permute(0, 2, 1)
+        with self._lock():
+            return self._bn_guarded(self.features(x), x)
 
     def forward(self, x):
         """waveforms [N, n] in [-1, 1] -> (chain_out, log_softmax(xent_out)), each [N, T', output_dim]

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.lib()
     header = open(os.path.join(ROOT, "include", "satools_hip.h")).read()
-    assert lib.sat_abi_version() == int(re.search(r"#define SAT_ABI_VERSION (\d+)", header).group(1)) == 6
+    assert lib.sat_abi_version() == int(re.search(r"#define SAT_ABI_VERSION (\d+)", header).group(1)) == 7
     declared = set(re.findall(r"\b(sat_[a-z0-9_]+)\s*\(", header))
     declared -= {"sat_status"}
     assert declared, "no declarations parsed"
@@ -401,6 +401,27 @@ def test_gpu_count_without_the_hip_runtime(monkeypatch):
     assert anonymize.parse_ngpu("[0, 3]") == ["0", "3"]
     import inspect
     assert "torch" not in inspect.getsource(anonymize.parse_ngpu) and "torch" not in inspect.getsource(anonymize.visible_gpu_count)
+
+
+def test_gpu_count_only_counts_render_nodes_this_process_can_open(tmp_path):
+    """sysfs lists every GPU of the machine; a container given only some /dev/dri/renderD* nodes must count those
+    (round-5 advisor item): a fake KFD topology of one CPU node and three GPUs, two of whose render nodes exist"""
+    from satools_amd import anonymize
+    props = []
+    for i, (simd, minor) in enumerate([(0, -1), (1024, 128), (1024, 129), (1024, 130)]):
+        d = tmp_path / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+        props.append(str(d / "properties"))
+    dri = tmp_path / "dri"
+    dri.mkdir()
+    (dri / "renderD128").write_text("")
+    (dri / "renderD130").write_text("")
+    assert anonymize._count_kfd_gpus(props, str(dri), []) == 2
+    (dri / "renderD129").write_text("")
+    assert anonymize._count_kfd_gpus(props, str(dri), []) == 3
+    assert anonymize._count_kfd_gpus(props, str(tmp_path / "no_such_dir"), []) == 3      # no render directory at all: the topology decides
+    assert anonymize._count_kfd_gpus([], str(dri), []) == 0
 
 
 def test_ragged_yaapt_length_dims_are_the_plans():

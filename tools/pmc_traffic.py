@@ -26,8 +26,11 @@ def main():
     w2v2 = len(sys.argv) > 3 and sys.argv[3] == "w2v2"
     if w2v2:
         return main_w2v2(fetch, write, int(sys.argv[4]) if len(sys.argv) > 4 else 5)
-    gen = lambda n: ("conv1d_f16x3" in n or "resblock_pair" in n or "convpost" in n or "act_split" in n or "mrf" in n or "ups2_kernel" in n or "pair32" in n)
-    # generator forwards in that run: 3 convert() steps + 1 warm + 3 timed forwards of the roofline probe
+    # every kernel of the run that is not torch's (`at::`: the load-time fold / pack of the weights) or the runtime's: tools/gen_only.py
+    # launches nothing but generator forwards.  (Rounds 1-5 kept a list of name fragments here, which `pairw_kernel` and
+    # `planes_f8_sidecar_kernel` matched none of: the round-4 / round-5 totals lack their 1.5-2.5 GB.)
+    gen = lambda n: not (n.startswith("at::") or "rocclr" in n or n.startswith("void at::"))
+    # generator forwards in that run = launches of the output stage
     n_post = max(1, sum(v[0] for k, v in fetch.items() if "convpost_kernel" in k))
     out = {"generator_forwards_in_run": n_post, "kernels": {}}
     tot_f = tot_w = 0.0
