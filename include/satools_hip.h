@@ -189,6 +189,9 @@ typedef struct {
   void* y_split8;          /* also write the e4m3 sidecar of y_split (k-tap convs and up_grouped upsamplers served by the LDS-DMA ring
                               kernel, SAT_CONV_F16X3 or SAT_CONV_F16F8R), or NULL */
   int32_t y_split_hi_only; /* with y_split8: do not store the lo units of y_split (a tensor that is only ever an F16F8R operand) */
+  int32_t accum_no_store;  /* ABI 7, with accum and y_split: y is READ (the running MRF sum, hifigan/archi.py:82-86) but the new sum is not
+                              written back — the last branch of a stage whose successor only takes the planes of the mean (y_split):
+                              nobody reads that f32 tensor again (164 MB per launch at the 64- and 32-channel stages) */
 } sat_conv1d_desc;
 
 /* 1 when sat_conv1d_f32 / sat_conv1d_multi_f32 serve this SAT_CONV_F16F8R descriptor (the LDS-DMA ring kernel's shapes and epilogues), else 0 */

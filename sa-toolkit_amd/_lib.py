@@ -43,6 +43,7 @@ class ConvDesc(C.Structure):
         ("w_descale", C.c_float),
         ("up_grouped", C.c_int32), ("up_zero_taps", C.c_uint32),
         ("x_split8", C.c_void_p), ("y_split8", C.c_void_p), ("y_split_hi_only", C.c_int32),
+        ("accum_no_store", C.c_int32),
     ]
 
 

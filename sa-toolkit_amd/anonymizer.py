@@ -195,9 +195,18 @@ def build(args):
             out = y.squeeze(0)
 
             def patch(rows):
-                bn, f0_d, spk = ctx
+                bn, f0_d, spk, arith = ctx
                 xs = ops.assemble_input(bn[rows].contiguous(), f0_d[rows].reshape(len(rows), -1).contiguous(), spk[rows].contiguous(), spk.shape[1])
-                ys, _ = self.hifigan(xs)
+                # in the arithmetic the batch ran: a few rows are too small a batch for the ring kernel's default dispatch and would run
+                # "f16x3" where the batch ran "f16f8r" — a row whose indices did not change then keeps its bits
+                f8 = (arith or "").startswith("f16f8r") and not self.hifigan.force_f8
+                if f8:
+                    self.hifigan.set_force_f8(1)
+                try:
+                    ys, _ = self.hifigan(xs)
+                finally:
+                    if f8:
+                        self.hifigan.set_force_f8(0)
                 y[rows] = ys.to(torch.float32)
 
             st = ConvertStatus(f0_status, fix, patch if fix is not None else None, torch.cuda.current_stream(y.device), bool(defer_status))
@@ -427,9 +436,9 @@ def build(args):
             assert B == spk.shape[0], \
                 "len(target) != len(input_wav), check if the waveform batch size == target=len(['6081','4214'])"
             x = ops.assemble_input(bn, f0_d.reshape(B, -1), spk, spk.shape[1])
-            if self._keep_ctx:            # convert(): the rows of near-tie utterances are assembled and generated again (_finish)
-                self._fwd_ctx = (bn, f0_d, spk)
             y, _ = self.hifigan(x)
+            if self._keep_ctx:            # convert(): the rows of near-tie utterances are assembled and generated again (_finish)
+                self._fwd_ctx = (bn, f0_d, spk, self.hifigan.last_arithmetic)
             return y.to(torch.float32)
 
         def forward(self, egs_with_feat):

@@ -81,7 +81,7 @@ class TieStatus:
     row behind the launch, `rows()` waits for them (the VQ runs before the generator: by the time a caller has enqueued the rest of
     `convert()` they have usually landed) and names the utterances to decide again on the exact-f32 kernels."""
 
-    def __init__(self, counts_dev):
+    def __init__(self, counts_dev, idx_dev):
         from .f0 import _pinned_ints
         self._pool = _pinned_ints
         self.host, self.row = _pinned_ints.take(counts_dev.numel())
@@ -89,6 +89,7 @@ class TieStatus:
         self.event = torch.cuda.Event()
         self.event.record()
         self.counts = None
+        self.idx = idx_dev             # [B, T'] indices of the arithmetic as configured (device)
 
     def rows(self):
         if self.counts is None:
@@ -106,6 +107,14 @@ class TieStatus:
                 self._pool.give(self.row)
         except Exception:
             pass
+
+
+class _TieCtx:
+    """what the VQ layer of a guarded run is handed (pair distances, window, per-utterance counts) and hands back (its indices)"""
+    __slots__ = ("pair", "scale", "counts", "idx")
+
+    def __init__(self, pair, scale, counts):
+        self.pair, self.scale, self.counts, self.idx = pair, scale, counts, None
 
 
 class _LayerCache:
@@ -127,7 +136,7 @@ class _TdnnfBase(nn.Module):
     #: on the device, and its utterance is decided again on the exact-f32 kernels — so the default arithmetic returns the exact
     #: kernels' indices (536-utterance sweep per tag: tests/test_hip_robust.py).  0 switches the guard off; frozen models (no f32
     #: parameters to fall back on) run without it.
-    vq_tie_sigmas = float(os.environ.get("SATOOLS_AMD_VQ_TIE_SIGMAS", "6"))
+    vq_tie_sigmas = float(os.environ.get("SATOOLS_AMD_VQ_TIE_SIGMAS", "4"))
 
     def _init_cache(self):
         self._cache = None
@@ -236,7 +245,9 @@ class _TdnnfBase(nn.Module):
                            x_split=xs if planes_in else None)
         aux = None
         if c.codebook is not None:
-            zq, idx, dist = ops.vq(z, c.codebook, want_dist=want_aux, tie=tie)
+            zq, idx, dist = ops.vq(z, c.codebook, want_dist=want_aux, tie=None if tie is None else (tie.pair, tie.scale, tie.counts))
+            if tie is not None:
+                tie.idx = idx
             aux = (z, idx, dist)
             z = zq
         if return_bottleneck:
@@ -351,9 +362,9 @@ class _TdnnfBase(nn.Module):
         guard = self._tie_guard(feats.device)
         if guard is None:
             return self._run_stack(feats, want_aux=want_aux), None
-        counts = torch.zeros(feats.shape[0], dtype=torch.int32, device=feats.device)
-        out = self._run_stack(feats, want_aux=want_aux, tie=(guard[0], guard[1], counts))
-        return out, TieStatus(counts)
+        ctx = _TieCtx(guard[0], guard[1], torch.zeros(feats.shape[0], dtype=torch.int32, device=feats.device))
+        out = self._run_stack(feats, want_aux=want_aux, tie=ctx)
+        return out, TieStatus(ctx.counts, ctx.idx)
 
     def _exact_rows(self, rows, feats, wav, want_aux=False):
         """the quantised bottleneck [len(rows), D, T'] of utterances `rows` on the exact-f32 kernels, from the batch's padded features
@@ -361,27 +372,49 @@ class _TdnnfBase(nn.Module):
         with self._exact(self):
             return self._run_stack(feats[rows].contiguous(), want_aux=want_aux)
 
+    #: tests: treat every flagged utterance as changed (the rows are rewritten and the caller generates them again)
+    vq_tie_force_patch = False
+
     def resolve_ties(self, status, bn, feats, wav, idx=None):
-        """decide the flagged utterances of `status` again on the exact kernels and write their rows into `bn` ([B, T', D] view of the
-        stack's output, as extract_bn returns it) and, when given, their VQ indices into `idx` [B, T']; -> the rows (empty list:
-        nothing to do).  Waits for the VQ launch of the batch."""
+        """Decide the flagged utterances of `status` again on the exact kernels; those whose indices CHANGE get their rows of `bn`
+        ([B, T', D] view of the stack's output, as extract_bn returns it) rewritten, and their VQ indices written into `idx` [B, T'] when
+        given.  -> the changed rows (empty list: nothing for the caller to redo).
+        The exact run goes to a side stream that waits for the batch's VQ launch only — not for what the caller has enqueued behind it
+        (the generator) — and the host waits for that side stream: a flagged utterance costs its extractor again (2 % of the 5 s
+        utterances at the default window), a changed one (a few per thousand) also what the caller derives from its rows."""
         if status is None:
             return []
         rows = status.rows()
-        if rows:
-            self.__dict__["_tie_busy"] = True
-            try:
-                if idx is None:
-                    bn[rows] = self._exact_rows(rows, feats, wav).permute(0, 2, 1)
-                else:
-                    zq, (_, idx_x, _) = self._exact_rows(rows, feats, wav, want_aux=True)
-                    bn[rows] = zq.permute(0, 2, 1)
-                    idx[rows] = idx_x
-            finally:
-                self.__dict__["_tie_busy"] = False
-            st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0})
-            st["rerun"] += len(rows)
-        return rows
+        st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0, "changed": 0})
+        if not rows:
+            return []
+        dev = feats.device
+        cur = torch.cuda.current_stream(dev)
+        sides = self.__dict__.setdefault("_tie_streams", {})
+        side = sides.get(cur.cuda_stream)
+        if side is None:
+            side = sides[cur.cuda_stream] = torch.cuda.Stream(device=dev)
+        side.wait_event(status.event)              # feats, wav and the indices precede the VQ launch's event on `cur`
+        self.__dict__["_tie_busy"] = True
+        try:
+            with torch.cuda.stream(side):
+                zq, (_, idx_x, _) = self._exact_rows(rows, feats, wav, want_aux=True)
+                changed = (idx_x != status.idx[rows]).any(dim=1)
+                flags = [True] * len(rows) if self.vq_tie_force_patch else changed.cpu().tolist()      # (waits for the side stream)
+        finally:
+            self.__dict__["_tie_busy"] = False
+        st["rerun"] += len(rows)
+        sel = [i for i, c in enumerate(flags) if c]
+        hit = [rows[i] for i in sel]
+        st["changed"] = st.get("changed", 0) + len(hit)
+        if hit:
+            cur.wait_stream(side)
+            zq.record_stream(cur)
+            idx_x.record_stream(cur)
+            bn[hit] = zq[sel].permute(0, 2, 1)
+            if idx is not None:
+                idx[hit] = idx_x[sel]
+        return hit
 
     # ---- the ASR half: Net.forward up to the chain / xent outputs (SURVEY 8 f4) --------------------------
     def _prepare_full(self, device):
@@ -546,7 +579,7 @@ class TdnnfVqNet(_TdnnfBase):
         once the rest of its launches are enqueued, and repeats what it derived from those rows of bn)"""
         out, status = self._run_stack_guarded(feats)
         bn = out.permute(0, 2, 1)
-        st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0})
+        st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0, "changed": 0})
         st["utterances"] += bn.shape[0] if status is not None else 0
         if defer_ties:
             return bn, (lambda: self.resolve_ties(status, bn, feats, wav))

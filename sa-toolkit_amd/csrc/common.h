@@ -121,6 +121,55 @@ __device__ __forceinline__ void gelu_fast4(float (&v)[4]) {
   v[0] = a[0], v[1] = a[1], v[2] = b[0], v[3] = b[1];
 }
 
+// ---- f16 halves <-> f32 in ONE instruction (v_fma_mix_f32: an fma whose operands may be f16 halves of a register, widened exactly).
+// hipcc folds fma(fpext(h), c, x) into it only when f32 denormals are flushed (not this build's mode): the split / decode steps of every
+// epilogue compiled to v_cvt_f32_f16 + v_add / v_sub — two or three instructions per value where one does, with the SAME result:
+// the f16 -> f32 widening is exact, so fma(h, 1, l) is the once-rounded sum (float)h + (float)l and fma(h, -1, v) the once-rounded
+// difference v - (float)h (tools/scratch/probe_fma_mix.hip: all 2^32 pairs of halves, and 2^28 (half, float) pairs, bit for bit).
+// `w` = a register holding two halves; HI selects the upper one.
+template <bool HI>
+__device__ __forceinline__ float mix_add_halves(unsigned h, unsigned l) {      // (float)half(h) + (float)half(l)
+  float r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+#else
+  r = 0.f;
+#endif
+  return r;
+}
+template <bool HI>
+__device__ __forceinline__ float mix_sub_half(float v, unsigned h) {           // v - (float)half(h)
+  float r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+#else
+  r = 0.f;
+#endif
+  return r;
+}
+
+// min(r, r * inv) — the leaky-relu undone for 0 < slope <= 1 (inv = 1 / slope >= 1) — on a value that came out of the asm above: through
+// __builtin_fminf hipcc first canonicalises an operand it did not compute itself (v_max_f32 x, x, x: one more instruction per value)
+__device__ __forceinline__ float lrelu_undo_min(float r, float inv) {
+  const float m = r * inv;
+  float o;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_min_f32 %0, %1, %2" : "=v"(o) : "v"(r), "v"(m));
+#else
+  o = r < m ? r : m;
+#endif
+  return o;
+}
+
+// lo halves of a split: f16(a - hi0) | f16(b - hi1) for the packed pair `h` = (hi0, hi1) (what v_cvt_pkrtz returned)
+template <class H2>
+__device__ __forceinline__ auto split_lo2(const H2 h, float a, float b) {
+  const unsigned hw = __builtin_bit_cast(unsigned, h);
+  return __builtin_amdgcn_cvt_pkrtz(mix_sub_half<false>(a, hw), mix_sub_half<true>(b, hw));
+}
+
 // ---- asynchronous global -> LDS copies (LDS-DMA: buffer_load_dwordx4 ... lds, 64 lanes x 16 bytes = 1 KB contiguous in
 // LDS per instruction, no staging registers), issued through inline asm: with the builtin, hipcc waits for the copy
 // before the next ds_read it cannot prove disjoint (the whole phase), and it knows nothing of these, so the kernel counts

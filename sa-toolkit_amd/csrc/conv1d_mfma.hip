@@ -1007,8 +1007,8 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_f16x3_kernel(const ConvA
       }
       const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
       const auto h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-      const auto l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
-      const auto l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+      const auto l01 = split_lo2(h01, v[0], v[1]);
+      const auto l23 = split_lo2(h23, v[2], v[3]);
       uint2* dh = (uint2*)(ldst + (((rg >> 1) * 4 + 0 * 2 + (rg & 1)) * FP_W1 + col)) + lh;
       uint2* dl = (uint2*)(ldst + (((rg >> 1) * 4 + 1 * 2 + (rg & 1)) * FP_W1 + col)) + lh;
       *dh = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
@@ -1191,8 +1191,8 @@ __global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(
     }
     const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
     const auto h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-    const auto l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
-    const auto l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+    const auto l01 = split_lo2(h01, v[0], v[1]);
+    const auto l23 = split_lo2(h23, v[2], v[3]);
     ((uint2*)(ldst + (0 + gt) * FP_W1 + col))[gh] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
     ((uint2*)(ldst + (2 + gt) * FP_W1 + col))[gh] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
   }
@@ -1254,7 +1254,7 @@ __global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = v[k] / p.accum_div;
     }
-    if (!p.no_y) {
+    if (!p.no_y && !p.no_store) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), yrs, yoff + k * y_rb, 0, 0);
     }
@@ -1264,8 +1264,8 @@ __global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(
       for (int k = 0; k < 4; ++k) u[k] = v[k] > 0.f ? v[k] : v[k] * p.y16_slope;
       const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
       const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-      const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-      const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+      const auto l01 = split_lo2(h01, u[0], u[1]);
+      const auto l23 = split_lo2(h23, u[2], u[3]);
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       u32x2 hv, lv;
       hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
@@ -1437,8 +1437,8 @@ __global__ void __launch_bounds__(256, 3) resblock_pair32_kernel(const ConvArgs 
       }
       const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
       const auto h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-      const auto l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
-      const auto l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+      const auto l01 = split_lo2(h01, v[0], v[1]);
+      const auto l23 = split_lo2(h23, v[2], v[3]);
       if (col < W1) {
         ((uint2*)(ldst + (((rg >> 1) * 4 + 0 + (rg & 1)) * W1 + col)))[lh] =
             make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
@@ -1668,6 +1668,9 @@ static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* 
   a.res_after = d->res_after_act;
   a.accum = d->accum;
   a.accum_div = d->accum_div;
+  a.no_store = d->accum_no_store;
+  SAT_REQUIRE(!d->accum_no_store || (d->accum && y && d->y_split && !d->no_y && d->up == 1),
+              "conv1d: accum_no_store goes with accum (y is read), y_split (the output that is written) and up 1");
   a.res_scale = d->res_scale;
   a.res_toff = d->res_toff;
   a.res_tstride = d->res_tstride > 0 ? d->res_tstride : 1;
@@ -1826,8 +1829,11 @@ extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const
   struct Span { const char* lo; const char* hi; };
   auto span = [](const void* p, long long bytes) { return Span{(const char*)p, p ? (const char*)p + (bytes > 0 ? bytes : 0) : (const char*)p}; };
   auto overlap = [](const Span& u, const Span& v) { return u.lo && v.lo && u.lo < v.hi && v.lo < u.hi; };
+  auto yspan = [&](const ConvArgs& c, int B) {
+    return span(c.no_y ? nullptr : (const void*)c.y, ((long long)(B - 1) * c.y_bs + (long long)(c.rows_g - 1) * c.y_cs + (long long)c.T_q * c.up) * 4);
+  };
   auto writes = [&](const ConvArgs& c, int B, Span (&w)[3]) {
-    w[0] = span(c.no_y ? nullptr : (const void*)c.y, ((long long)(B - 1) * c.y_bs + (long long)(c.rows_g - 1) * c.y_cs + (long long)c.T_q * c.up) * 4);
+    w[0] = c.no_store ? Span{nullptr, nullptr} : yspan(c, B);      // (accum_no_store: y is only read)
     w[1] = span(c.y16, (long long)B * c.rows_g * c.T_q * c.up * 4);
     w[2] = span(c.y8, (long long)B * c.rows_g * c.T_q * c.up * 2);
   };
@@ -1838,7 +1844,7 @@ extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const
       Span wi[3], wj[3];
       writes(a[i], B, wi);
       writes(a[j], B, wj);
-      const Span rd[6] = {a[j].accum ? wj[0] : Span{nullptr, nullptr},
+      const Span rd[6] = {a[j].accum ? yspan(a[j], B) : Span{nullptr, nullptr},
                           span(a[j].res, ((long long)(B - 1) * a[j].r_bs + (long long)(a[j].rows_g - 1) * a[j].r_cs + (long long)a[j].T_q * a[j].res_tstride + a[j].res_toff) * 4),
                           span(a[j].res16, (long long)B * a[j].rows_g * a[j].T_q * 4), span(a[j].x16, (long long)B * a[j].cin_g * a[j].T_in * 4),
                           span(a[j].x, ((long long)(B - 1) * a[j].x_bs + (long long)(a[j].cin_g - 1) * a[j].x_cs + a[j].T_in) * 4),
@@ -1907,6 +1913,8 @@ extern "C" int sat_resblock_pair_scaled_f16x3(const sat_conv1d_desc* d, const fl
   a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;
   a.in_lrelu = 1; a.in_slope = d->in_slope;
   a.accum = d->accum; a.accum_div = d->accum_div;
+  a.no_store = d->accum_no_store;
+  SAT_REQUIRE(!d->accum_no_store || (d->accum && y && d->y_split && !d->no_y), "resblock_pair: accum_no_store goes with accum and y_split");
   a.res_scale = 1.f; a.res_toff = 0; a.res_tstride = 1;
   a.w_descale = d->w_descale != 0.f ? d->w_descale : 1.f;        // second conv (the epilogue's)
   a.w_descale1 = w1_descale != 0.f ? w1_descale : 1.f;

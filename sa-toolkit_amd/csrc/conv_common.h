@@ -101,6 +101,7 @@ struct ConvArgs {
   const void* x8;        // its e4m3 sidecar of x16
   void* y8;              // e4m3 sidecar of y16 to write, or null
   int y16_hi_only;       // with y8: the lo units of y16 are not stored
+  int no_store;          // with accum: y is read (the running MRF sum) but the new sum is not stored (sat_conv1d_desc.accum_no_store)
 #ifdef SAT_STAMPS
   long long* dbg;        // diagnostic build (tools/stamp_conv.hip): per-block, per-chunk phase time stamps
 #endif
@@ -179,13 +180,12 @@ __device__ __forceinline__ void epilogue_prefetch_res(const ConvArgs& p, float (
 
 // raw plane words (hi01, hi23, lo01, lo23 of four consecutive rows) -> the four residual values
 __device__ __forceinline__ void decode_res16(float w0, float w1, float w2, float w3, float inv_slope, float (&out)[4]) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 h01 = __builtin_bit_cast(h2, w0), h23 = __builtin_bit_cast(h2, w1);
-  const h2 l01 = __builtin_bit_cast(h2, w2), l23 = __builtin_bit_cast(h2, w3);
-  out[0] = (float)h01[0] + (float)l01[0];
-  out[1] = (float)h01[1] + (float)l01[1];
-  out[2] = (float)h23[0] + (float)l23[0];
-  out[3] = (float)h23[1] + (float)l23[1];
+  const unsigned h01 = __builtin_bit_cast(unsigned, w0), h23 = __builtin_bit_cast(unsigned, w1);
+  const unsigned l01 = __builtin_bit_cast(unsigned, w2), l23 = __builtin_bit_cast(unsigned, w3);
+  out[0] = mix_add_halves<false>(h01, l01);          // (float)hi + (float)lo in one v_fma_mix_f32 (common.h)
+  out[1] = mix_add_halves<true>(h01, l01);
+  out[2] = mix_add_halves<false>(h23, l23);
+  out[3] = mix_add_halves<true>(h23, l23);
 #pragma unroll
   for (int k = 0; k < 4; ++k) out[k] = out[k] > 0.f ? out[k] : out[k] * inv_slope;
 }
@@ -329,7 +329,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = v[r] / p.accum_div;
         }
-        if (!p.no_y) {
+        if (!p.no_y && !p.no_store) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs,
@@ -365,8 +365,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
               __builtin_amdgcn_raw_buffer_store_b32(x8h, y16rs, off8, 0, 0);
               __builtin_amdgcn_raw_buffer_store_b32(x8l, y16rs, off8, p.T_q * 16, 0);
             } else {
-              const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-              const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+              const auto l01 = split_lo2(h01, u[0], u[1]);
+              const auto l23 = split_lo2(h23, u[2], u[3]);
               u32x2 lv;
               lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
               __builtin_amdgcn_raw_buffer_store_b64(lv, y16rs, off, 2 * p.T_q * 16, 0);
@@ -621,7 +621,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] / p.accum_div;
       }
-      if (!p.no_y) {
+      if (!p.no_y && !p.no_store) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs, yoff + r * y_rb, 0, 0);
@@ -633,8 +633,8 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[
         for (int r = 0; r < 4; ++r) u[r] = v[r] > 0.f ? v[r] : v[r] * p.y16_slope;
         const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
         const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-        const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-        const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+        const auto l01 = split_lo2(h01, u[0], u[1]);
+        const auto l23 = split_lo2(h23, u[2], u[3]);
         const unsigned off = qok ? (unsigned)(((chunk * 4 + (lg >> 1)) * p.T_q + q) * 16 + 8 * (lg & 1)) : OOB;
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         u32x2 hv, lv;

@@ -78,7 +78,7 @@ struct RingJob {
   unsigned w_bytes;
   int nstep;             // F8: steps of a tile, 2 * ceil(chunk pairs x ksize / 2)
   int hi_only;           // the lo units of y16 are not stored
-  int pad_;
+  int no_store;          // y is the MRF sum so far (read: accum) and the new sum is not written back (sat_conv1d_desc.accum_no_store)
 };
 struct RingArgs {
   RingJob job[3];
@@ -124,6 +124,7 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
   const bool accum = (PROF == 0 || PROF == 3) ? e.accum != 0 : false;
   const bool has_y8 = PROF == 0 ? e.y8 != nullptr : (PROF == 3 ? false : Y8);
   const bool hi_only = PROF == 0 ? e.hi_only != 0 : (PROF == 1 && Y8);
+  const bool no_store = (PROF == 0 || PROF == 3) ? e.no_store != 0 : false;
   const float descale = e.w_descale, slope = e.y16_slope, inv = e.res16_inv, div = (PROF == 0 || PROF == 3) ? e.accum_div : 0.f;
   float bi[MT][4];
 #pragma unroll
@@ -180,17 +181,16 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
         // of the lo unit, which the partner lane holds: swap(u0, u2), swap(u1, u3) hand every lane its (hi, lo) pair
         const auto s0 = __builtin_amdgcn_permlane16_swap(rr[n][0], rr[n][2], false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(rr[n][1], rr[n][3], false, false);
-        // (each pair read as ONE vector of four halves: bit_cast<half2> of the elements of a 2 x u32 vector is miscompiled by
-        // this hipcc — element 0 used for both, tools/hipcc_bitcast_repro.hip)
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        const h4 c01 = __builtin_bit_cast(h4, s0), c23 = __builtin_bit_cast(h4, s1);      // (hi, hi, lo, lo) of channels 0, 1 / 2, 3
-        rv[0] = (float)c01[0] + (float)c01[2];
-        rv[1] = (float)c01[1] + (float)c01[3];
-        rv[2] = (float)c23[0] + (float)c23[2];
-        rv[3] = (float)c23[1] + (float)c23[3];
+        // (the words go to the instruction as they are: bit_cast<half2> of the elements of a 2 x u32 vector is miscompiled by this
+        // hipcc — element 0 used for both, tools/hipcc_bitcast_repro.hip)
+        // s0 = ((hi0, hi1), (lo0, lo1)) of channels 0, 1; s1 of channels 2, 3: (float)hi + (float)lo in one v_fma_mix_f32 each (common.h)
+        rv[0] = mix_add_halves<false>(s0[0], s0[1]);
+        rv[1] = mix_add_halves<true>(s0[0], s0[1]);
+        rv[2] = mix_add_halves<false>(s1[0], s1[1]);
+        rv[3] = mix_add_halves<true>(s1[0], s1[1]);
         // (leaky-relu undone: x > 0 ? x : x * inv with inv >= 1 is min(x, x * inv) — one instruction less per value)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rv[r] = __builtin_fminf(rv[r], rv[r] * inv);
+        for (int r = 0; r < 4; ++r) rv[r] = lrelu_undo_min(rv[r], inv);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += rv[r];
       }
@@ -202,7 +202,7 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] / div;
       }
-      if (has_y) {
+      if (has_y && !no_store) {
         const unsigned yoff = qok ? (unsigned)(row0 * y_rb + q * 4) : OOB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs, yoff + r * y_rb, 0, 0);
@@ -214,8 +214,8 @@ __device__ __forceinline__ void ring_epilogue(const RingJob& e, const RingArgs& 
         for (int r = 0; r < 4; ++r) u[r] = __builtin_fmaxf(v[r], v[r] * slope);
         const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
         const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-        const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-        const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+        const auto l01 = split_lo2(h01, u[0], u[1]);
+        const auto l23 = split_lo2(h23, u[2], u[3]);
         // a lane holds 8 bytes of the hi unit and 8 of the lo unit of (chunk, half lg >> 1), its partner lg ^ 1 the other 8 of
         // each: after swap(hi, lo) per word the lanes of even lg hold the whole hi unit and their partners the whole lo unit —
         // ONE 16-byte store per lane instead of two 8-byte ones (the epilogue is bound by the issue of its stores)
@@ -276,8 +276,8 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
       }
       const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
       const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-      const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-      const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+      const auto l01 = split_lo2(h01, u[0], u[1]);
+      const auto l23 = split_lo2(h23, u[2], u[3]);
       // (ring_epilogue: after swap(hi, lo) per word the lanes of even lg hold the whole hi unit, their partners lg ^ 1 the whole lo unit)
       const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, l01), false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, l23), false, false);
@@ -870,6 +870,7 @@ static int launch_convring(const ConvArgs* a, int njobs, int rotate, int B, hipS
     r.w_bytes = (unsigned)a[j].w_gs;
     r.y_bs = a[j].y_bs, r.y_cs = a[j].y_cs;
     r.x8 = a[j].x8, r.y8 = a[j].y8, r.hi_only = a[j].y16_hi_only && a[j].y8;
+    r.no_store = a[j].no_store;
     r.nstep = F8 ? 2 * (((a[j].cin_pad / (2 * CI_CHUNK)) * a[j].ksize + 1) / 2) : a[j].ksize;
   }
   A.cin_g = a[0].cin_g, A.cin_pad = a[0].cin_pad, A.rows_g = a[0].rows_g, A.co_pad = a[0].co_pad, A.T_in = a[0].T_in, A.T_q = a[0].T_q;

@@ -82,8 +82,8 @@ __device__ __forceinline__ void walk_epilogue_piece(const WalkJob& e, const Walk
     for (int r = 0; r < 4; ++r) u[r] = v[r] > 0.f ? v[r] : v[r] * e.y16_slope;
     const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
     const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-    const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-    const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+    const auto l01 = split_lo2(h01, u[0], u[1]);
+    const auto l23 = split_lo2(h23, u[2], u[3]);
     // 16-byte units: lanes of even lg the hi unit, their partners lg ^ 1 the lo unit (conv_ring16.hip)
     const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, l01), false, false);
     const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, l23), false, false);

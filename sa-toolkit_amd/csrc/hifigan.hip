@@ -195,6 +195,8 @@ struct sat_hifigan {
   int fuse_mrf = 1;          // a whole MRF block (all branches, all steps, the mean) as one launch where mrf.hip supports the stage (C = 16)
   int split_acts = 1;
   int planes_residual = 1;
+  int skip_dead_sum = 1;     // the f32 MRF mean of a stage that is not the last is read by nobody (the next upsampler takes its planes): the last
+                             // branch's launch does not store it (sat_conv1d_desc.accum_no_store) — 0.45 GB of writes per forward of 32 x 5 s
   int force_f8 = 0;          // SAT_CONV_F16F8R stages at EVERY batch size (a calibration batch is too small for the ring kernel's default dispatch:
                              // check_precision sets it on its own handle's forward instead of touching the process-wide "convring" option)
   mutable std::atomic<int> last_f8_stages{0};   // bit i: stage i of the LAST forward ran its ResBlock convs with 8-bit cross terms
@@ -343,6 +345,7 @@ extern "C" int sat_hifigan_set_option(sat_hifigan* h, const char* name, int valu
   if (std::string(name) == "planes_residual") { h->planes_residual = value; return SAT_OK; }
   if (std::string(name) == "branch_streams") { h->branch_streams = value; return SAT_OK; }
   if (std::string(name) == "force_f8") { h->force_f8 = value; return SAT_OK; }
+  if (std::string(name) == "skip_dead_sum") { h->skip_dead_sum = value; return SAT_OK; }
   set_error("hifigan_set_option: unknown option %s", name);
   return SAT_ERR_INVALID;
 }
@@ -363,6 +366,7 @@ extern "C" int sat_hifigan_get_option(const sat_hifigan* h, const char* name, in
   if (n == "planes_residual") { *value = h->planes_residual; return SAT_OK; }
   if (n == "branch_streams") { *value = h->branch_streams; return SAT_OK; }
   if (n == "force_f8") { *value = h->force_f8; return SAT_OK; }
+  if (n == "skip_dead_sum") { *value = h->skip_dead_sum; return SAT_OK; }
   set_error("hifigan_get_option: unknown option %s", name);
   return SAT_ERR_INVALID;
 }
@@ -661,6 +665,8 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
                 d2[j].accum = j > 0;
                 d2[j].accum_div = (j == nk - 1) ? (float)nk : 0.f;
                 dst_s[j] = (j == nk - 1 && !last_stage) ? XSn : nullptr;
+                // the mean only leaves this stage as planes (the next upsampler's input): its f32 form is not written
+                d2[j].accum_no_store = h->skip_dead_sum && j > 0 && dst_s[j] != nullptr;
               }
               d2[j].y_split = dst_s[j];
               w2[j] = cv2.w;
@@ -741,6 +747,7 @@ extern "C" int sat_hifigan_forward_f32(const sat_hifigan* h, const float* x, flo
             d2.accum = j > 0;
             d2.accum_div = (j == nk - 1) ? (float)nk : 0.f;
             dsts = (j == nk - 1 && !last_stage) ? XSn : nullptr;   // the next stage's input planes
+            d2.accum_no_store = h->skip_dead_sum && planes_res && j > 0 && dsts != nullptr;      // (see the thick stages above)
           }
           d2.y_split = dsts;
           int s;

@@ -176,25 +176,22 @@ __device__ __forceinline__ float mrf_lrelu(float v, float slope) {      // 0 < s
 // four consecutive channels of one column -> the 8-byte hi and lo words of their plane unit
 // (lo = v - hi in one v_fma_mix_f32 each: fma(float(hi), -1, v), exact like the subtraction)
 __device__ __forceinline__ void mrf_split4(const float (&v)[4], uint2& hv, uint2& lv) {
-  const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-  const auto h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-  const auto l01 = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h01[0], -1.0f, v[0]), __builtin_fmaf((float)h01[1], -1.0f, v[1]));
-  const auto l23 = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h23[0], -1.0f, v[2]), __builtin_fmaf((float)h23[1], -1.0f, v[3]));
-  hv = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+  const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
+  const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
+  const auto l01 = __builtin_amdgcn_cvt_pkrtz(mix_sub_half<false>(v[0], h01), mix_sub_half<true>(v[1], h01));
+  const auto l23 = __builtin_amdgcn_cvt_pkrtz(mix_sub_half<false>(v[2], h23), mix_sub_half<true>(v[3], h23));
+  hv = make_uint2(h01, h23);
   lv = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
 // plane words of four channels -> their values (hi + lo), the leaky-relu undone: min(r, r / slope) for 0 < slope < 1
 __device__ __forceinline__ void mrf_decode4(const uint2 hv, const uint2 lv, float inv_slope, float (&out)[4]) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 h01 = __builtin_bit_cast(h2, hv.x), h23 = __builtin_bit_cast(h2, hv.y);
-  const h2 l01 = __builtin_bit_cast(h2, lv.x), l23 = __builtin_bit_cast(h2, lv.y);
-  out[0] = (float)h01[0] + (float)l01[0];
-  out[1] = (float)h01[1] + (float)l01[1];
-  out[2] = (float)h23[0] + (float)l23[0];
-  out[3] = (float)h23[1] + (float)l23[1];
+  out[0] = mix_add_halves<false>(hv.x, lv.x);
+  out[1] = mix_add_halves<true>(hv.x, lv.x);
+  out[2] = mix_add_halves<false>(hv.y, lv.y);
+  out[3] = mix_add_halves<true>(hv.y, lv.y);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) out[k] = __builtin_fminf(out[k], out[k] * inv_slope);
+  for (int k = 0; k < 4; ++k) out[k] = lrelu_undo_min(out[k], inv_slope);
 }
 
 // EXACT: the residual x of steps 2 and 3 stays in f32 registers (closer to the reference's f32 arithmetic than the

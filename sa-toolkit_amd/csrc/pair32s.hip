@@ -151,8 +151,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) pair32s_kernel(const
         }
         const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
         const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-        const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-        const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+        const auto l01 = split_lo2(h01, u[0], u[1]);
+        const auto l23 = split_lo2(h23, u[2], u[3]);
         // channels 16 m + 4 g ..: chunk m, half g >> 1, bytes 8 (g & 1) of the unit
         u32x2* dst = (u32x2*)(T1 + (m * 4 + (g >> 1)) * PITCH + 16 * s + j16) + (g & 1);
         dst[0] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
@@ -204,8 +204,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) pair32s_kernel(const
         const h4* src = (const h4*)(img + (m * 4 + (g >> 1)) * PITCH + 16 * s + j16 + HL) + (g & 1);
         const h4 rh = src[0], rl = src[2 * PITCH * 2];
         float rv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rv[k] = (float)rh[k] + (float)rl[k];
+        {
+          typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+          const u32x2v hw = __builtin_bit_cast(u32x2v, rh), lw = __builtin_bit_cast(u32x2v, rl);      // (hi0 hi1 | hi2 hi3), (lo0 lo1 | lo2 lo3)
+          rv[0] = mix_add_halves<false>(hw[0], lw[0]);
+          rv[1] = mix_add_halves<true>(hw[0], lw[0]);
+          rv[2] = mix_add_halves<false>(hw[1], lw[1]);
+          rv[3] = mix_add_halves<true>(hw[1], lw[1]);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) rv[k] = rv[k] > 0.f ? rv[k] : rv[k] * p.inv_slope;
         float v[4];
@@ -230,8 +236,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) pair32s_kernel(const
           for (int k = 0; k < 4; ++k) u[k] = v[k] > 0.f ? v[k] : v[k] * p.y_slope;
           const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
           const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-          const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-          const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+          const auto l01 = split_lo2(h01, u[0], u[1]);
+          const auto l23 = split_lo2(h23, u[2], u[3]);
           const unsigned off = ok ? (unsigned)((((m * 4 + (g >> 1)) * p.T + pos) * 16) + 8 * (g & 1)) : OOB;
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)}, y16rs, off, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)}, y16rs, off, 2 * p.T * 16, 0);
@@ -464,8 +470,8 @@ __global__ void __launch_bounds__(512, 1) pairw_kernel(const P32Args p) {
                    }
                    const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
                    const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-                   const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-                   const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+                   const auto l01 = split_lo2(h01, u[0], u[1]);
+                   const auto l23 = split_lo2(h23, u[2], u[3]);
                    u32x2* dst = (u32x2*)(t1 + ((2 * mh + m) * 4 + (g >> 1)) * T1P + 16 * s_ + j16) + (g & 1);
                    dst[0] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
                    dst[2 * T1P * 2] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
@@ -518,13 +524,14 @@ __global__ void __launch_bounds__(512, 1) pairw_kernel(const P32Args p) {
                  const int set = RD == 2 ? (i & 1) : 0;
 #pragma unroll
                  for (int m = 0; m < 2; ++m) {
-                   const h4 xh = __builtin_bit_cast(h4, u32x2{rh[set][m][0], rh[set][m][1]}), xl = __builtin_bit_cast(h4, u32x2{rl[set][m][0], rl[set][m][1]});
+                   const float rsum[4] = {mix_add_halves<false>(rh[set][m][0], rl[set][m][0]), mix_add_halves<true>(rh[set][m][0], rl[set][m][0]),
+                                          mix_add_halves<false>(rh[set][m][1], rl[set][m][1]), mix_add_halves<true>(rh[set][m][1], rl[set][m][1])};
                    const float4 bq = my_bias[4 * m];
                    const float bias_m[4] = {bq.x, bq.y, bq.z, bq.w};
                    float v[4];
 #pragma unroll
                    for (int k = 0; k < 4; ++k) {
-                     float r = (float)xh[k] + (float)xl[k];
+                     float r = rsum[k];
                      r = r > 0.f ? r : r * p.inv_slope;
                      v[k] = __builtin_fmaf(acc[m][k], descale, bias_m[k]) + r;
                      if (YF && p.accum) v[k] = yv[m][k] + v[k];
@@ -545,8 +552,8 @@ __global__ void __launch_bounds__(512, 1) pairw_kernel(const P32Args p) {
                      for (int k = 0; k < 4; ++k) u[k] = v[k] > 0.f ? v[k] : v[k] * p.y_slope;
                      const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
                      const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-                     const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-                     const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+                     const auto l01 = split_lo2(h01, u[0], u[1]);
+                     const auto l23 = split_lo2(h23, u[2], u[3]);
                      const unsigned off = ok ? (unsigned)(((((2 * mh + m) * 4 + (g >> 1)) * p.T + pos) * 16) + 8 * (g & 1)) : OOB;
                      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)}, y16rs, off, 0, 0);
                      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)}, y16rs, off, 2 * p.T * 16, 0);
@@ -627,7 +634,7 @@ bool pair32s_supports(const ConvArgs& a) {
                      (a.cin_g == 64 && a.rows_g == 64 && a.ksize == 3 && g_pair64w);
   return shape && a.dil >= 1 &&
          a.dil <= P32_HL - 1 && a.x16 && a.res16 == a.x16 && !a.res &&
-         !a.ch_scale && !a.relu && !a.gelu && a.co_pad == 64 && a.res_scale == 1.f && !a.y16_f8 && (a.y16 || !a.no_y);
+         !a.ch_scale && !a.relu && !a.gelu && a.co_pad == 64 && a.res_scale == 1.f && !a.y16_f8 && (a.y16 || !a.no_y) && !a.no_store;
 }
 
 int launch_pair32s(const ConvArgs& a, int B, hipStream_t s) {

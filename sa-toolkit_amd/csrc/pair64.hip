@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs 
         }
         const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
         const auto h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-        const auto l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
-        const auto l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+        const auto l01 = split_lo2(h01, v[0], v[1]);
+        const auto l23 = split_lo2(h23, v[2], v[3]);
         // rows 32 m + 8 rg + 4 lh + k: chunk 2 m + rg / 2, half rg & 1, bytes 8 lh .. of the unit
         const int chunk = 2 * m + (rg >> 1);
         ((uint2*)(ldst + ((chunk * 4 + 0 + (rg & 1)) * W1 + col)))[lh] =

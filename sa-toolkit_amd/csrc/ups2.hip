@@ -141,8 +141,8 @@ __global__ void __launch_bounds__(512, 1) ups2_kernel(const Ups2Args p) {
           }
           const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
           const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
-          const auto l01 = __builtin_amdgcn_cvt_pkrtz(u[0] - (float)h01[0], u[1] - (float)h01[1]);
-          const auto l23 = __builtin_amdgcn_cvt_pkrtz(u[2] - (float)h23[0], u[3] - (float)h23[1]);
+          const auto l01 = split_lo2(h01, u[0], u[1]);
+          const auto l23 = split_lo2(h23, u[2], u[3]);
           typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
           // channels 16 m + 4 g ..: chunk m, half g >> 1, bytes 8 (g & 1) of the unit at time tpos
           const unsigned off = (q0 + 16 * s + j16 < p.T) ? (unsigned)((((m * 4 + (g >> 1)) * To + tpos) * 16) + 8 * (g & 1)) : OOB;

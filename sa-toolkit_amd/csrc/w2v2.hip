@@ -442,8 +442,8 @@ __global__ void __launch_bounds__(64 * NW, 1) attention_f16x3_kernel(const uint4
       if (jg + 3 >= T) w.w = 0.f;
       const auto h01 = __builtin_amdgcn_cvt_pkrtz(w.x, w.y);
       const auto h23 = __builtin_amdgcn_cvt_pkrtz(w.z, w.w);
-      const auto l01 = __builtin_amdgcn_cvt_pkrtz(w.x - (float)h01[0], w.y - (float)h01[1]);
-      const auto l23 = __builtin_amdgcn_cvt_pkrtz(w.z - (float)h23[0], w.w - (float)h23[1]);
+      const auto l01 = split_lo2(h01, w.x, w.y);
+      const auto l23 = split_lo2(h23, w.z, w.w);
       // keys j4 .. j4 + 3 of the block: k-step j4 / 16, lane half (j4 / 4) & 1, first or second 8 bytes of the unit
       uint2* dst = (uint2*)(R + d * AT_VU + (j4 >> 4) * 2 + ((j4 >> 2) & 1)) + ((j4 >> 3) & 1);
       dst[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
@@ -503,8 +503,8 @@ __global__ void __launch_bounds__(64 * NW, 1) attention_f16x3_kernel(const uint4
           if (os) {
             const auto h01 = __builtin_amdgcn_cvt_pkrtz(w[0], w[1]);
             const auto h23 = __builtin_amdgcn_cvt_pkrtz(w[2], w[3]);
-            const auto l01 = __builtin_amdgcn_cvt_pkrtz(w[0] - (float)h01[0], w[1] - (float)h01[1]);
-            const auto l23 = __builtin_amdgcn_cvt_pkrtz(w[2] - (float)h23[0], w[3] - (float)h23[1]);
+            const auto l01 = split_lo2(h01, w[0], w[1]);
+            const auto l23 = split_lo2(h23, w[2], w[3]);
             const size_t un = ub + (size_t)((c >> 4) * 4 + ((c >> 3) & 1)) * T + q;
             ((uint2*)(os + un))[lh] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
             ((uint2*)(os + un + 2 * (size_t)T))[lh] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));

@@ -50,6 +50,9 @@ class CoreHifiGan(CoreHifiGanParams):
     #: weights at k = 8).  Needs the split-f16 generator on the split-plane pipeline (precision "f16x3", split_acts)
     ups_ring = int(os.environ.get("SATOOLS_AMD_GEN_UPS_RING", "1"))
 
+    #: the f32 mean of an MRF block that only the next upsampler consumes (as planes) is not stored (sat_conv1d_desc.accum_no_store)
+    skip_dead_sum = int(os.environ.get("SATOOLS_AMD_GEN_SKIP_DEAD_SUM", "1"))
+
     #: per-stream workspaces kept (3.3 GB each at 32 x 5 s: 26 GB at the default); beyond it the least recently used one is
     #: dropped.  One per convert() job in flight on the GPU (the reference's jobs_per_compute_device, bench.py --jobs) is
     #: what is needed; raise SATOOLS_AMD_GEN_MAX_WORKSPACES for more concurrent streams
@@ -72,7 +75,7 @@ class CoreHifiGan(CoreHifiGanParams):
         ps = self.__dict__.get("_flat_params")
         if ps is None:
             ps = self.__dict__["_flat_params"] = list(self.parameters())
-        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf, self.ups2, self.multi_branch, self.ups_ring, self.f8_stages) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (self.precision, self.split_acts, self.branch_streams, self.fuse_pair64, self.fuse_mrf, self.ups2, self.multi_branch, self.ups_ring, self.f8_stages, self.skip_dead_sum) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def invalidate(self):
         self._packed_key = None
@@ -166,6 +169,7 @@ class CoreHifiGan(CoreHifiGanParams):
         check(l.sat_hifigan_set_option(self._handle, b"multi_branch", int(self.multi_branch)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"ups2", int(self.ups2)), "sat_hifigan_set_option")
         check(l.sat_hifigan_set_option(self._handle, b"force_f8", int(self.force_f8)), "sat_hifigan_set_option")
+        check(l.sat_hifigan_set_option(self._handle, b"skip_dead_sum", int(self.skip_dead_sum)), "sat_hifigan_set_option")
         # (a frozen model brings the row order its weights were packed in)
         self._packed_ups_grouped = self._ups_grouped() if ups_grouped is None else bool(ups_grouped)
         check(l.sat_hifigan_set_option(self._handle, b"ups_ring", int(self._packed_ups_grouped)), "sat_hifigan_set_option")

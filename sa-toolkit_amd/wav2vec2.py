@@ -241,6 +241,8 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         W = self._prepare_w2v2(wav.device)
         mm = self._mm_mode
         B, n = wav.shape
+        fe_len = self._fe_lens(n)       # (from THIS call's length: a field set by features() went stale when another call — the tie
+                                        # guard's calibration utterances, a flagged row decided again — ran in between)
         heads, hd = 16, 64
         # conv feature extractor
         planes = mm == _lib.CONV_F16X3        # split-f16: LayerNorm hands its result on as split planes (16-byte staging)
@@ -259,10 +261,10 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             if not last:
                 nxt = W["fe"][i + 1]
                 if xs is not None and "w_wrap" in nxt:
-                    x = ops.conv1d(x, nxt["w_wrap"], 512, 1, bias=nxt["b"], t_out=self._fe_len[i + 1], mode=mm, x_split=xs,
+                    x = ops.conv1d(x, nxt["w_wrap"], 512, 1, bias=nxt["b"], t_out=fe_len[i + 1], mode=mm, x_split=xs,
                                    x_wrap_channels=x.shape[1], c_in=3 * x.shape[1] // 2)
                 else:
-                    x = ops.conv1d(x, nxt["w"], 512, nxt["k"], bias=nxt["b"], pad_left=0, pad_right=0, t_out=self._fe_len[i + 1], mode=mm,
+                    x = ops.conv1d(x, nxt["w"], 512, nxt["k"], bias=nxt["b"], pad_left=0, pad_right=0, t_out=fe_len[i + 1], mode=mm,
                                    x_split=xs)
         T = x.shape[2]
         # feature projection
@@ -342,6 +344,15 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
                 x = ops.conv1d(h, L["f2_w"], 1024, 1, bias=L["f2_b"], res=x, mode=mm)
         return x
 
+    @staticmethod
+    def _fe_lens(n):
+        """frames after each of the seven conv layers of the feature extractor for n samples"""
+        lens, t = [], n
+        for _, k, s in CONV_LAYERS:
+            t = (t - k) // s + 1
+            lens.append(t)
+        return lens
+
     def features(self, x):
         """[N, n] raw waveforms -> [N, 1024, 250 + 2 * padding]: last transformer layer output, replicate-padded by one
         frame (249 -> 250), then pad_input(self.padding)   (tdnnf_wav2vec2_vq.py:295-306 == :320-331)"""
@@ -349,14 +360,8 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             raise _lib.SatError("the wav2vec2 extractor runs on the HIP device only (no CPU fallback); move the input to 'cuda'")
         if x.dim() != 2:
             raise _lib.SatError("expected a 2-dimensional tensor [N, samples]")
-        n = x.shape[1]
-        lens, t = [], n
-        for _, k, s in CONV_LAYERS:
-            t = (t - k) // s + 1
-            lens.append(t)
-        if t < 1:
+        if self._fe_lens(x.shape[1])[-1] < 1:
             raise _lib.SatError("input too short for the wav2vec2 feature extractor")
-        self._fe_len = lens
         feats = self.w2v2_features(x.to(torch.float32).contiguous())                # [N, 1024, 249]
         feats = ops.pad_replicate(feats, 0, 1)                                      # F.pad(.., (0, 1), "replicate")
         return ops.pad_replicate(feats, self.padding, self.padding, interleave_right=True)   # pad_input
@@ -369,7 +374,7 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         """stack + VQ with the near-tie guard (asrbn.TdnnfVqNet._bn_guarded)"""
         out, status = self._run_stack_guarded(feats)
         bn = out.permute(0, 2, 1)
-        st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0})
+        st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0, "changed": 0})
         st["utterances"] += bn.shape[0] if status is not None else 0
         if defer_ties:
             return bn, (lambda: self.resolve_ties(status, bn, feats, wav))

@@ -27,22 +27,25 @@ def _oracle_f0(wav):
         torch.set_num_threads(nt)
 
 
-def _trained_like_state(sigma_rows=4.0, seed=11):
+def _trained_like_state(sigma_rows=1.0, seed=11, big_pair=None):
     """the synthetic fbank-tag checkpoint with statistics a trained weight-normed HiFi-GAN can have and seeded-random weights do not:
     `weight_g` of conv1 of every ResBlock step of the two thick stages (C = 256 / 128: the SAT_CONV_F16F8R layers) drawn log-normal
-    over its output channels (sigma_rows nats: a few rows 2^12 and more above the bulk), conv1's bias scaled with its row, and the
-    matching INPUT channel of conv2 divided by the same gain (weight_v columns) — leaky_relu is positively homogeneous, so the
-    generator's function is unchanged in exact arithmetic while the rows of a layer differ by orders of magnitude"""
+    over its output channels (sigma_rows nats), conv1's bias scaled with its row, and the matching INPUT channel of conv2 divided by
+    the same gain — leaky_relu is positively homogeneous, so the generator's function is unchanged in exact arithmetic while the rows
+    of a layer, and with them the inner activations' channels, differ by an order of magnitude and more.
+    big_pair = (resblock, step, log2 gain): that ONE layer pair scaled as a whole on top (conv1 up, conv2 down)"""
     from satools_amd import synthetic
     state, _ = synthetic.checkpoint(FBANK_TAG)
     sd = {k: v.clone() for k, v in state["base_model_state_dict"].items()}
     g = torch.Generator().manual_seed(seed)
     n_k = 3                                                    # resblocks per stage (kernel sizes 3 / 7 / 11)
-    for rb in range(2 * n_k):                                  # stages 0 and 1
+    for rb in range(2 * n_k):                                  # stages 1 and 2
         for step in range(3):
             k1, k2 = f"hifigan.resblocks.{rb}.convs1.{step}", f"hifigan.resblocks.{rb}.convs2.{step}"
             c = sd[k1 + ".weight_g"].shape[0]
             gain = torch.exp2(torch.round(torch.randn(c, generator=g) * sigma_rows / math.log(2.0)))     # powers of two: exact rescaling
+            if big_pair is not None and (rb, step) == tuple(big_pair[:2]):
+                gain = gain * 2.0 ** big_pair[2]
             sd[k1 + ".weight_g"] = sd[k1 + ".weight_g"] * gain.view(-1, 1, 1)
             sd[k1 + ".bias"] = sd[k1 + ".bias"] * gain
             # conv2's weight = g2 * v2 / |v2| per OUTPUT channel: dividing input channel c of the folded weight by gain[c] needs the
@@ -56,16 +59,9 @@ def _trained_like_state(sigma_rows=4.0, seed=11):
     return state, sd
 
 
-def test_load_model_runs_the_precision_guard_on_a_trained_like_checkpoint(tmp_path, caplog):
-    """`load_model(<checkpoint file>)` + `.to("cuda")` = the precision guard, once, with its report logged and kept; on a checkpoint
-    whose layers hold rows of very different gain the 8-bit cross terms of "f16f8r" (e4m3 weights: 2^-9 .. 448 around ONE scale per
-    layer) lose the small rows — the guard says so (flushed / subnormal e4m3 weights counted, the calibration forward compared with the
-    exact-f32 kernels), the generator falls back to "f16x3", and convert() matches the CPU oracle below 1e-5 RMS"""
+def _load_through_the_guard(tmp_path, name, state, caplog):
     import satools_amd
-    from oracle import convert as oconv
-    from satools_amd import synthetic
-    state, sd = _trained_like_state()
-    path = tmp_path / "trained_like" / "final.pt"
+    path = tmp_path / name / "final.pt"
     path.parent.mkdir()
     torch.save(state, str(path))
     with caplog.at_level(logging.INFO, logger="satools_amd"):
@@ -74,22 +70,59 @@ def test_load_model_runs_the_precision_guard_on_a_trained_like_checkpoint(tmp_pa
         model.to(DEV)
     model.eval()
     rep = model.__dict__.get("precision_report")
-    print("precision guard on the trained-like checkpoint:", rep)
     assert rep is not None and model.__dict__["_precision_check_pending"] is False
     assert any("precision guard" in r.message for r in caplog.records)
-    st = rep["generator_f8_weights"]
-    assert st["values"] > 0 and st["clipped"] == 0 and st["flushed"] + st["subnormal"] > 0.01 * st["values"], st
-    assert "generator: f16f8r -> f16x3" in rep["fallback"], rep
-    assert model.hifigan.precision == "f16x3"
-    assert sum(rep["generator_range"]["past_e5m2_max"]) == 0                  # the planes stayed inside the f16 / e5m2 range
+    return model, rep
+
+
+def test_load_model_runs_the_precision_guard_on_a_trained_like_checkpoint(tmp_path, caplog):
+    """`load_model(<checkpoint file>)` + `.to("cuda")` = the precision guard, once, with its report logged and kept.
+    (a) log-normal row gains (one nat: the rows of a layer spread over ~2^6): every arithmetic passes — the 8-bit cross-term operands
+        carry the layer scale's range (e4m3 weights lose nothing down to 2^-14 of the layer's largest, as the f16 lo halves; counted:
+        `generator_f8_weights`), the planes stay far inside the f16 / e5m2 range (`generator_range`) — nothing falls back, and the
+        generator forced onto the 8-bit kernels meets the 1e-5 bar against the CPU oracle;
+    (b) the same checkpoint with ONE layer pair carrying a 2^12 gain (conv1 up, conv2 down: the same function): its inner activation
+        leaves the f16 range (counted by the range probe at that stage), both split arithmetics fail the comparison with the
+        exact-f32 kernels, the generator falls back to them and convert() meets the bar again instead of saturating silently."""
+    from oracle import convert as oconv
+    from oracle import hifigan as ohg
+    from satools_amd import synthetic
     wav = synthetic.harm_batch([2], 16000)
     f0 = _oracle_f0(wav)
+    # (a)
+    state, sd = _trained_like_state(sigma_rows=1.0)
+    model, rep = _load_through_the_guard(tmp_path, "trained_like", state, caplog)
+    print("precision guard, log-normal row gains:", rep)
+    st = rep["generator_f8_weights"]
+    assert st["values"] > 0 and st["clipped"] == 0 and st["flushed"] < 0.01 * st["values"], st      # (measured 0.33 %: lo halves of the smallest rows)
+    assert rep["fallback"] == [] and model.hifigan.precision == "f16f8r", rep
+    assert sum(rep["generator_range"]["past_e5m2_max"]) == 0 and rep["generator_arithmetic_f16f8r_ran"].startswith("f16f8r")
     ref = oconv.convert_fbank(sd, model.spk, wav, model.spk[1], f0)
-    err = rms(model.convert(wav.to(DEV), target=model.spk[1]).cpu().numpy() - ref.numpy())
-    print("convert() after the guard's fall-back: RMS error against the CPU oracle", err)
+    model.hifigan.set_force_f8(1)                      # one utterance is too small a batch for the 8-bit kernels' default dispatch
+    try:
+        y = model.convert(wav.to(DEV), target=model.spk[1])
+        assert model.hifigan.last_arithmetic.startswith("f16f8r")
+    finally:
+        model.hifigan.set_force_f8(0)
+    err = rms(y.cpu().numpy() - ref.numpy())
+    print("convert() on the 8-bit kernels, log-normal row gains: RMS error against the CPU oracle", err)
     assert err < 1e-5, err
-    model.to(DEV)                                                             # the guard runs once
+    model.to(DEV)                                      # the guard runs once
     assert model.__dict__["precision_report"] is rep
+    # (b)
+    caplog.clear()
+    state_b, sd_b = _trained_like_state(sigma_rows=1.0, big_pair=(1, 1, 12))
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model_b, rep_b = _load_through_the_guard(tmp_path, "one_pair_2p12", state_b, caplog)
+    print("precision guard, one layer pair with a 2^12 gain:", rep_b)
+    assert "generator" in rep_b["fallback"] and model_b.hifigan.precision == "f32" and w, rep_b
+    assert rep_b["generator_range"]["past_e5m2_max"][0] > 0, rep_b["generator_range"]        # (what the saturated stage hands on may count further down too)
+    ref_b = oconv.convert_fbank(sd_b, model_b.spk, wav, model_b.spk[1], f0)
+    err_b = rms(model_b.convert(wav.to(DEV), target=model_b.spk[1]).cpu().numpy() - ref_b.numpy())
+    print("convert() after the guard's fall-back to the exact-f32 kernels: RMS error against the CPU oracle", err_b)
+    assert err_b < 1e-5, err_b
 
 
 def test_load_model_guard_can_be_skipped_and_leaves_synthetic_loads_alone(tmp_path, monkeypatch):
@@ -175,9 +208,10 @@ def test_convert_patches_near_tie_utterances(tag):
     ext.vq_tie_sigmas = 0.0
     y_plain = model.convert(wav, target=tg).clone()
     ext.vq_tie_sigmas = 1e6
+    ext.vq_tie_force_patch = True           # (an utterance is generated again only when its indices change: here, always)
     ext.__dict__.pop("tie_stats", None)
     y_all = model.convert(wav, target=tg).clone()
-    assert ext.tie_stats["rerun"] == 3 and ext.tie_stats["utterances"] == 3, ext.tie_stats
+    assert ext.tie_stats["rerun"] == 3 and ext.tie_stats["changed"] == 3 and ext.tie_stats["utterances"] == 3, ext.tie_stats
     y_def, st = model.convert(wav, target=tg, defer_status=True)
     st.check()
     torch.cuda.synchronize()
@@ -185,6 +219,10 @@ def test_convert_patches_near_tie_utterances(tag):
     model.set_f0(f0.clone().unsqueeze(0))                       # F0 handed in (set_f0): the same deferred path
     y_set = model.convert(wav, target=tg).clone()
     assert torch.equal(y_set, y_all)
+    ext.vq_tie_force_patch = False
+    ext.__dict__.pop("tie_stats", None)
+    y_cmp = model.convert(wav, target=tg).clone()       # every utterance decided again, none CHANGED (no flip among them): nothing rewritten
+    assert ext.tie_stats["rerun"] == 3 and (ext.tie_stats["changed"] > 0 or torch.equal(y_cmp, y_plain)), ext.tie_stats
     ext.vq_tie_sigmas = 0.0
     with ext._exact(ext):
         y_exact = model.convert(wav, target=tg).clone()

@@ -217,7 +217,7 @@ def test_vq_flip_rate_of_the_default_arithmetic(tag):
     model.to(DEV)
     model.eval()
     ext = model.bn_extractor
-    tot = {"frames": 0, "flips": 0, "raw_flips": 0, "utterances": 0, "rerun": 0}
+    tot = {"frames": 0, "flips": 0, "raw_flips": 0, "utterances": 0, "rerun": 0, "changed": 0}
     sets = [("5 s", [synthetic.harm_batch(list(range(3000 + 32 * i, 3032 + 32 * i)), 80000) for i in range(16)]),
             ("20 s", [_long_batch(list(range(4000 + 4 * i, 4004 + 4 * i)), 20 * 16000) for i in range(4)]),
             ("35 s", [_long_batch(list(range(5000 + 2 * i, 5002 + 2 * i)), 35 * 16000) for i in range(4)])]
@@ -225,6 +225,7 @@ def test_vq_flip_rate_of_the_default_arithmetic(tag):
         sub = {k: 0 for k in tot}
         for wav in batches:
             wd = wav.to(DEV)
+            ext.__dict__.pop("tie_stats", None)
             idx, rows = ext.vq_indices(wd)
             _, (_, idx_raw, _) = ext.extract_bn(wd.clone(), want_aux=True)
             with ext._exact(ext):
@@ -233,14 +234,15 @@ def test_vq_flip_rate_of_the_default_arithmetic(tag):
             sub["flips"] += int((idx != idx32).sum())
             sub["raw_flips"] += int((idx_raw != idx32).sum())
             sub["utterances"] += wd.shape[0]
-            sub["rerun"] += len(rows)
+            sub["rerun"] += ext.tie_stats["rerun"]
+            sub["changed"] += len(rows)
         print(f"VQ indices, {tag}, {sub['utterances']} x {name}: {sub['flips']} flips in {sub['frames']} frames; "
-              f"{sub['rerun']} utterances decided again on the exact kernels ({100.0 * sub['rerun'] / sub['utterances']:.1f} %); "
+              f"{sub['rerun']} utterances decided again on the exact kernels ({100.0 * sub['rerun'] / sub['utterances']:.1f} %), {sub['changed']} of them changed; "
               f"the raw arithmetic: {sub['raw_flips']} flips = {1e6 * sub['raw_flips'] / sub['frames']:.0f} per million")
         for k in tot:
             tot[k] += sub[k]
     print(f"VQ indices, {tag}, all: {tot['flips']} flips in {tot['frames']} frames; {tot['rerun']} of {tot['utterances']} utterances decided again "
-          f"({100.0 * tot['rerun'] / tot['utterances']:.1f} %); the raw arithmetic: {tot['raw_flips']} flips = {1e6 * tot['raw_flips'] / tot['frames']:.0f} per million "
+          f"({100.0 * tot['rerun'] / tot['utterances']:.1f} %), {tot['changed']} changed; the raw arithmetic: {tot['raw_flips']} flips = {1e6 * tot['raw_flips'] / tot['frames']:.0f} per million "
           f"(window {ext.vq_tie_sigmas} sigma, sigma_rel {ext._tie[2]:.2e})")
     assert tot["flips"] == 0, tot
     assert tot["rerun"] <= 0.08 * tot["utterances"], tot          # (5 s utterances: a few per cent; 35 s utterances carry 7 x the frames each)
