@@ -33,9 +33,29 @@ __global__ void __launch_bounds__(256) vq_kernel(const float* __restrict__ z, co
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane;
-  for (int i = threadIdx.x; i < D * NC; i += 256) {
-    const int d = i / NC, e = i - d * NC;
-    et[i] = e < n_codes ? cb[(size_t)e * D + d] : 0.f;
+  // the codebook [code][d] is read as it lies in memory (consecutive threads, consecutive words: the transposed gather of rounds 1-5 —
+  // thread i fetching cb[(i % NC) * D + i / NC] — cost one latency round trip per 4-byte load, 48 of them in sequence: most of this
+  // kernel's 93 us), eight loads in flight per thread, and transposed by the LDS stores
+  const int total = n_codes * D;
+  for (int base = threadIdx.x; base < total; base += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + 256 * k;
+      v[k] = i < total ? cb[i] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + 256 * k;
+      if (i < total) {
+        const int e = i / D, d = i - e * D;
+        et[d * NC + e] = v[k];
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < D * (NC - n_codes); i += 256) {      // padding codes: zeros
+    const int d = i / (NC - n_codes), e = n_codes + (i - d * (NC - n_codes));
+    et[d * NC + e] = 0.f;
   }
   __syncthreads();
   if (threadIdx.x < NC) {
@@ -54,7 +74,30 @@ __global__ void __launch_bounds__(256) vq_kernel(const float* __restrict__ z, co
   for (int e = 0; e < CPG; ++e) dot[e] = 0.f;
   float xx = 0.f;
   const int e0 = grp * CPG;
-  for (int d = 0; d < D; ++d) {
+  // per accumulator the same d-ordered chain as ever; the frame's values are fetched eight rows ahead and the codes of a group four
+  // at a time (16-byte LDS broadcasts: e0 and NC are multiples of 4)
+  static_assert(CPG % 4 == 0 && NC % 4 == 0, "four codes per LDS read");
+  int d0 = 0;
+  for (; d0 + 8 <= D; d0 += 8) {
+    float xv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xv[k] = zb[(size_t)(d0 + k) * T];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float x = xv[k];
+      xx += x * x;
+      const float4* er = (const float4*)(et + (d0 + k) * NC + e0);
+#pragma unroll
+      for (int e4 = 0; e4 < CPG / 4; ++e4) {
+        const float4 c = er[e4];
+        dot[4 * e4 + 0] = fmaf(x, c.x, dot[4 * e4 + 0]);
+        dot[4 * e4 + 1] = fmaf(x, c.y, dot[4 * e4 + 1]);
+        dot[4 * e4 + 2] = fmaf(x, c.z, dot[4 * e4 + 2]);
+        dot[4 * e4 + 3] = fmaf(x, c.w, dot[4 * e4 + 3]);
+      }
+    }
+  }
+  for (int d = d0; d < D; ++d) {
     const float x = zb[(size_t)d * T];
     xx += x * x;
     const float* er = et + d * NC + e0;

@@ -82,8 +82,11 @@ def test_load_model_runs_the_precision_guard_on_a_trained_like_checkpoint(tmp_pa
         `generator_f8_weights`), the planes stay far inside the f16 / e5m2 range (`generator_range`) — nothing falls back, and the
         generator forced onto the 8-bit kernels meets the 1e-5 bar against the CPU oracle;
     (b) the same checkpoint with ONE layer pair carrying a 2^12 gain (conv1 up, conv2 down: the same function): its inner activation
-        leaves the f16 range (counted by the range probe at that stage), both split arithmetics fail the comparison with the
-        exact-f32 kernels, the generator falls back to them and convert() meets the bar again instead of saturating silently."""
+        reaches 2e4, still inside the f16 / e5m2 range (the sidecar is e5m2 BECAUSE of such layers) — nothing falls back and
+        the 8-bit kernels still meet the bar;
+    (c) a 2^15 gain: the inner activation leaves the f16 range (counted by the range probe at that stage), both split arithmetics
+        fail the comparison with the exact-f32 kernels, the generator falls back to them and convert() meets the bar again instead
+        of saturating silently."""
     from oracle import convert as oconv
     from oracle import hifigan as ohg
     from satools_amd import synthetic
@@ -112,17 +115,32 @@ def test_load_model_runs_the_precision_guard_on_a_trained_like_checkpoint(tmp_pa
     # (b)
     caplog.clear()
     state_b, sd_b = _trained_like_state(sigma_rows=1.0, big_pair=(1, 1, 12))
+    model_b, rep_b = _load_through_the_guard(tmp_path, "one_pair_2p12", state_b, caplog)
+    print("precision guard, one layer pair with a 2^12 gain:", rep_b)
+    assert rep_b["fallback"] == [] and model_b.hifigan.precision == "f16f8r", rep_b
+    assert 4096.0 < rep_b["generator_range"]["max_abs"][0] < 57344.0 and sum(rep_b["generator_range"]["past_e5m2_max"]) == 0
+    ref_b = oconv.convert_fbank(sd_b, model_b.spk, wav, model_b.spk[1], f0)
+    model_b.hifigan.set_force_f8(1)
+    try:
+        err_b = rms(model_b.convert(wav.to(DEV), target=model_b.spk[1]).cpu().numpy() - ref_b.numpy())
+    finally:
+        model_b.hifigan.set_force_f8(0)
+    print("convert() on the 8-bit kernels, one layer pair with a 2^12 gain: RMS error against the CPU oracle", err_b)
+    assert err_b < 1e-5, err_b
+    # (c)
+    caplog.clear()
+    state_c, sd_c = _trained_like_state(sigma_rows=1.0, big_pair=(1, 1, 15))
     import warnings
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        model_b, rep_b = _load_through_the_guard(tmp_path, "one_pair_2p12", state_b, caplog)
-    print("precision guard, one layer pair with a 2^12 gain:", rep_b)
-    assert "generator" in rep_b["fallback"] and model_b.hifigan.precision == "f32" and w, rep_b
-    assert rep_b["generator_range"]["past_e5m2_max"][0] > 0, rep_b["generator_range"]        # (what the saturated stage hands on may count further down too)
-    ref_b = oconv.convert_fbank(sd_b, model_b.spk, wav, model_b.spk[1], f0)
-    err_b = rms(model_b.convert(wav.to(DEV), target=model_b.spk[1]).cpu().numpy() - ref_b.numpy())
-    print("convert() after the guard's fall-back to the exact-f32 kernels: RMS error against the CPU oracle", err_b)
-    assert err_b < 1e-5, err_b
+        model_c, rep_c = _load_through_the_guard(tmp_path, "one_pair_2p15", state_c, caplog)
+    print("precision guard, one layer pair with a 2^15 gain:", rep_c)
+    assert "generator" in rep_c["fallback"] and model_c.hifigan.precision == "f32" and w, rep_c
+    assert rep_c["generator_range"]["past_e5m2_max"][0] > 0, rep_c["generator_range"]        # (what the saturated stage hands on may count further down too)
+    ref_c = oconv.convert_fbank(sd_c, model_c.spk, wav, model_c.spk[1], f0)
+    err_c = rms(model_c.convert(wav.to(DEV), target=model_c.spk[1]).cpu().numpy() - ref_c.numpy())
+    print("convert() after the guard's fall-back to the exact-f32 kernels: RMS error against the CPU oracle", err_c)
+    assert err_c < 1e-5, err_c
 
 
 def test_load_model_guard_can_be_skipped_and_leaves_synthetic_loads_alone(tmp_path, monkeypatch):

@@ -8,6 +8,7 @@ from satools_amd import synthetic
 
 model = satools_amd.load_model("synthetic:hifigan_bn_tdnnf_600h_vq_48_v1")
 model.to("cuda")
+model.bn_extractor.vq_tie_sigmas = 0.0      # the extractor ALONE as configured (the near-tie guard would add its calibration and exact-f32 re-runs to the trace)
 wav = synthetic.harm_batch(list(range(32))).to("cuda")
 
 
