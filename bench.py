@@ -249,7 +249,11 @@ def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each, repeats=1
             if status == "sync":
                 return model.convert(wav, target=targets)
             y, pending[j] = model.convert(wav, target=targets, defer_status=True)
-            return y
+        # the batch launched two steps ago: its VQ launch has completed by now — its near-tie utterances (if any) go to the exact kernels
+        # on a side stream WITHOUT the launching thread waiting for them (ConvertStatus.start; check() two steps on finds them decided)
+        if jobs > 2 and pending[(j - 2) % jobs] is not None:
+            pending[(j - 2) % jobs].start()
+        return y
 
     def drain():
         for j in range(jobs):
@@ -328,6 +332,8 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
             e = torch.cuda.Event()
             e.record(s)
             produced[a] = e
+        if status != "sync" and jobs > 2 and pending[(j - 2) % jobs] is not None:
+            pending[(j - 2) % jobs][0].start()           # (run_steps: the near-tie utterances of the batch launched two steps ago, without waiting)
         return None
 
     def before_chunk(c, ra, rb):
@@ -623,7 +629,7 @@ def gen_arithmetic(model):
     return f"f32 (matrix products: {g.precision})", PEAK_F16X3, g.precision
 
 
-def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu, cpu_args, repeats=1, gen_precision=None, want_roofline=True):
+def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu, cpu_args, repeats=1, gen_precision=None, want_roofline=True, status=None):
     """measure one BASELINE config on the loaded device; returns the JSON object (rank 0) or None.  `value` = the MEDIAN of
     `repeats` timed windows of `steps` steps (median of >= 5 repeats), min / max beside it."""
     model = load(tag, f0_tr, dev)
@@ -632,8 +638,9 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
         model.hifigan.invalidate()
     seed_each = "awgn" in f0_tr
     extra = {}
+    status = status or a.f0_status
     if use_pg:
-        r = run_sharded(model, dev, rank, world, steps, warmup, a.jobs, seed_each, a.gather, repeats, a.gather_chunk, status=a.f0_status)
+        r = run_sharded(model, dev, rank, world, steps, warmup, a.jobs, seed_each, a.gather, repeats, a.gather_chunk, status=status)
         windows, setup = r["windows"], r["setup_steps"]
         gb = 2 if a.gather == "pcm16" else 4
         mid = sorted(range(len(windows)), key=lambda i: windows[i])[len(windows) // 2]
@@ -649,7 +656,9 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
                                + ("issued on a communication stream as the batches complete, inside the timed region; all_gather_ms = what is left "
                                   "exposed behind the slowest rank's last batch" if r["chunk_batches"] else "at the end, inside the timed region")}
     else:
-        windows, setup = run_steps(model, dev, rank, steps, warmup, a.jobs, seed_each, repeats, status=a.f0_status)
+        windows, setup = run_steps(model, dev, rank, steps, warmup, a.jobs, seed_each, repeats, status=status)
+    ext = model.bn_extractor
+    tie = dict(ext.__dict__.get("tie_stats") or {})
     if rank != 0:
         return None
     w2 = tag == TAG_W2V2
@@ -667,9 +676,12 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
                                        f"batch=32 x 5 s @ 16 kHz synthetic `harm` utterances per GPU",
                            "batch_per_gpu": BATCH, "utt_seconds": UTT_SECONDS, "weights": "seeded random (conditioned)",
                            "f0": "YAAPT computed on-path on the GPU inside convert()", "jobs_per_gpu": a.jobs,
-                           "f0_status": ("YAAPT's status word of a batch (convert()'s error path) is checked before the same job launches its next batch "
-                                         "and at the end of every timed window: convert(..., defer_status=True), as the batch job does"
-                                         if a.f0_status == "deferred" else "checked inside every convert() call (a host round trip to the GPU per step)"),
+                           "f0_status": ("convert(..., defer_status=True), as the batch job does (pipeline.process_data): a batch's deferred work — YAAPT's status word "
+                                         "(convert()'s error path) and the utterances whose VQ decision was a near-tie, decided again on the exact kernels — is "
+                                         "checked before the same job launches its next batch and at the end of every timed window, inside the timed region"
+                                         if status == "deferred" else "the plain convert() call: status word and near-tie utterances waited for inside every call (host round trips to the GPU per step)"),
+                           "vq_near_tie_guard": {"window_sigmas": getattr(ext, "vq_tie_sigmas", None), "utterances": tie.get("utterances"),
+                                                 "decided_again_on_exact_kernels": tie.get("rerun"), "changed_and_generated_again": tie.get("changed")},
                            "setup_steps": setup, "generator_precision": model.hifigan.precision,
                            "reference_default_tag": f"{TAG_W2V2} (hubconf.py:69): its lines are configs[2] / configs[3] / configs[4] of this same run; "
                                                     f"the headline is BASELINE.json's configs[1], the tag the metric is quoted on",
@@ -748,9 +760,11 @@ def main():
     ap.add_argument("--gather-chunk", type=int, default=4,
                     help="sharded mode: the waveform exchange is issued in chunks of this many batches on a communication stream while "
                          "the shard is still being computed (0 = one all_gather_into_tensor at the end)")
-    ap.add_argument("--f0-status", choices=("sync", "deferred"), default="sync",
-                    help="when YAAPT's status word of a batch is checked: inside every convert() call (default: the plain call) or before the "
-                         "same job's next batch (convert(..., defer_status=True), what the batch job does)")
+    ap.add_argument("--f0-status", choices=("sync", "deferred"), default="deferred",
+                    help="when a batch's deferred work (YAAPT's status word, the near-tie utterances of the VQ) is checked: before the same job's "
+                         "next batch (default: convert(..., defer_status=True), what the batch job does) or inside every convert() call (the plain "
+                         "call: the one launching thread then waits for the GPU in every step; measured beside the headline as "
+                         "`configs[\"configs[1] plain convert()\"]`)")
     ap.add_argument("--gen-precision", default=None,
                     help="generator arithmetic of every line (default: the package default, SATOOLS_AMD_GEN_PRECISION); when that is "
                          "f16f8r the headline tag is also measured as f16x3 and kept in `configs`")
@@ -821,12 +835,18 @@ def main():
     if prec == "f16f8r" and not a.tag and not use_pg and not a.headline_only:
         # the headline tag on the f16x3 generator too, beside the headline (same run, same box)
         plan.insert(len(plan) - 1, ("configs[1] generator f16x3", TAG, "", a.steps, a.warmup, "f16x3"))
+    if a.f0_status == "deferred" and not a.tag and not use_pg and not a.headline_only:
+        # ... and with the plain convert() call (rounds 1-5 measured the headline that way)
+        plan.insert(len(plan) - 1, ("configs[1] plain convert()", TAG, "", a.steps, a.warmup, "status:sync"))
     for i, (name, tag, f0_tr, steps, warmup, cpu_args) in enumerate(plan):
         headline = i == len(plan) - 1
-        alt = cpu_args if isinstance(cpu_args, str) else None           # a generator precision instead of CPU-leg arguments
+        alt = cpu_args if isinstance(cpu_args, str) else None           # a generator precision / a status mode instead of CPU-leg arguments
         cpu_args = None if alt else cpu_args
+        st_alt = alt[len("status:"):] if alt and alt.startswith("status:") else None
+        alt = None if st_alt else alt
         out = one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu and cpu_args is not None, cpu_args or {},
-                         repeats=a.repeats if headline else min(a.repeats, 3), gen_precision=alt or a.gen_precision)
+                         repeats=a.repeats if headline else min(a.repeats, 3), gen_precision=alt or a.gen_precision, status=st_alt,
+                         want_roofline=st_alt is None)
         torch.cuda.empty_cache()
         if rank == 0:
             lines.append(out)
@@ -836,13 +856,15 @@ def main():
         head = lines[-1]
         if len(lines) > 1:
             def brief(o):
-                r, c = o["roofline"], o["config"]
+                r, c = o.get("roofline"), o["config"]
                 d = {"workload": c["workload"].split(" model.convert")[0], "value": o["value"], "unit": "x real-time", "ms_per_step": o["ms_per_step"],
                      "steps": o["steps"], "n_gpus": o["n_gpus"], "windows": o["repeats"]["windows"], "value_min_max": o["repeats"]["value_min_max"],
-                     "generator_precision": c["generator_precision"], "dtype": o["dtype"],
-                     "roofline": {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
-                                  "kernel": r["kernel"].split(":")[0],
-                                  "dominant_kernel_frac": (r.get("dominant_kernel") or {}).get("frac")}}
+                     "generator_precision": c["generator_precision"], "dtype": o["dtype"], "f0_status": c["f0_status"].split(":")[0].split(",")[0],
+                     "vq_near_tie_guard": c.get("vq_near_tie_guard")}
+                if r is not None:
+                    d["roofline"] = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+                                     "kernel": r["kernel"].split(":")[0],
+                                     "dominant_kernel_frac": (r.get("dominant_kernel") or {}).get("frac")}
                 for k in ("all_gather_ms", "ranks_seen_by_rccl", "utterances"):
                     if k in c:
                         d[k] = c[k]

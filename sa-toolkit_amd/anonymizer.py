@@ -39,6 +39,14 @@ class ConvertStatus:
         self.f0_status, self.fix, self.patch, self.stream, self.deferred = f0_status, fix, patch, stream, deferred
         self.rows = None
 
+    def start(self):
+        """non-blocking: begin the second decision of the batch's near-tie utterances if its VQ launch has completed (asrbn.TieFix.start);
+        a loop that keeps several batches in flight calls it a step or two before `check()`, which then finds the work done"""
+        if self.fix is not None and self.rows is None:
+            with torch.cuda.stream(self.stream):
+                return self.fix.start()
+        return True
+
     def check(self):
         if self.f0_status is not None:
             self.f0_status.check()
@@ -46,7 +54,7 @@ class ConvertStatus:
             self.rows = []
             if self.fix is not None:
                 with torch.cuda.stream(self.stream):
-                    rows = self.fix()
+                    rows = self.fix.finish()
                     if rows:
                         self.patch(rows)
                         self.rows = rows
@@ -124,8 +132,8 @@ def build(args):
         # ---- feature extractors (decorators are pass-through under SA_JIT_TWEAK=true,
         #      utils/feature_extractor_decorator.py:60-71; parse_wavinfo_wav clones) -------------
         def get_bn(self, wavinfo, defer_ties=False):
-            """defer_ties=True (inside convert()): -> (bn, fix) — `fix()` waits for the batch's VQ launch and decides near-tie utterances
-            again on the exact kernels (rows of bn are rewritten in place; returns them), to be run once the generator is enqueued"""
+            """defer_ties=True (inside convert()): -> (bn, fix) — `fix` (asrbn.TieFix or None) decides the batch's near-tie utterances again
+            on the exact kernels (`start()` non-blocking, `finish()` -> the rows of bn it rewrote), once the generator is enqueued"""
             wav = self._to_device(getattr(wavinfo, "wav", wavinfo).detach())
             # parse_wavinfo_wav clones because the extractor scales its argument in place (wav_scp_dataset.py:48-53);
             # the private entry leaves the input untouched instead (no clone, no scaling pass)

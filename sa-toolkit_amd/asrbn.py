@@ -109,6 +109,94 @@ class TieStatus:
             pass
 
 
+class TieFix:
+    """The second decision of a batch's near-tie utterances, in two steps so that a caller with several batches in flight never waits:
+    `start()` (non-blocking: returns False while the batch's VQ launch has not completed) sends the flagged utterances through the
+    exact-f32 kernels on a side stream that waits for that launch only — not for what the caller enqueued behind it (the generator);
+    `finish()` (blocking, starts what `start()` has not) waits for the side stream, and where an utterance's indices CHANGED rewrites
+    its rows of `bn` (and of `idx`) on the stream current at that time.  -> the changed rows.  A flagged utterance costs its
+    extractor again (2 % of 5 s utterances at the default window), a changed one (a few per thousand) also what the caller derives
+    from its rows (`convert()` generates them again)."""
+
+    def __init__(self, ext, status, bn, feats, wav, idx=None):
+        self.ext, self.status, self.bn, self.feats, self.wav, self.idx = ext, status, bn, feats, wav, idx
+        self.stage, self.hit = (2, []) if status is None else (0, None)
+        self.rows = self.zq = self.idx_x = self.flags = self.flag_row = self.event = self.side = None
+
+    def start(self, block=False):
+        if self.stage:
+            return True
+        if not block and not self.status.event.query():
+            return False
+        ext = self.ext
+        rows = self.status.rows()
+        if not rows:
+            self.stage, self.hit = 2, []
+            self._drop()
+            return True
+        dev = self.feats.device
+        cur = torch.cuda.current_stream(dev)
+        sides = ext.__dict__.setdefault("_tie_streams", {})
+        side = sides.get(cur.cuda_stream)
+        if side is None:
+            side = sides[cur.cuda_stream] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SATOOLS_AMD_VQ_TIE_STREAM_PRIORITY", "-1")))
+        side.wait_event(self.status.event)              # feats, wav and the indices precede the VQ launch's event on the batch's stream
+        from .f0 import _pinned_ints
+        self.flags, self.flag_row = _pinned_ints.take(len(rows))
+        ext.__dict__["_tie_busy"] = True
+        try:
+            with torch.cuda.stream(side):
+                self.zq, (_, self.idx_x, _) = ext._exact_rows(rows, self.feats, self.wav, want_aux=True)
+                changed = (self.idx_x != self.status.idx[rows]).any(dim=1)
+                self.flags.copy_(changed.to(torch.int32), non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record(side)
+        finally:
+            ext.__dict__["_tie_busy"] = False
+        self.rows, self.side, self.stage = rows, side, 1
+        return True
+
+    def _drop(self):
+        if self.flag_row is not None:
+            from .f0 import _pinned_ints
+            _pinned_ints.give(self.flag_row)
+            self.flag_row = None
+        self.feats = self.wav = self.status = None
+
+    def finish(self):
+        if self.stage == 0:
+            self.start(block=True)
+        if self.stage == 1:
+            ext, rows = self.ext, self.rows
+            self.event.synchronize()
+            flags = [1] * len(rows) if ext.vq_tie_force_patch else self.flags.tolist()
+            st = ext.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0, "changed": 0})
+            st["rerun"] += len(rows)
+            sel = [i for i, c in enumerate(flags) if c]
+            self.hit = [rows[i] for i in sel]
+            st["changed"] = st.get("changed", 0) + len(self.hit)
+            if self.hit:
+                cur = torch.cuda.current_stream(self.bn.device)
+                cur.wait_stream(self.side)
+                self.zq.record_stream(cur)
+                self.idx_x.record_stream(cur)
+                self.bn[self.hit] = self.zq[sel].permute(0, 2, 1)
+                if self.idx is not None:
+                    self.idx[self.hit] = self.idx_x[sel]
+            self.stage = 2
+            self.zq = self.idx_x = None
+            self._drop()
+        return self.hit
+
+    def __del__(self):
+        try:
+            if self.stage == 1 and self.event is not None:
+                self.event.synchronize()
+            self._drop()
+        except Exception:
+            pass
+
+
 class _TieCtx:
     """what the VQ layer of a guarded run is handed (pair distances, window, per-utterance counts) and hands back (its indices)"""
     __slots__ = ("pair", "scale", "counts", "idx")
@@ -238,8 +326,20 @@ class _TdnnfBase(nn.Module):
             zs = ops.split_like(B, lay.bottleneck_dim, t_q, x.device)
             z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, pad_left=0, pad_right=0, mode=1,
                            x_split=xs, y_split=zs, y_split_slope=1.0, no_y=True)     # z: shape carrier only
+        elif c.modeB == 1 and sub > 1 and xs is not None and x.shape[1] % 64 == 0 and lay.bottleneck_dim % 16 == 0 and not need_z:
+            # context-free subsampling layer on split planes: the 1x1 product on EVERY frame (the GEMM kernels read the planes the
+            # previous layer wrote: 8 x fewer bytes than the strided f32 copy of x the stride-1 kernels needed, round 6), every
+            # sub-th frame of the 128-row result kept and handed on as planes
+            z_all = ops.conv1d(x, c.wB, lay.bottleneck_dim, 1, bias=c.bB, pad_left=0, pad_right=0, mode=1, x_split=xs)
+            z = z_all[:, :, ::sub].contiguous()
+            zs = ops.act_split(z, 1.0)
         elif c.modeB == 1 and sub > 1:
             z = ops.conv1d(x[:, :, ::sub].contiguous(), c.wB, lay.bottleneck_dim, 1, bias=c.bB, pad_left=0, pad_right=0, mode=1)
+        elif c.modeB == 1 and sub == 1 and not need_z and lay.bottleneck_dim % 16 == 0 and c.modeA == 1:
+            # f32 input (the first layer: features), bottleneck still handed on as planes: linearA runs on the GEMM kernels
+            t_q = x.shape[2] - (ctx - 1)
+            zs = ops.split_like(B, lay.bottleneck_dim, t_q, x.device)
+            z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, pad_left=0, pad_right=0, mode=1, y_split=zs, y_split_slope=1.0, no_y=True)
         else:
             z = ops.conv1d(x, c.wB, lay.bottleneck_dim, ctx, bias=c.bB, stride=sub, pad_left=0, pad_right=0, mode=c.modeB,
                            x_split=xs if planes_in else None)
@@ -378,43 +478,8 @@ class _TdnnfBase(nn.Module):
     def resolve_ties(self, status, bn, feats, wav, idx=None):
         """Decide the flagged utterances of `status` again on the exact kernels; those whose indices CHANGE get their rows of `bn`
         ([B, T', D] view of the stack's output, as extract_bn returns it) rewritten, and their VQ indices written into `idx` [B, T'] when
-        given.  -> the changed rows (empty list: nothing for the caller to redo).
-        The exact run goes to a side stream that waits for the batch's VQ launch only — not for what the caller has enqueued behind it
-        (the generator) — and the host waits for that side stream: a flagged utterance costs its extractor again (2 % of the 5 s
-        utterances at the default window), a changed one (a few per thousand) also what the caller derives from its rows."""
-        if status is None:
-            return []
-        rows = status.rows()
-        st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0, "changed": 0})
-        if not rows:
-            return []
-        dev = feats.device
-        cur = torch.cuda.current_stream(dev)
-        sides = self.__dict__.setdefault("_tie_streams", {})
-        side = sides.get(cur.cuda_stream)
-        if side is None:
-            side = sides[cur.cuda_stream] = torch.cuda.Stream(device=dev)
-        side.wait_event(status.event)              # feats, wav and the indices precede the VQ launch's event on `cur`
-        self.__dict__["_tie_busy"] = True
-        try:
-            with torch.cuda.stream(side):
-                zq, (_, idx_x, _) = self._exact_rows(rows, feats, wav, want_aux=True)
-                changed = (idx_x != status.idx[rows]).any(dim=1)
-                flags = [True] * len(rows) if self.vq_tie_force_patch else changed.cpu().tolist()      # (waits for the side stream)
-        finally:
-            self.__dict__["_tie_busy"] = False
-        st["rerun"] += len(rows)
-        sel = [i for i, c in enumerate(flags) if c]
-        hit = [rows[i] for i in sel]
-        st["changed"] = st.get("changed", 0) + len(hit)
-        if hit:
-            cur.wait_stream(side)
-            zq.record_stream(cur)
-            idx_x.record_stream(cur)
-            bn[hit] = zq[sel].permute(0, 2, 1)
-            if idx is not None:
-                idx[hit] = idx_x[sel]
-        return hit
+        given.  -> the changed rows (empty list: nothing for the caller to redo).  Blocking form of `TieFix`."""
+        return TieFix(self, status, bn, feats, wav, idx).finish()
 
     # ---- the ASR half: Net.forward up to the chain / xent outputs (SURVEY 8 f4) --------------------------
     def _prepare_full(self, device):
@@ -582,7 +647,7 @@ class TdnnfVqNet(_TdnnfBase):
         st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0, "changed": 0})
         st["utterances"] += bn.shape[0] if status is not None else 0
         if defer_ties:
-            return bn, (lambda: self.resolve_ties(status, bn, feats, wav))
+            return bn, (TieFix(self, status, bn, feats, wav) if status is not None else None)
         self.resolve_ties(status, bn, feats, wav)
         return bn
 

@@ -364,11 +364,15 @@ def _process_data(dataset_path, target_selection_algorithm, wavscps, settings, p
             buf = slot["buf"][(kind, dtype)] = torch.empty(like_numel, dtype=dtype, pin_memory=True)
         return buf[:like_numel]
 
-    def write_batch(wav_conv, done_event, utid, freq, original_len, f0_status=None):
+    def write_batch(wav_conv, done_event, utid, freq, original_len, f0_status=None, refresh=None):
         if done_event is not None:
             done_event.synchronize()
         if f0_status is not None:
             f0_status.check()                       # what convert() raises for a batch YAAPT cannot track (deferred: see below)
+            # ... and the batch's other deferred work: utterances whose VQ decision was a near-tie are decided again on the exact kernels,
+            # and where their indices changed their rows were generated again (anonymizer.ConvertStatus) — copied to the host again
+            if getattr(f0_status, "rows", None) and refresh is not None:
+                refresh(f0_status.rows)
         arr = wav_conv.detach().numpy()             # f32, or int16 already converted on the device (sat_pcm16_from_f32)
         for i in range(arr.shape[0]):
             wav = arr[i]
@@ -451,18 +455,31 @@ def _process_data(dataset_path, target_selection_algorithm, wavscps, settings, p
                     else:
                         wav_conv = model.convert_padded(x, original_len.tolist(), targets) if fused else model.convert(x, **kw)
                     t_convert += _time.perf_counter() - _t3
+                    refresh = None
                     if use_streams:
                         # the samples the files hold are made on the device: half the bytes to copy back, nothing to round on the host
-                        if out_pcm16 and wav_conv.is_cuda and wav_conv.dtype == torch.float32:
+                        dev_f32 = wav_conv
+                        to_pcm = out_pcm16 and wav_conv.is_cuda and wav_conv.dtype == torch.float32
+                        if to_pcm:
                             wav_conv = _ops().pcm16_from_f32(wav_conv)
                         host = staging(slot, "out", wav_conv.numel(), wav_conv.dtype).view(wav_conv.shape)
                         host.copy_(wav_conv, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(sh.stream)
+                        if f0_status is not None:
+                            def refresh(rows, dev_f32=dev_f32, host=host, stream=sh.stream, to_pcm=to_pcm):
+                                # rows of the device result rewritten behind the copy above (rare: a few utterances per thousand)
+                                with torch.cuda.stream(stream):
+                                    part = dev_f32[rows].contiguous()
+                                    if to_pcm:
+                                        part = _ops().pcm16_from_f32(part)
+                                    host[rows] = part.cpu()
                     else:
+                        if f0_status is not None:
+                            f0_status.check()       # (no streams: the copy below is synchronous anyway; the deferred work first, it may rewrite rows)
                         host, ev = wav_conv.cpu(), None
                 t_launch += _time.perf_counter() - _t1
-                fut = writers.submit(write_batch, host, ev, utid, freq[0], original_len, f0_status)
+                fut = writers.submit(write_batch, host, ev, utid, freq[0], original_len, f0_status, refresh)
                 if slot is not None:
                     slot["busy"] = fut
                 pending_writes.append(fut)

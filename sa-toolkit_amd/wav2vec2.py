@@ -377,7 +377,8 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
         st = self.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0, "changed": 0})
         st["utterances"] += bn.shape[0] if status is not None else 0
         if defer_ties:
-            return bn, (lambda: self.resolve_ties(status, bn, feats, wav))
+            from .asrbn import TieFix
+            return bn, (TieFix(self, status, bn, feats, wav) if status is not None else None)
         self.resolve_ties(status, bn, feats, wav)
         return bn
 

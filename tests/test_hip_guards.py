@@ -84,9 +84,11 @@ def test_load_model_runs_the_precision_guard_on_a_trained_like_checkpoint(tmp_pa
     (b) the same checkpoint with ONE layer pair carrying a 2^12 gain (conv1 up, conv2 down: the same function): its inner activation
         reaches 2e4, still inside the f16 / e5m2 range (the sidecar is e5m2 BECAUSE of such layers) — nothing falls back and
         the 8-bit kernels still meet the bar;
-    (c) a 2^15 gain: the inner activation leaves the f16 range (counted by the range probe at that stage), both split arithmetics
-        fail the comparison with the exact-f32 kernels, the generator falls back to them and convert() meets the bar again instead
-        of saturating silently."""
+    (c) a 2^15 gain: the inner activation passes 65 504 (counted by the range probe at that stage).  The 8-bit sidecar saturates and
+        "f16f8r" fails the comparison with the exact-f32 kernels: the guard takes the generator to "f16x3", whose planes still carry
+        such values (hi, rounded toward zero, stops at 65 504 and lo takes the rest up to twice that) — convert() meets the path's bar;
+    (d) a 2^18 gain: both split arithmetics fail, the generator falls back to the exact-f32 kernels and convert() is at 1e-6 of the CPU
+        oracle again instead of saturating silently."""
     from oracle import convert as oconv
     from oracle import hifigan as ohg
     from satools_amd import synthetic
@@ -135,12 +137,24 @@ def test_load_model_runs_the_precision_guard_on_a_trained_like_checkpoint(tmp_pa
         warnings.simplefilter("always")
         model_c, rep_c = _load_through_the_guard(tmp_path, "one_pair_2p15", state_c, caplog)
     print("precision guard, one layer pair with a 2^15 gain:", rep_c)
-    assert "generator" in rep_c["fallback"] and model_c.hifigan.precision == "f32" and w, rep_c
+    assert rep_c["fallback"] == ["generator: f16f8r -> f16x3"] and model_c.hifigan.precision == "f16x3" and w, rep_c
     assert rep_c["generator_range"]["past_e5m2_max"][0] > 0, rep_c["generator_range"]        # (what the saturated stage hands on may count further down too)
     ref_c = oconv.convert_fbank(sd_c, model_c.spk, wav, model_c.spk[1], f0)
     err_c = rms(model_c.convert(wav.to(DEV), target=model_c.spk[1]).cpu().numpy() - ref_c.numpy())
-    print("convert() after the guard's fall-back to the exact-f32 kernels: RMS error against the CPU oracle", err_c)
-    assert err_c < 1e-5, err_c
+    print("convert() after the guard's fall-back to f16x3: RMS error against the CPU oracle", err_c)
+    assert err_c < 1e-4, err_c                       # the bar of the path; hi (round toward zero) stops at 65 504 and lo carries the rest up to 2 x that
+    # (d)
+    caplog.clear()
+    state_d, sd_d = _trained_like_state(sigma_rows=1.0, big_pair=(1, 1, 18))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model_d, rep_d = _load_through_the_guard(tmp_path, "one_pair_2p18", state_d, caplog)
+    print("precision guard, one layer pair with a 2^18 gain:", rep_d)
+    assert "generator" in rep_d["fallback"] and model_d.hifigan.precision == "f32" and w, rep_d
+    ref_d = oconv.convert_fbank(sd_d, model_d.spk, wav, model_d.spk[1], f0)
+    err_d = rms(model_d.convert(wav.to(DEV), target=model_d.spk[1]).cpu().numpy() - ref_d.numpy())
+    print("convert() after the guard's fall-back to the exact-f32 kernels: RMS error against the CPU oracle", err_d)
+    assert err_d < 1e-5, err_d
 
 
 def test_load_model_guard_can_be_skipped_and_leaves_synthetic_loads_alone(tmp_path, monkeypatch):
