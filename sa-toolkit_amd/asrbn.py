@@ -120,6 +120,7 @@ class TieFix:
 
     def __init__(self, ext, status, bn, feats, wav, idx=None):
         self.ext, self.status, self.bn, self.feats, self.wav, self.idx = ext, status, bn, feats, wav, idx
+        ext.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0, "changed": 0})
         self.stage, self.hit = (2, []) if status is None else (0, None)
         self.rows = self.zq = self.idx_x = self.flags = self.flag_row = self.event = self.side = None
 
@@ -143,16 +144,14 @@ class TieFix:
         side.wait_event(self.status.event)              # feats, wav and the indices precede the VQ launch's event on the batch's stream
         from .f0 import _pinned_ints
         self.flags, self.flag_row = _pinned_ints.take(len(rows))
-        ext.__dict__["_tie_busy"] = True
-        try:
-            with torch.cuda.stream(side):
-                self.zq, (_, self.idx_x, _) = ext._exact_rows(rows, self.feats, self.wav, want_aux=True)
-                changed = (self.idx_x != self.status.idx[rows]).any(dim=1)
-                self.flags.copy_(changed.to(torch.int32), non_blocking=True)
-                self.event = torch.cuda.Event()
-                self.event.record(side)
-        finally:
-            ext.__dict__["_tie_busy"] = False
+        # (the exact run takes the extractor's arithmetic lock while it launches: a launching thread and a writer thread that
+        # finishes another batch's decision do not meet half way; nothing in it asks for the guard again)
+        with torch.cuda.stream(side):
+            self.zq, (_, self.idx_x, _) = ext._exact_rows(rows, self.feats, self.wav, want_aux=True)
+            changed = (self.idx_x != self.status.idx[rows]).any(dim=1)
+            self.flags.copy_(changed.to(torch.int32), non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(side)
         self.rows, self.side, self.stage = rows, side, 1
         return True
 
