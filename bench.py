@@ -265,14 +265,26 @@ def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each, repeats=1
         step()
     drain()
     windows = []
+    chk = os.environ.get("SAT_BENCH_HOSTCHK") == "1"
+    host_ms = []
     for _ in range(max(1, repeats)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
+            if chk:
+                h0 = time.perf_counter()
+                step()
+                host_ms.append(1e3 * (time.perf_counter() - h0))
+            else:
+                step()
         drain()                              # every status of the window is checked inside it
         torch.cuda.synchronize()
         windows.append(time.perf_counter() - t0)
+    if chk and host_ms:
+        hs = sorted(host_ms)
+        import gc
+        print(f"HOSTCHK steps ({status}): host time per step mean {sum(hs) / len(hs):.2f} ms, median {hs[len(hs) // 2]:.2f}, p90 {hs[int(0.9 * len(hs))]:.2f}, "
+              f"max {hs[-1]:.2f}; gc counts {gc.get_count()}, gen2 collections {gc.get_stats()[2]['collections']}", file=sys.stderr, flush=True)
     return windows, setup_steps
 
 
@@ -687,6 +699,20 @@ def one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, wan
                                                     f"the headline is BASELINE.json's configs[1], the tag the metric is quoted on",
                            "parallelism": f"dp{world}" + (" sharded (contiguous shards, batches of 32 in index order)" if use_pg else "")},
                           **extra)}
+    if os.environ.get("SAT_BENCH_HOSTCHK") == "1":
+        # diagnostic: how long the launching thread needs to ENQUEUE ten generator forwards in this process state (no device wait)
+        import torch
+        xg = torch.randn(BATCH, model.hifigan.imput_dim, 250, device=dev)
+        model.hifigan(xg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            model.hifigan(xg)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"HOSTCHK {name}: enqueue of 10 generator forwards {1e3 * (t1 - t0):.1f} ms, until done {1e3 * (t2 - t0):.1f} ms; "
+              f"threads {torch.get_num_threads()}", file=sys.stderr, flush=True)
     if want_roofline:
         out["roofline"] = roofline_w2v2(model, dev, reps) if w2 else roofline_generator(model, dev, reps)
     if want_cpu:
@@ -769,6 +795,7 @@ def main():
                     help="generator arithmetic of every line (default: the package default, SATOOLS_AMD_GEN_PRECISION); when that is "
                          "f16f8r the headline tag is also measured as f16x3 and kept in `configs`")
     ap.add_argument("--cpu-worker", nargs=4, metavar=("TAG", "F0TR", "N", "INDEX"), default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-config", default=None, help=argparse.SUPPRESS)       # JSON spec of ONE side config measured in its own process
     ap.add_argument("--tag", default=None, help="measure only this tag (one line)")
     ap.add_argument("--f0-transformation", default="", help="with --tag: e.g. quant_16_awgn_2")
     a = ap.parse_args()
@@ -785,6 +812,38 @@ def main():
         env = dict(os.environ, MASTER_ADDR="127.0.0.1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         sys.exit(subprocess.call(cmd, env=env))
+
+    # N = 1, default run: every config but the headline is measured in its OWN process, one after the other, BEFORE this process touches
+    # the GPU (round 6: in one process the later configs of a run were slower than the same config alone — per-step host waits with a
+    # heavier tail, and a device-wide slowdown for the rest of the process once a high-priority stream had been created, DESIGN toolchain
+    # note 22 — so a line must not depend on what ran before it).  The children print their full line; the headline runs here, last.
+    child_lines = []
+    side_in_children = (a.gpus == 1 and "WORLD_SIZE" not in os.environ and not a.tag and not a.headline_only and not a.child_config and
+                        os.environ.get("SAT_BENCH_FORCE_PG") != "1" and os.environ.get("SAT_BENCH_DRYRUN") != "1")
+    if side_in_children:
+        k2 = min(a.steps, 12)
+        specs = [dict(name="configs[2]", tag=TAG_W2V2, f0_tr="", steps=k2, warmup=a.warmup,
+                      cpu_args=dict(n_utt=8, runs_1=1, runs_n=3, n_utt_1=4, procs=8, n_utt_proc=2)),
+                 dict(name="configs[3]", tag=TAG_W2V2, f0_tr="quant_16_awgn_2", steps=k2, warmup=a.warmup,
+                      cpu_args=dict(n_utt=8, runs_1=1, runs_n=1, n_utt_1=2,
+                                    budget_note="; configs[3] differs from configs[2] by the quantisation + noise of 250 x B values only, so its CPU leg is a shorter sample"))]
+        prec0 = a.gen_precision or os.environ.get("SATOOLS_AMD_GEN_PRECISION", "f16f8r")
+        if prec0 == "f16f8r":
+            # the headline tag on the f16x3 generator too, beside the headline (same run, same box)
+            specs.append(dict(name="configs[1] generator f16x3", tag=TAG, f0_tr="", steps=a.steps, warmup=a.warmup, cpu_args=None, gen_precision="f16x3"))
+        if a.f0_status == "deferred":
+            # ... and with the plain convert() call (rounds 1-5 measured the headline that way)
+            specs.append(dict(name="configs[1] plain convert()", tag=TAG, f0_tr="", steps=a.steps, warmup=a.warmup, cpu_args=None, status="sync", roofline=False))
+        for spec in specs:
+            spec["repeats"] = min(a.repeats, 3)
+            cmd = [sys.executable, os.path.abspath(__file__), "--child-config", json.dumps(spec), "--jobs", str(a.jobs), "--f0-status", a.f0_status,
+                   "--gather", a.gather] + (["--no-cpu-baseline"] if a.no_cpu_baseline else []) + (["--gen-precision", a.gen_precision] if a.gen_precision else [])
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=1500)
+            got = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not got:
+                print(f"bench.py: the child process measuring {spec['name']} failed (exit code {r.returncode})", file=sys.stderr)
+                sys.exit(3)
+            child_lines.append(json.loads(got[-1]))
 
     import torch
     import torch.distributed as dist
@@ -815,7 +874,16 @@ def main():
         flush_c_stdio()
 
     want_cpu = (not a.no_cpu_baseline) and world == 1 and not use_pg
-    lines = []
+    lines = list(child_lines)
+    if a.child_config:
+        # one side config, alone in this process: its full line on stdout
+        spec = json.loads(a.child_config)
+        cpu_args = spec.get("cpu_args")
+        out = one_config(spec["name"], spec["tag"], spec["f0_tr"], a, dev, rank, world, False, spec["steps"], spec["warmup"],
+                         want_cpu and cpu_args is not None, cpu_args or {}, repeats=spec.get("repeats", 3),
+                         gen_precision=spec.get("gen_precision") or a.gen_precision, status=spec.get("status"), want_roofline=spec.get("roofline", True))
+        print(json.dumps(out), flush=True)
+        return
     if a.tag:
         plan = [("--tag", a.tag, a.f0_transformation, a.steps, a.warmup, dict(n_utt=8, runs_1=1, runs_n=3, n_utt_1=4))]
     elif use_pg:
@@ -823,30 +891,12 @@ def main():
         plan = ([] if a.headline_only else [("configs[4]", TAG_W2V2, "", k2, min(a.warmup, 4), None)]) + \
                [("configs[1] sharded", TAG, "", a.steps, a.warmup, None)]
     else:
-        k2 = min(a.steps, 12)
-        plan = ([] if a.headline_only else [
-            ("configs[2]", TAG_W2V2, "", k2, a.warmup, dict(n_utt=8, runs_1=1, runs_n=3, n_utt_1=4, procs=8, n_utt_proc=2)),
-            ("configs[3]", TAG_W2V2, "quant_16_awgn_2", k2, a.warmup,
-             dict(n_utt=8, runs_1=1, runs_n=1, n_utt_1=2,
-                  budget_note="; configs[3] differs from configs[2] by the quantisation + noise of 250 x B values only, so its CPU leg is a shorter sample"))]) + \
-            [("configs[1]", TAG, "", a.steps, a.warmup, dict(n_utt=8, runs_1=3, runs_n=3, procs=32, n_utt_proc=4))]
-    from satools_amd.hifigan import CoreHifiGan
-    prec = a.gen_precision or CoreHifiGan.precision
-    if prec == "f16f8r" and not a.tag and not use_pg and not a.headline_only:
-        # the headline tag on the f16x3 generator too, beside the headline (same run, same box)
-        plan.insert(len(plan) - 1, ("configs[1] generator f16x3", TAG, "", a.steps, a.warmup, "f16x3"))
-    if a.f0_status == "deferred" and not a.tag and not use_pg and not a.headline_only:
-        # ... and with the plain convert() call (rounds 1-5 measured the headline that way)
-        plan.insert(len(plan) - 1, ("configs[1] plain convert()", TAG, "", a.steps, a.warmup, "status:sync"))
+        # (the other configs of a default N = 1 run were measured in child processes above)
+        plan = [("configs[1]", TAG, "", a.steps, a.warmup, dict(n_utt=8, runs_1=3, runs_n=3, procs=32, n_utt_proc=4))]
     for i, (name, tag, f0_tr, steps, warmup, cpu_args) in enumerate(plan):
         headline = i == len(plan) - 1
-        alt = cpu_args if isinstance(cpu_args, str) else None           # a generator precision / a status mode instead of CPU-leg arguments
-        cpu_args = None if alt else cpu_args
-        st_alt = alt[len("status:"):] if alt and alt.startswith("status:") else None
-        alt = None if st_alt else alt
         out = one_config(name, tag, f0_tr, a, dev, rank, world, use_pg, steps, warmup, want_cpu and cpu_args is not None, cpu_args or {},
-                         repeats=a.repeats if headline else min(a.repeats, 3), gen_precision=alt or a.gen_precision, status=st_alt,
-                         want_roofline=st_alt is None)
+                         repeats=a.repeats if headline else min(a.repeats, 3), gen_precision=a.gen_precision)
         torch.cuda.empty_cache()
         if rank == 0:
             lines.append(out)
@@ -876,7 +926,7 @@ def main():
                         d["cpu_baseline"]["processes"] = {"value": cb["processes"]["value"], "processes": cb["processes"]["processes"]}
                 return d
             head["configs"] = {o["config"]["workload"].split(":")[0]: brief(o) for o in lines[:-1]}
-            if not use_pg and not a.tag:
+            if not use_pg and not a.tag and side_in_children:
                 head["configs"].update(aux_forwards(dev))
             for o in lines[:-1]:
                 print("CONFIG_LINE " + json.dumps(o), file=sys.stderr, flush=True)

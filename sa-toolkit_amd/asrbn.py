@@ -140,7 +140,9 @@ class TieFix:
         sides = ext.__dict__.setdefault("_tie_streams", {})
         side = sides.get(cur.cuda_stream)
         if side is None:
-            side = sides[cur.cuda_stream] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SATOOLS_AMD_VQ_TIE_STREAM_PRIORITY", "-1")))
+            # (normal priority: a HIGH-priority stream, once created, left every later launch of the process slower — generator alone
+            # 7.7 -> 10.7 -> 12.0 ms over the configs of one bench.py run, DESIGN toolchain note 22)
+            side = sides[cur.cuda_stream] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SATOOLS_AMD_VQ_TIE_STREAM_PRIORITY", "0")))
         side.wait_event(self.status.event)              # feats, wav and the indices precede the VQ launch's event on the batch's stream
         from .f0 import _pinned_ints
         self.flags, self.flag_row = _pinned_ints.take(len(rows))

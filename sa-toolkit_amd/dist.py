@@ -142,7 +142,7 @@ class ChunkedGather:
 
 
 def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, local_out=None, before_gather=None, transform=None,
-                    gather_chunk_batches=0, before_chunk=None, stats=None):
+                    gather_chunk_batches=0, before_chunk=None, stats=None, gather_chunk_lag=1):
     """run `convert_fn(lo, hi) -> [hi-lo, ...]` over this rank's shard in fixed batches and
     (optionally) all-gather the results in global index order.
 
@@ -156,7 +156,10 @@ def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, lo
     `gather_chunk_batches` = K > 0 (needs `local_out`): the exchange is issued in chunks of K batches as they are enqueued
     (`ChunkedGather`) instead of once at the end — `before_chunk(c, a, b)` runs before chunk c (local rows [a, b)) is handed to the
     collective and may return a context manager the issue runs inside (e.g. a communication stream that waits for the job streams of
-    those batches).  The result equals the one-collective path's; `stats` (a dict) receives the per-chunk host timings."""
+    those batches).  The result equals the one-collective path's; `stats` (a dict) receives the per-chunk host timings.
+    `gather_chunk_lag` = L (default 1): chunk c is handed to the collective once the batches of chunk c + L have been enqueued too — a
+    caller whose batches carry deferred work (`convert(..., defer_status=True)`: rows may be rewritten until the batch's status has been
+    checked, which it does before the same job's next batch) then never has to finish that work for batches it has only just launched."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if n_items < world:
         raise ValueError(f"convert_sharded: {n_items} items cannot be sharded over {world} ranks (every rank needs one)")
@@ -180,9 +183,11 @@ def convert_sharded(convert_fn, n_items, batch_size, gather=True, group=None, lo
     outs, done = [], 0
     for i, (s, e) in enumerate(batches(lo, hi, batch_size)):
         outs.append(convert_fn(s, e))
-        if chunked is not None and (i + 1) % gather_chunk_batches == 0:
-            issue_chunk(done)
-            done += 1
+        if chunked is not None:
+            ready = (i + 1) // gather_chunk_batches - max(0, int(gather_chunk_lag))     # chunks enqueued at least `lag` chunks ago
+            while done < min(ready, chunked.n_chunks):
+                issue_chunk(done)
+                done += 1
     if local_out is not None:
         local = local_out
     else:
