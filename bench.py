@@ -249,10 +249,12 @@ def run_steps(model, dev, rank, steps, warmup, jobs, seed_before_each, repeats=1
             if status == "sync":
                 return model.convert(wav, target=targets)
             y, pending[j] = model.convert(wav, target=targets, defer_status=True)
-        # the batch launched two steps ago: its VQ launch has completed by now — its near-tie utterances (if any) go to the exact kernels
-        # on a side stream WITHOUT the launching thread waiting for them (ConvertStatus.start; check() two steps on finds them decided)
-        if jobs > 2 and pending[(j - 2) % jobs] is not None:
-            pending[(j - 2) % jobs].start()
+        # the batches launched in the previous steps: as soon as a batch's VQ launch has completed (a query, no wait) its near-tie
+        # utterances (if any) go to the exact kernels on a side stream WITHOUT the launching thread waiting for them
+        # (ConvertStatus.start; check() before the job's next batch finds them decided)
+        for k in range(1, jobs):
+            if pending[(j - k) % jobs] is not None:
+                pending[(j - k) % jobs].start()
         return y
 
     def drain():
@@ -344,8 +346,10 @@ def run_sharded(model, dev, rank, world, steps, warmup, jobs, seed_before_each, 
             e = torch.cuda.Event()
             e.record(s)
             produced[a] = e
-        if status != "sync" and jobs > 2 and pending[(j - 2) % jobs] is not None:
-            pending[(j - 2) % jobs][0].start()           # (run_steps: the near-tie utterances of the batch launched two steps ago, without waiting)
+        if status != "sync":
+            for k in range(1, jobs):                     # (run_steps: the near-tie utterances of the batches launched before, without waiting)
+                if pending[(j - k) % jobs] is not None:
+                    pending[(j - k) % jobs][0].start()
         return None
 
     def before_chunk(c, ra, rb):

@@ -36,20 +36,30 @@ class ConvertStatus:
     `check()`; when rows were replaced, `check()` returns after they have been written."""
 
     def __init__(self, f0_status, fix, patch, stream, deferred):
+        import threading
         self.f0_status, self.fix, self.patch, self.stream, self.deferred = f0_status, fix, patch, stream, deferred
         self.rows = None
+        self._lock = threading.Lock()          # start() from a launching thread, check() from the thread that consumes y
 
     def start(self):
         """non-blocking: begin the second decision of the batch's near-tie utterances if its VQ launch has completed (asrbn.TieFix.start);
         a loop that keeps several batches in flight calls it a step or two before `check()`, which then finds the work done"""
-        if self.fix is not None and self.rows is None:
-            with torch.cuda.stream(self.stream):
-                return self.fix.start()
+        if self.fix is not None and self.rows is None and self._lock.acquire(blocking=False):
+            try:
+                if self.fix is not None and self.rows is None:
+                    with torch.cuda.stream(self.stream):
+                        return self.fix.start()
+            finally:
+                self._lock.release()
         return True
 
     def check(self):
         if self.f0_status is not None:
             self.f0_status.check()
+        with self._lock:
+            self._check_locked()
+
+    def _check_locked(self):
         if self.rows is None:
             self.rows = []
             if self.fix is not None:

@@ -381,6 +381,8 @@ def _process_data(dataset_path, target_selection_algorithm, wavscps, settings, p
             write_riff_pcm16(results_dir / f"{utid[i]}.wav", pcm16_of(wav[:, :int(original_len[i])]), freq)
 
     pending_writes, n_done = [], 0
+    import collections
+    recent_status = collections.deque(maxlen=8)
     scp_lines = [[] for _ in shards]
     # round-robin over the jobs of this device: one batch of each in flight, each on its own stream; the next
     # batches are being read meanwhile
@@ -479,6 +481,12 @@ def _process_data(dataset_path, target_selection_algorithm, wavscps, settings, p
                             f0_status.check()       # (no streams: the copy below is synchronous anyway; the deferred work first, it may rewrite rows)
                         host, ev = wav_conv.cpu(), None
                 t_launch += _time.perf_counter() - _t1
+                if f0_status is not None and hasattr(f0_status, "start"):
+                    # batches launched before this one: where a batch's VQ launch has completed (a query, no wait), its near-tie utterances go
+                    # to the exact kernels now, so that the writer's check() finds them decided (anonymizer.ConvertStatus.start)
+                    for st in recent_status:
+                        st.start()
+                    recent_status.append(f0_status)
                 fut = writers.submit(write_batch, host, ev, utid, freq[0], original_len, f0_status, refresh)
                 if slot is not None:
                     slot["busy"] = fut
