@@ -822,7 +822,7 @@ def main():
     # heavier tail, and a device-wide slowdown for the rest of the process once a high-priority stream had been created, DESIGN toolchain
     # note 22 — so a line must not depend on what ran before it).  The children print their full line; the headline runs here, last.
     child_lines = []
-    side_in_children = (a.gpus == 1 and "WORLD_SIZE" not in os.environ and not a.tag and not a.headline_only and not a.child_config and
+    side_in_children = (a.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not a.tag and not a.headline_only and not a.child_config and
                         os.environ.get("SAT_BENCH_FORCE_PG") != "1" and os.environ.get("SAT_BENCH_DRYRUN") != "1")
     if side_in_children:
         k2 = min(a.steps, 12)

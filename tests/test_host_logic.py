@@ -222,6 +222,17 @@ for K in (1, 2, 5):
     exp_chunks = {{1: [(0, 0, 4), (1, 4, hi - lo)], 2: [(0, 0, hi - lo)], 5: [(0, 0, hi - lo)]}}[K]
     assert order == exp_chunks, (K, order)
     assert len(st["chunks"]) == len(exp_chunks) and all("wait_ms" in c for c in st["chunks"])
+# the chunks lag one chunk behind the launches (a batch's deferred work — rows that may be rewritten until its status has been checked —
+# is never finished early for the collective); gather_chunk_lag=0 hands a chunk over right behind its last batch
+for lag, exp_seen in ((1, [2, 2]), (0, [1, 2])):
+    buf.fill_(-1.0)
+    produced, seen = [0], []
+    def fill_counting(a, b):
+        produced[0] += 1
+        fill(a, b)
+    out7 = sdist.convert_sharded(fill_counting, N, batch_size=4, local_out=buf, gather_chunk_batches=1, gather_chunk_lag=lag,
+                                 before_chunk=lambda c, a, b: seen.append(produced[0]))
+    assert torch.equal(out7, out) and seen == exp_seen, (lag, seen)
 out5 = sdist.convert_sharded(lambda a, b: buf.__setitem__(slice(a - lo, b - lo), (torch.arange(a, b, dtype=torch.float32).view(-1, 1, 1) / 32768.0) * torch.ones(1, 1, 5)),
                              N, batch_size=4, local_out=buf, transform=sdist.pcm16_rows, gather_chunk_batches=1)
 assert out5.dtype == torch.int16 and torch.equal(out5, out3)
