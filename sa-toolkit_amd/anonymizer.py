@@ -373,9 +373,11 @@ def build(args):
             return (f0, bn, spk_id)
 
         def convert(self, x, target, defer_status=False):
-            """hifigan.py:58-71.  defer_status=True (not in the reference): returns (y, status) without waiting for YAAPT's status word —
-            `status.check()` raises what this call would have raised (None when the F0 came from `set_f0`); a caller that keeps several
-            batches in flight checks a batch's status before it uses y instead of making a round trip to the GPU per call"""
+            """hifigan.py:58-71.  defer_status=True (not in the reference): returns (y, status) without waiting for the GPU — `status`
+            (ConvertStatus) carries the call's deferred work: `status.check()` raises what this call would have raised (YAAPT's status
+            word) and finishes the second decision of near-tie utterances of the VQ, whose rows of y it may rewrite (`status.rows`);
+            `status.start()` begins that decision without blocking.  A caller that keeps several batches in flight checks a batch's
+            status before it uses y instead of making round trips to the GPU inside every call"""
             self._defer_f0_status, self._f0_status, self._bn_fix = True, None, None
             try:
                 (f0, bn, spk_id) = self.extract_features(x, target)
