@@ -373,11 +373,12 @@ int sat_fbank_cmvn_pad_f32(const float* wav, float* feats, const float* window, 
  * ------------------------------------------------------------------------------------------ */
 int sat_vq_argmin_gather_f32(const float* z, const float* codebook, float* q, int32_t* idx,
                              float* dist, int B, int D, int T, int n_codes, void* stream);
-/* ABI 7.  The same, and tie_count[b] += the frames of utterance b whose two best codes a, a' are a NEAR-TIE of this arithmetic:
+/* ABI 7.  The same, and tie_count[0][b] += the frames of utterance b whose two best codes a, a' are a NEAR-TIE of this arithmetic:
  * d[a'] - d[a] <= tie_scale * |z_t| * pair_dist[a][a'] (pair_dist [n_codes][n_codes] = |e_a - e_a'|; tie_scale = 2 K sigma_rel / sqrt(D),
  * K standard deviations of the calibrated per-component feature error of the split-f16 extractor against its exact-f32 twin).  The
  * host re-decides flagged utterances on the exact-f32 kernels (asrbn.py), so that the indices of the default arithmetic are the
- * exact ones (chain/nn.py:424-459 is index work).  tie_count [B] int32, zeroed by the caller. */
+ * exact ones (chain/nn.py:424-459 is index work).  tie_count [3][B] int32: row 0 the counts (zeroed by the caller), row 1 the first and
+ * row 2 the last near-tie frame of the utterance (the caller sets them to INT32_MAX / -1): the frames in between are what is decided again. */
 int sat_vq_argmin_gather_tie_f32(const float* z, const float* codebook, float* q, int32_t* idx, float* dist,
                                  const float* pair_dist, float tie_scale, int32_t* tie_count,
                                  int B, int D, int T, int n_codes, void* stream);

@@ -84,8 +84,9 @@ class TieStatus:
     def __init__(self, counts_dev, idx_dev):
         from .f0 import _pinned_ints
         self._pool = _pinned_ints
+        self.B = counts_dev.shape[1]
         self.host, self.row = _pinned_ints.take(counts_dev.numel())
-        self.host.copy_(counts_dev, non_blocking=True)
+        self.host.copy_(counts_dev.reshape(-1), non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
         self.counts = None
@@ -94,11 +95,15 @@ class TieStatus:
     def rows(self):
         if self.counts is None:
             self.event.synchronize()
-            self.counts = self.host.clone()
+            self.counts = self.host.clone().reshape(3, self.B)      # counts | first | last near-tie frame
             self.host = None
             self._pool.give(self.row)
             self.row = None
-        return torch.nonzero(self.counts).flatten().tolist()
+        return torch.nonzero(self.counts[0]).flatten().tolist()
+
+    def spans(self, rows):
+        """(first, last) near-tie frame of each of `rows` (after rows())"""
+        return [(int(self.counts[1, r]), int(self.counts[2, r])) for r in rows]
 
     def __del__(self):
         try:
@@ -122,7 +127,7 @@ class TieFix:
         self.ext, self.status, self.bn, self.feats, self.wav, self.idx = ext, status, bn, feats, wav, idx
         ext.__dict__.setdefault("tie_stats", {"utterances": 0, "rerun": 0, "changed": 0})
         self.stage, self.hit = (2, []) if status is None else (0, None)
-        self.rows = self.zq = self.idx_x = self.flags = self.flag_row = self.event = self.side = None
+        self.rows = self.zq = self.idx_x = self.t0 = self.flags = self.flag_row = self.event = self.side = None
 
     def start(self, block=False):
         if self.stage:
@@ -149,8 +154,12 @@ class TieFix:
         # (the exact run takes the extractor's arithmetic lock while it launches: a launching thread and a writer thread that
         # finishes another batch's decision do not meet half way; nothing in it asks for the guard again)
         with torch.cuda.stream(side):
-            self.zq, (_, self.idx_x, _) = ext._exact_rows(rows, self.feats, self.wav, want_aux=True)
-            changed = (self.idx_x != self.status.idx[rows]).any(dim=1)
+            self.zq, self.idx_x, self.t0 = ext._exact_rows(rows, self.feats, self.wav, spans=self.status.spans(rows))
+            Lq = self.idx_x.shape[1]
+            if all(t == 0 for t in self.t0) and Lq == self.status.idx.shape[1]:
+                changed = (self.idx_x != self.status.idx[rows]).any(dim=1)
+            else:
+                changed = torch.stack([(self.idx_x[i] != self.status.idx[r, t:t + Lq]).any() for i, (r, t) in enumerate(zip(rows, self.t0))])
             self.flags.copy_(changed.to(torch.int32), non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(side)
@@ -181,9 +190,12 @@ class TieFix:
                 cur.wait_stream(self.side)
                 self.zq.record_stream(cur)
                 self.idx_x.record_stream(cur)
-                self.bn[self.hit] = self.zq[sel].permute(0, 2, 1)
-                if self.idx is not None:
-                    self.idx[self.hit] = self.idx_x[sel]
+                Lq = self.idx_x.shape[1]
+                for i in sel:                 # (the frames the exact run computed: the whole utterance, or the window around its near-ties)
+                    r, t = rows[i], self.t0[i]
+                    self.bn[r, t:t + Lq] = self.zq[i].t()
+                    if self.idx is not None:
+                        self.idx[r, t:t + Lq] = self.idx_x[i]
             self.stage = 2
             self.zq = self.idx_x = None
             self._drop()
@@ -463,15 +475,51 @@ class _TdnnfBase(nn.Module):
         guard = self._tie_guard(feats.device)
         if guard is None:
             return self._run_stack(feats, want_aux=want_aux), None
-        ctx = _TieCtx(guard[0], guard[1], torch.zeros(feats.shape[0], dtype=torch.int32, device=feats.device))
+        B = feats.shape[0]
+        init = self.__dict__.setdefault("_tie_init", {})
+        tmpl = init.get((B, str(feats.device)))
+        if tmpl is None:            # counts 0 | first near-tie frame INT32_MAX | last -1
+            tmpl = init[(B, str(feats.device))] = torch.tensor([[0] * B, [2 ** 31 - 1] * B, [-1] * B], dtype=torch.int32).to(feats.device)
+        ctx = _TieCtx(guard[0], guard[1], tmpl.clone())
         out = self._run_stack(feats, want_aux=want_aux, tie=ctx)
         return out, TieStatus(ctx.counts, ctx.idx)
 
-    def _exact_rows(self, rows, feats, wav, want_aux=False):
-        """the quantised bottleneck [len(rows), D, T'] of utterances `rows` on the exact-f32 kernels, from the batch's padded features
-        `feats` (f32 front end: the fbank tag) — the wav2vec2 tag overrides this to recompute its encoder for those rows"""
+    def _stack_receptive_field(self):
+        """(S, W): output frame t of the TDNNF stack (tdnn1 .. the VQ layer's bottleneck) reads the padded input frames S t .. S t + W - 1
+        ('valid' windows of context_len frames every subsampling_factor frames, chain/nn.py:267-278)"""
+        S, W = 1, 1
+        for lay in reversed(self._stack_layers()):
+            sub, ctx = int(lay.subsampling_factor), int(lay.context_len)
+            W = (W - 1) * sub + ctx
+            S *= sub
+        return S, W
+
+    def _exact_rows(self, rows, feats, wav, spans=None):
+        """Utterances `rows` on the exact-f32 kernels, from the batch's padded features `feats` (f32 front end: the fbank tag; the
+        wav2vec2 tag overrides this and recomputes its encoder for those rows).  -> (zq [n, D, L'], idx [n, L'], t0 [n]): row i holds
+        the output frames t0[i] .. t0[i] + L' - 1 of utterance rows[i].
+        `spans` = (first, last) near-tie frame per row: only a WINDOW of the utterance is computed — every layer is a 'valid' window over
+        frames, so the frames first .. last depend on the input frames S first .. S last + W - 1 alone, and the exact kernels give a
+        frame the same bits whatever the tile it falls in: the window's frames ARE the full run's (asserted by
+        tests/test_hip_guards.py).  Rows share one window length (the longest, moved left where it would pass the end); a window of
+        three quarters of the utterance or more is the full run.  A flagged utterance then costs launches of 2 - 4 blocks instead of 16."""
+        n, Tf = len(rows), feats.shape[2]
+        S, W = self._stack_receptive_field()
+        starts = [0] * n
+        L = Tf
+        if spans is not None:
+            need = max(S * (hi - lo) + W for lo, hi in spans)
+            need += (Tf - need) % S                              # (Tf - L) a multiple of S: a window moved to the end stays aligned
+            if need * 4 < Tf * 3:
+                L = need
+                starts = [min(S * lo, Tf - L) for lo, _ in spans]
         with self._exact(self):
-            return self._run_stack(feats[rows].contiguous(), want_aux=want_aux)
+            if L == Tf:
+                sub = feats[rows].contiguous()
+            else:
+                sub = torch.stack([feats[r, :, a:a + L] for r, a in zip(rows, starts)]).contiguous()
+            zq, (_, idx_x, _) = self._run_stack(sub, want_aux=True)
+        return zq, idx_x, [a // S for a in starts]
 
     #: tests: treat every flagged utterance as changed (the rows are rewritten and the caller generates them again)
     vq_tie_force_patch = False

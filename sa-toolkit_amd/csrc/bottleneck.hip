@@ -148,7 +148,13 @@ __global__ void __launch_bounds__(256) vq_kernel(const float* __restrict__ z, co
     // near-tie of the two best codes: their gap is inside what the arithmetic's feature error (tie_scale * |z_t| per unit of
     // code distance: asrbn.py calibrates it) can move the two distances against each other -> the utterance is decided again on the exact kernels
     const float gap = secondd - bestd;
-    if (!(gap > tie_scale * sqrtf(xx) * pair_dist[best * n_codes + second])) atomicAdd(tie_count + b, 1);
+    if (!(gap > tie_scale * sqrtf(xx) * pair_dist[best * n_codes + second])) {
+      // count, first and last near-tie frame of the utterance: tie_count [3][B] (the host decides the frames in between again)
+      const int B = (int)gridDim.y;
+      atomicAdd(tie_count + b, 1);
+      atomicMin(tie_count + B + b, t);
+      atomicMax(tie_count + 2 * B + b, t);
+    }
   }
   if (!live) return;
   if (grp == 0) idx_out[(size_t)b * T + t] = best;
@@ -388,7 +394,7 @@ extern "C" int sat_vq_argmin_gather_f32(const float* z, const float* codebook, f
 extern "C" int sat_vq_argmin_gather_tie_f32(const float* z, const float* codebook, float* q, int32_t* idx, float* dist,
                                             const float* pair_dist, float tie_scale, int32_t* tie_count,
                                             int B, int D, int T, int n_codes, void* stream) {
-  SAT_REQUIRE(pair_dist && tie_count && tie_scale >= 0.f, "vq(tie): pair_dist [n_codes][n_codes], tie_count [B] and a tie_scale >= 0");
+  SAT_REQUIRE(pair_dist && tie_count && tie_scale >= 0.f, "vq(tie): pair_dist [n_codes][n_codes], tie_count [3][B] and a tie_scale >= 0");
   return vq_launch(z, codebook, q, idx, dist, pair_dist, tie_scale, tie_count, B, D, T, n_codes, stream);
 }
 

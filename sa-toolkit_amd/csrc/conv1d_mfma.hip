@@ -73,29 +73,37 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
 
+  // XWI > 0 (compile-time trip counts): the input rows of chunk c + 1 are requested into registers BEFORE the MFMA phase of chunk c and
+  // stored to LDS behind it (round 6): a launch with few blocks per CU — one or two utterances on the exact-f32 kernels, what the
+  // near-tie guard of the VQ runs — no longer pays one exposed global round trip per 16-channel chunk.  Same chunks in the same order:
+  // the same bits.
+  constexpr int XWR = XWI > 0 ? XWI : 1;
+  float stg[CI_CHUNK / 4][XWR];
+  auto request_rows = [&](int c0) __attribute__((always_inline)) {
+    // every global load of the chunk is issued before the first LDS store, so the loads overlap each other
+    const int voff = (xi0 + lane) * 4;  // byte offset inside the row; negative / past-the-end -> 0 by the range check
+#pragma unroll
+    for (int rr = 0; rr < CI_CHUNK / 4; ++rr) {
+      const int ci = c0 + wave + rr * 4;
+      // one buffer descriptor per (utterance, channel) row: the hardware range check supplies the
+      // conv's zero padding on both sides; descriptor inputs are wave-uniform (readfirstlane, T20)
+      const unsigned long long a = (unsigned long long)(xg + (long long)ci * p.x_cs);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+      const unsigned nbytes = __builtin_amdgcn_readfirstlane(ci < p.cin_g ? (unsigned)p.T_in * 4u : 0u);
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(((unsigned long long)hi << 32) | lo), 0, nbytes, 0x00020000);
+#pragma unroll
+      for (int it = 0; it < XWR; ++it)
+        stg[rr][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 256 * it, 0, 0));
+    }
+  };
+  if constexpr (XWI > 0) request_rows(0);
+
   for (int c0 = 0; c0 < p.cin_pad; c0 += CI_CHUNK) {
     __syncthreads();
     // ---- stage the input tile: 16 channels x XW columns, pre-activation fused ----
     if constexpr (XWI > 0) {
-      // compile-time trip counts: every global load of the chunk is issued before the first LDS
-      // store, so the loads overlap each other instead of running one dependent round trip each
-      float stg[CI_CHUNK / 4][XWI];
-      const int voff = (xi0 + lane) * 4;  // byte offset inside the row; negative / past-the-end -> 0 by the range check
-#pragma unroll
-      for (int rr = 0; rr < CI_CHUNK / 4; ++rr) {
-        const int ci = c0 + wave + rr * 4;
-        // one buffer descriptor per (utterance, channel) row: the hardware range check supplies the
-        // conv's zero padding on both sides; descriptor inputs are wave-uniform (readfirstlane, T20)
-        const unsigned long long a = (unsigned long long)(xg + (long long)ci * p.x_cs);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        const unsigned nbytes = __builtin_amdgcn_readfirstlane(ci < p.cin_g ? (unsigned)p.T_in * 4u : 0u);
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(((unsigned long long)hi << 32) | lo), 0, nbytes, 0x00020000);
-#pragma unroll
-        for (int it = 0; it < XWI; ++it)
-          stg[rr][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 256 * it, 0, 0));
-      }
 #pragma unroll
       for (int rr = 0; rr < CI_CHUNK / 4; ++rr) {
         float* dst = lds + (wave + rr * 4) * XW;
@@ -127,7 +135,17 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
       }
     }
     __syncthreads();
-    if (!wave_active) continue;
+    // (the next chunk's rows are requested BEHIND this chunk's first weight loads: vmcnt retires in issue order, so a wait for a
+    // weight fragment also waits for every older load)
+    auto request_next = [&]() __attribute__((always_inline)) {
+      if constexpr (XWI > 0) {
+        if (c0 + CI_CHUNK < p.cin_pad) request_rows(c0 + CI_CHUNK);      // in flight during this chunk's MFMA phase
+      }
+    };
+    if (!wave_active) {
+      request_next();
+      continue;
+    }
 
     const int wc_soff = c0 * w_ci_bytes;   // scalar byte offset of this chunk's first channel
     const float* xrow = lds + lh * XW + (wn * (32 * NT) + l31) * st;
@@ -135,12 +153,41 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
   __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32( \
       wrsrc, a_voff + (m) * 128, wc_soff + (2 * (pair)) * w_ci_bytes + (tap) * p.co_pad * 4, 0))
 
-    if constexpr (KS > 0) {
+    if constexpr (KS > 0 && KS * MT <= 4) {
+      // few taps and row tiles (the 1x1 GEMM shapes of the encoders, TDNNF linearA / linearB): ALL weight fragments of the chunk are
+      // requested up front (8 channel pairs x KS x MT <= 32 registers) — one round trip per chunk instead of one per channel pair,
+      // which is what a launch of a few blocks per CU waits for (round 6; the same products in the same order)
+      float a_all[CI_CHUNK / 2][KS][MT];
+#pragma unroll
+      for (int pr = 0; pr < CI_CHUNK / 2; ++pr)
+#pragma unroll
+        for (int t = 0; t < KS; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a_all[pr][t][m] = SAT_LOAD_A(pr, t, m);
+      request_next();
+#pragma unroll
+      for (int pr = 0; pr < CI_CHUNK / 2; ++pr) {
+        const float* xp = xrow + (2 * pr) * XW;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+          float bf[NT];
+          const float* xt = xp + t * p.dil;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bf[n] = xt[n * 32 * st];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_all[pr][t][m], bf[n], acc[m][n], 0, 0, 0);
+        }
+      }
+    } else if constexpr (KS > 0) {
       float a_cur[KS][MT];
 #pragma unroll
       for (int t = 0; t < KS; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m) a_cur[t][m] = SAT_LOAD_A(0, t, m);
+      request_next();
 #pragma unroll
       for (int pr = 0; pr < CI_CHUNK / 2; ++pr) {
         float a_nxt[KS][MT];
@@ -175,6 +222,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_kernel(const ConvArgs p) {
       }
     } else {
       // runtime tap count (k = 2, 10, 128 ...): taps looped, one k-pair of channels at a time
+      request_next();
 #pragma unroll 1
       for (int pr = 0; pr < CI_CHUNK / 2; ++pr) {
         const float* xp = xrow + (2 * pr) * XW;

@@ -176,8 +176,8 @@ def fbank_cmvn_pad(wav, window, mel, mel_lo, mel_hi, *, scale=32768.0, pad=0, cm
 
 
 def vq(z, codebook, want_dist=False, tie=None):
-    """`tie` = (pair_dist [n_codes, n_codes], tie_scale, tie_count [B] int32): also count, per utterance, the frames whose two best
-    codes are a near-tie (sat_vq_argmin_gather_tie_f32)"""
+    """`tie` = (pair_dist [n_codes, n_codes], tie_scale, tie_count [3, B] int32: counts (zeroed) | first (INT32_MAX) | last (-1) near-tie
+    frame): also count, per utterance, the frames whose two best codes are a near-tie (sat_vq_argmin_gather_tie_f32)"""
     z = _f32c(z)
     B, D, T = z.shape
     n_codes = codebook.shape[0]
@@ -186,8 +186,8 @@ def vq(z, codebook, want_dist=False, tie=None):
     dist = torch.empty(B, T, n_codes, dtype=torch.float32, device=z.device) if want_dist else None
     if tie is not None:
         pair, scale, count = tie
-        if tuple(pair.shape) != (n_codes, n_codes) or pair.dtype != torch.float32 or count.dtype != torch.int32 or count.numel() != B:
-            raise _lib.SatError("vq: tie = (pair_dist [n_codes, n_codes] f32, tie_scale, tie_count [B] int32)")
+        if tuple(pair.shape) != (n_codes, n_codes) or pair.dtype != torch.float32 or count.dtype != torch.int32 or count.numel() != 3 * B:
+            raise _lib.SatError("vq: tie = (pair_dist [n_codes, n_codes] f32, tie_scale, tie_count [3, B] int32: counts | first | last near-tie frame)")
         check(lib().sat_vq_argmin_gather_tie_f32(ptr(z), ptr(codebook), ptr(q), ptr(idx), ptr(dist), ptr(pair), float(scale), ptr(count),
                                                  B, D, T, n_codes, stream()), "sat_vq_argmin_gather_tie_f32")
         return q, idx, dist

@@ -385,7 +385,7 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
     def _features_of(self, x):
         return self.features(x)
 
-    def _exact_rows(self, rows, feats, wav, want_aux=False):
+    def _exact_rows(self, rows, feats, wav, spans=None):
         """flagged utterances again on the exact-f32 kernels: the encoder is recomputed for those rows; their frames and their own
         replicated frames (left pad, the 250th frame) replace the split-f16 ones in a copy of the batch's padded features, the
         right-hand pad frames — `pad_input` tiles the last frames of ALL utterances of the batch there (tdnnf_vq.py:228-234) — stay the
@@ -397,7 +397,9 @@ class TdnnfWav2vec2VqNet(_TdnnfBase):
             sub[:, :, p:p + T] = f
             sub[:, :, p + T] = f[:, :, -1]
             sub[:, :, :p] = f[:, :, :1]
-            return self._run_stack(sub, want_aux=want_aux)
+            # (the whole utterance: attention and the positional conv look at every frame — `spans` is not used on this tag)
+            zq, (_, idx_x, _) = self._run_stack(sub, want_aux=True)
+            return zq, idx_x, [0] * len(rows)
 
     def extract_bn(self, x: torch.Tensor, want_aux=False) -> torch.Tensor:
         """inputs [N, n] in [-1, 1] (no 32768 scaling on this tag) -> [N, T, 256]

@@ -264,6 +264,37 @@ def test_convert_patches_near_tie_utterances(tag):
     assert e_all < 3e-6, e_all
 
 
+def test_windowed_exact_decision_gives_the_frames_of_the_full_run():
+    """fbank tag: the second decision of a near-tie utterance computes only the window of frames around its near-ties (TDNNF layers are
+    'valid' windows over frames, and the exact-f32 kernels give a frame the same bits whatever tile it falls in): the window's
+    quantised frames and indices ARE those of the whole utterance on the exact kernels — windows at the start, in the middle, at the
+    very end (moved left) and a span too wide to window"""
+    import satools_amd
+    from satools_amd import synthetic
+    model = satools_amd.load_model("synthetic:" + FBANK_TAG)
+    model.to(DEV)
+    model.eval()
+    ext = model.bn_extractor
+    wav = synthetic.harm_batch([41, 42, 43, 44], 80000).to(DEV)
+    with torch.no_grad():
+        feats = ext._features_of(wav)
+        rows = [0, 1, 2, 3]
+        zq_f, idx_f, t0_f = ext._exact_rows(rows, feats, wav)
+        Tq = idx_f.shape[1]
+        assert t0_f == [0, 0, 0, 0] and zq_f.shape[2] == Tq
+        S, W = ext._stack_receptive_field()
+        assert (feats.shape[2] - W) // S + 1 == Tq
+        for spans in ([(0, 0), (5, 9), (Tq - 1, Tq - 1), (Tq - 40, Tq - 3)], [(120, 121), (7, 7), (200, 230), (Tq - 2, Tq - 1)]):
+            zq_w, idx_w, t0 = ext._exact_rows(rows, feats, wav, spans=spans)
+            Lq = idx_w.shape[1]
+            assert Lq < Tq // 2
+            for i, (lo, hi) in enumerate(spans):
+                assert t0[i] <= lo and hi < t0[i] + Lq <= Tq, (spans[i], t0[i], Lq)
+                assert torch.equal(idx_w[i], idx_f[i, t0[i]:t0[i] + Lq]) and torch.equal(zq_w[i], zq_f[i, :, t0[i]:t0[i] + Lq]), (spans[i], t0[i])
+        zq_a, idx_a, t0_a = ext._exact_rows(rows, feats, wav, spans=[(3, Tq - 5)] * 4)       # too wide: the full run
+        assert t0_a == [0, 0, 0, 0] and torch.equal(idx_a, idx_f) and torch.equal(zq_a, zq_f)
+
+
 def test_f8r_entry_refuses_foreign_packings_and_short_sidecars():
     """ops.conv1d(mode=CONV_F16F8R) moves its operands by LDS-DMA at offsets derived from the shapes: an f16x3 packing (half the bytes)
     or a short / stale sidecar must be refused, not read past its end (round-5 advisor item; sat_conv1d_desc.x_split8 / y_split8)"""
