@@ -842,12 +842,15 @@ def main():
             spec["repeats"] = min(a.repeats, 3)
             cmd = [sys.executable, os.path.abspath(__file__), "--child-config", json.dumps(spec), "--jobs", str(a.jobs), "--f0-status", a.f0_status,
                    "--gather", a.gather] + (["--no-cpu-baseline"] if a.no_cpu_baseline else []) + (["--gen-precision", a.gen_precision] if a.gen_precision else [])
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=1500)
-            got = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode != 0 or not got:
-                print(f"bench.py: the child process measuring {spec['name']} failed (exit code {r.returncode})", file=sys.stderr)
-                sys.exit(3)
-            child_lines.append(json.loads(got[-1]))
+            # (a side config that fails or hangs must not take the headline with it: it is reported on stderr and left out of `configs`)
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=900)
+                got = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not got:
+                    raise RuntimeError(f"exit code {r.returncode}")
+                child_lines.append(json.loads(got[-1]))
+            except Exception as e:      # noqa: BLE001
+                print(f"bench.py: the child process measuring {spec['name']} failed ({e!r}): that config is missing from this line", file=sys.stderr, flush=True)
 
     import torch
     import torch.distributed as dist
