@@ -76,6 +76,20 @@ def vq_flip_stats(z, idx, z_exact, idx_exact, dist_exact):
     return out
 
 
+def tie_windows(Tf, S, W, spans):
+    """Input windows for the second decision of near-tie utterances: output frame t of a stack of 'valid' windows reads the input frames
+    S t .. S t + W - 1, so the output frames lo .. hi of an utterance need the inputs S lo .. S hi + W - 1.  -> (L, starts): ONE window
+    length for all rows (the longest need, rounded so that Tf - L is a multiple of S) and per row the first input frame, a multiple of
+    S, moved left where the window would pass the end of the Tf input frames; the run on inputs starts[i] .. starts[i] + L - 1 yields
+    the output frames starts[i] / S .. (starts[i] + L - W) / S, which contain lo .. hi.  A need of three quarters of the utterance or more
+    returns the whole utterance (L = Tf, starts 0)."""
+    need = max(S * (hi - lo) + W for lo, hi in spans)
+    need += (Tf - need) % S
+    if need * 4 >= Tf * 3:
+        return Tf, [0] * len(spans)
+    return need, [min(S * lo, Tf - need) for lo, _ in spans]
+
+
 class TieStatus:
     """Deferred near-tie report of one VQ launch (`sat_vq_argmin_gather_tie_f32`): the per-utterance counts travel to a page-locked
     row behind the launch, `rows()` waits for them (the VQ runs before the generator: by the time a caller has enqueued the rest of
@@ -505,14 +519,7 @@ class _TdnnfBase(nn.Module):
         three quarters of the utterance or more is the full run.  A flagged utterance then costs launches of 2 - 4 blocks instead of 16."""
         n, Tf = len(rows), feats.shape[2]
         S, W = self._stack_receptive_field()
-        starts = [0] * n
-        L = Tf
-        if spans is not None:
-            need = max(S * (hi - lo) + W for lo, hi in spans)
-            need += (Tf - need) % S                              # (Tf - L) a multiple of S: a window moved to the end stays aligned
-            if need * 4 < Tf * 3:
-                L = need
-                starts = [min(S * lo, Tf - L) for lo, _ in spans]
+        L, starts = tie_windows(Tf, S, W, spans) if spans is not None else (Tf, [0] * n)
         with self._exact(self):
             if L == Tf:
                 sub = feats[rows].contiguous()

@@ -435,6 +435,35 @@ def test_gpu_count_only_counts_render_nodes_this_process_can_open(tmp_path):
     assert anonymize._count_kfd_gpus([], str(dri), []) == 0
 
 
+def test_near_tie_windows_cover_their_frames():
+    """asrbn.tie_windows (the input windows of the VQ guard's second decision, round 6): for random spans of near-tie frames the
+    common window length and the per-row starts are aligned to the stack's stride, stay inside the utterance, and the output
+    frames a window yields contain the span — checked against the receptive field of the fbank-tag stack built on the CPU"""
+    import random
+    from satools_amd import asrbn
+    net = asrbn.TdnnfVqNet(output_dim=8)
+    S, W = net._stack_receptive_field()
+    assert (S, W) == (2, 39)
+    layers = net._stack_layers()
+    rng = random.Random(3)
+    for _ in range(2000):
+        Tf = rng.randint(W, 1900)
+        Tq = (Tf - W) // S + 1
+        assert net._layers_out_len(layers, Tf) == Tq
+        spans = []
+        for _ in range(rng.randint(1, 4)):
+            lo = rng.randint(0, Tq - 1)
+            spans.append((lo, rng.randint(lo, min(Tq - 1, lo + rng.choice([0, 0, 1, 5, 40, 400])))))
+        L, starts = asrbn.tie_windows(Tf, S, W, spans)
+        assert W <= L <= Tf and (Tf - L) % S == 0
+        Lq = net._layers_out_len(layers, L)
+        assert Lq == (L - W) // S + 1
+        for (lo, hi), a in zip(spans, starts):
+            assert a % S == 0 and 0 <= a and a + L <= Tf
+            t0 = a // S
+            assert t0 <= lo and hi <= t0 + Lq - 1 and t0 + Lq <= Tq, (Tf, spans, L, starts)
+
+
 def test_ragged_yaapt_length_dims_are_the_plans():
     """f0.length_dims(P, n) — what a ragged batch sends per utterance — equals the length-dependent fields of a full make_plan(n)"""
     from satools_amd import f0
