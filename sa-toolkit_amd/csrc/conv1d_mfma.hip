@@ -26,6 +26,7 @@ static int g_k1_gemm = 3;
 // the three-blocks-per-CU form of the tile (1, conv_lean.hip) or the two-block form (0)
 static int g_lean3 = 1, g_lean7 = 1, g_lean11 = 1;
 static int g_trim_halo = 1; // the fused pair kernels load only the columns of their staged window that conv1 reads (window + halo of the dilation)
+static int g_half_tile7 = 1;   // conv_pre on 64 x 128 tiles when the 64 x 256 ones are at most one per CU
 static int g_pair32s = 1;   // the 3-tap fused step at C = 32 on the streaming kernel (pair32s.hip)
 
 template <int MT, int NT, int WM, int WN, int KS, bool STRIDE1, int XWI>
@@ -1843,6 +1844,10 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
     if (a.x16 && a.ksize == 3 && !a.f8 && !a.poly_planes && a.rows_g > 32 && a.T_q > 128 &&
         (long long)ceil_div(a.rows_g, 64) * ceil_div(a.T_q, 256) * d->B * d->groups < 256)
       return launch_f16x3<2, 1, 3>(a, d->B, d->groups, s);
+    // the same for the generator's conv_pre (f32 input, 7 taps, 512 rows x 250 frames x 32 utterances = 256 tiles of 64 x 256)
+    if (g_half_tile7 && !a.x16 && a.ksize == 7 && a.rows_g > 32 && a.T_q > 128 &&
+        (long long)ceil_div(a.rows_g, 64) * ceil_div(a.T_q, 256) * d->B * d->groups <= 256)
+      return launch_f16x3<2, 1, 7>(a, d->B, d->groups, s);
     // the generator's resblock convs: the three-blocks-per-CU form of the tile (conv_lean.hip)
     if (d->groups == 1 && (a.ksize == 3 ? g_lean3 : a.ksize == 7 ? g_lean7 : g_lean11) && lean_supports(a))
       return launch_f16x3_lean(a, d->B, s);
@@ -2071,6 +2076,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "lean3")) { g_lean3 = value != 0; return SAT_OK; }
   if (!strcmp(name, "lean7")) { g_lean7 = value != 0; return SAT_OK; }
   if (!strcmp(name, "lean11")) { g_lean11 = value != 0; return SAT_OK; }
+  if (!strcmp(name, "half_tile7")) { g_half_tile7 = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32s")) { g_pair32s = value != 0; return SAT_OK; }
   if (!strcmp(name, "trim_halo")) { g_trim_halo = value != 0; return SAT_OK; }
   if (!strcmp(name, "pair32w")) { pair32w_set(value); return SAT_OK; }
