@@ -8,7 +8,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsatools_hip.so")
+# (SATOOLS_AMD_LIB: another build of the same ABI, for A/B measurements of two builds on one box — tools/ab_builds.sh)
+LIB_PATH = os.environ.get("SATOOLS_AMD_LIB") or os.path.join(_HERE, "libsatools_hip.so")
 
 c_float_p = C.c_void_p  # raw device pointers travel as integers
 

@@ -163,6 +163,20 @@ __device__ __forceinline__ float lrelu_undo_min(float r, float inv) {
   return o;
 }
 
+// max(v, v * slope) == (v > 0 ? v : v * slope) for 0 <= slope <= 1, bit for bit (signed zeros included: -0 * slope = -0 = max(-0, -0);
+// NaN stays NaN) — two instructions instead of multiply, compare, select with the wait of the select on the compare's mask; the hosts
+// of every kernel that uses it refuse slopes outside [0, 1].  Through the asm like lrelu_undo_min: no canonicalising copy.
+__device__ __forceinline__ float lrelu_max(float v, float slope) {
+  const float m = v * slope;
+  float o;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(v), "v"(m));
+#else
+  o = v > m ? v : m;
+#endif
+  return o;
+}
+
 // lo halves of a split: f16(a - hi0) | f16(b - hi1) for the packed pair `h` = (hi0, hi1) (what v_cvt_pkrtz returned)
 template <class H2>
 __device__ __forceinline__ auto split_lo2(const H2 h, float a, float b) {

@@ -366,8 +366,8 @@ __global__ void __launch_bounds__(256, 2) conv1d_f16x3_kernel(const ConvArgs p) 
             for (int j = 0; j < 4; ++j) {
               float x0 = stg[ii][2 * j], x1 = stg[ii][2 * j + 1];
               if (p.in_lrelu) {
-                x0 = x0 > 0.f ? x0 : x0 * p.in_slope;
-                x1 = x1 > 0.f ? x1 : x1 * p.in_slope;
+                x0 = lrelu_max(x0, p.in_slope);
+                x1 = lrelu_max(x1, p.in_slope);
               }
               const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
               const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
@@ -461,8 +461,8 @@ __device__ __forceinline__ void polyphase_planes_epilogue(const ConvArgs& p, f32
     for (int j = 0; j < 4; ++j) {
       float x0 = tile[((cg * 8 + 2 * j) * up + ph) * PITCH + ql];
       float x1 = tile[((cg * 8 + 2 * j + 1) * up + ph) * PITCH + ql];
-      x0 = x0 > 0.f ? x0 : x0 * p.y16_slope;
-      x1 = x1 > 0.f ? x1 : x1 * p.y16_slope;
+      x0 = lrelu_max(x0, p.y16_slope);
+      x1 = lrelu_max(x1, p.y16_slope);
       const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
       const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
       hi[j] = __builtin_bit_cast(unsigned, h);
@@ -1006,8 +1006,8 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_f16x3_kernel(const ConvA
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float x0 = stg[ii][2 * j], x1 = stg[ii][2 * j + 1];
-            x0 = x0 > 0.f ? x0 : x0 * p.in_slope;
-            x1 = x1 > 0.f ? x1 : x1 * p.in_slope;
+            x0 = lrelu_max(x0, p.in_slope);
+            x1 = lrelu_max(x1, p.in_slope);
             const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
             const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
             hi[j] = __builtin_bit_cast(unsigned, h);
@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_f16x3_kernel(const ConvA
       for (int k = 0; k < 4; ++k) {
         const int row = 8 * rg + 4 * lh + k;
         float t = __builtin_fmaf(acc[n][4 * rg + k], p.w_descale1, row < p.rows_g ? p.bias1[row] : 0.f);
-        t = t > 0.f ? t : t * p.in_slope;
+        t = lrelu_max(t, p.in_slope);
         v[k] = inside ? t : 0.f;
       }
       const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
@@ -1235,7 +1235,7 @@ __global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float t = __builtin_fmaf(acc[s][k], p.w_descale1, bias1[k]);
-      t = t > 0.f ? t : t * p.in_slope;
+      t = lrelu_max(t, p.in_slope);
       v[k] = inside ? t : 0.f;      // t1 outside the utterance is conv2's zero padding
     }
     const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
@@ -1310,7 +1310,7 @@ __global__ void __launch_bounds__(256, KS == 11 ? 2 : 3) resblock_pair16_kernel(
     if (p.y16) {
       float u[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) u[k] = v[k] > 0.f ? v[k] : v[k] * p.y16_slope;
+      for (int k = 0; k < 4; ++k) u[k] = lrelu_max(v[k], p.y16_slope);
       const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
       const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
       const auto l01 = split_lo2(h01, u[0], u[1]);
@@ -1481,7 +1481,7 @@ __global__ void __launch_bounds__(256, 3) resblock_pair32_kernel(const ConvArgs 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float t = __builtin_fmaf(acc[0][n][4 * rg + k], p.w_descale1, p.bias1[8 * rg + 4 * lh + k]);
-        t = t > 0.f ? t : t * p.in_slope;
+        t = lrelu_max(t, p.in_slope);
         v[k] = inside ? t : 0.f;
       }
       const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
@@ -1549,8 +1549,8 @@ __global__ void __launch_bounds__(256) act_split_kernel(const float* __restrict_
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float x0 = v[2 * j], x1 = v[2 * j + 1];
-    x0 = x0 > 0.f ? x0 : x0 * slope;
-    x1 = x1 > 0.f ? x1 : x1 * slope;
+    x0 = lrelu_max(x0, slope);
+    x1 = lrelu_max(x1, slope);
     const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
     const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
     hi[j] = __builtin_bit_cast(unsigned, h);
@@ -1568,7 +1568,7 @@ __global__ void __launch_bounds__(256) act_split_kernel(const float* __restrict_
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float xv = v[j];
-    xv = xv > 0.f ? xv : xv * slope;
+    xv = lrelu_max(xv, slope);
     const auto hh = __builtin_bit_cast(decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)), hi[j >> 1]);
     hf[j] = (float)hh[j & 1];
     lf[j] = (xv - hf[j]) * F8_XLO_SCALE;
@@ -1751,6 +1751,10 @@ static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* 
     a.y16 = d->y_split;
     a.y16_slope = d->y_split_slope;
     a.no_y = d->no_y;
+    // the split-f16 kernels apply a leaky-relu as max(v, slope v) and undo one as min(r, r / slope) (common.h lrelu_max)
+    SAT_REQUIRE((!d->in_lrelu || (d->in_slope >= 0.f && d->in_slope <= 1.f)) && (!d->y_split || (d->y_split_slope >= 0.f && d->y_split_slope <= 1.f)) &&
+                    (!d->res_split || d->res_split_slope <= 1.f),
+                "conv1d(f16x3): leaky-relu slopes must lie in [0, 1]");
     if (a.x16)
       SAT_REQUIRE(d->groups == 1 && a.cin_g % 16 == 0 && (long long)a.cin_g * a.T_in * 4 < (1LL << 31),
                   "conv1d(f16x3): x_split needs groups 1, C_in %% 16 == 0 and a slab below 2 GiB");
@@ -1965,6 +1969,9 @@ extern "C" int sat_resblock_pair_scaled_f16x3(const sat_conv1d_desc* d, const fl
   a.co_pad = 64;
   a.w_gs = (long long)(a.cin_pad / CI_CHUNK) * a.ksize * a.co_pad * 64;
   a.in_lrelu = 1; a.in_slope = d->in_slope;
+  SAT_REQUIRE(d->in_slope >= 0.f && d->in_slope <= 1.f && (!d->y_split || (d->y_split_slope >= 0.f && d->y_split_slope <= 1.f)) &&
+                  (!d->res_split || d->res_split_slope <= 1.f),
+              "resblock_pair: leaky-relu slopes must lie in [0, 1] (common.h lrelu_max)");
   a.accum = d->accum; a.accum_div = d->accum_div;
   a.no_store = d->accum_no_store;
   SAT_REQUIRE(!d->accum_no_store || (d->accum && y && d->y_split && !d->no_y), "resblock_pair: accum_no_store goes with accum and y_split");
@@ -2062,6 +2069,7 @@ extern "C" int sat_act_split_f32(const float* x, void* x_split, int B, int C, in
   SAT_REQUIRE(x && x_split, "act_split: null pointer");
   SAT_REQUIRE(format == SAT_SPLIT_F16 || format == SAT_SPLIT_F8, "act_split: unknown format");
   SAT_REQUIRE(B > 0 && C > 0 && T > 0 && C % 16 == 0 && B < 65536, "act_split: unsupported shape B=%d C=%d T=%d", B, C, T);
+  SAT_REQUIRE(slope >= 0.f && slope <= 1.f, "act_split: slope must lie in [0, 1]");
   dim3 grid(ceil_div(T, 256), C / 8, B);
   hipLaunchKernelGGL(act_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (uint4*)x_split, C, T, slope, format == SAT_SPLIT_F8);
   SAT_LAUNCH_CHECK("act_split_kernel");
@@ -2082,6 +2090,7 @@ extern "C" int sat_conv_set_option(const char* name, int value) {
   if (!strcmp(name, "pair32w")) { pair32w_set(value); return SAT_OK; }
   if (!strcmp(name, "pair64w")) { pair64w_set(value); return SAT_OK; }
   if (!strcmp(name, "pair64_rpre")) { pair64_rpre_set(value); return SAT_OK; }
+  if (!strcmp(name, "convpost_quad")) { convpost_set_quad(value); return SAT_OK; }
   if (!strcmp(name, "convring")) { convring_set(value); return SAT_OK; }
   if (!strcmp(name, "convring_blocks")) { convring_set_blocks(value); return SAT_OK; }
   if (!strcmp(name, "convring_wr")) { convring_set_wr(value); return SAT_OK; }

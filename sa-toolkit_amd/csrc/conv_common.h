@@ -187,7 +187,7 @@ __device__ __forceinline__ void decode_res16(float w0, float w1, float w2, float
   out[2] = mix_add_halves<false>(h23, l23);
   out[3] = mix_add_halves<true>(h23, l23);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) out[k] = out[k] > 0.f ? out[k] : out[k] * inv_slope;
+  for (int k = 0; k < 4; ++k) out[k] = lrelu_undo_min(out[k], inv_slope);
 }
 
 // HAS_BN = false compiles the folded-BatchNorm step out of the fast path (32 registers of scale / shift per row tile):
@@ -346,7 +346,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const float t = v[4 * rg + k];
-              u[k] = t > 0.f ? t : t * p.y16_slope;
+              u[k] = lrelu_max(t, p.y16_slope);
             }
             const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
             const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
@@ -630,7 +630,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[
         const int chunk = (co_w >> 4) + m;
         float u[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = v[r] > 0.f ? v[r] : v[r] * p.y16_slope;
+        for (int r = 0; r < 4; ++r) u[r] = lrelu_max(v[r], p.y16_slope);
         const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
         const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
         const auto l01 = split_lo2(h01, u[0], u[1]);
@@ -678,6 +678,7 @@ bool convring_same_shape(const ConvArgs& a, const ConvArgs& b);
 bool convring_supports(const ConvArgs& a, int B);
 bool convring_wanted(int rows_g, int T_q, int B);
 void convring_set(int v);
+void convpost_set_quad(int v);  // hifigan.hip: four consecutive outputs per lane in the output stage
 void convring_set_blocks(int v);
 void convring_set_wr(int v);
 int convring_debug_stamps(long long* buf);

@@ -272,7 +272,7 @@ __device__ __forceinline__ void ring_epilogue_ups(const RingJob& e, const RingAr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = __builtin_fmaf(acc[m][n][r], descale, bi[r]);
-        u[r] = v > 0.f ? v : v * slope;
+        u[r] = lrelu_max(v, slope);
       }
       const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
       const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);

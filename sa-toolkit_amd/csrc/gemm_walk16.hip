@@ -79,7 +79,7 @@ __device__ __forceinline__ void walk_epilogue_piece(const WalkJob& e, const Walk
     const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)e.y16 + (long long)b * rows_g * T * 4), 0, (unsigned)(rows_g * T * 4), 0x00020000);
     float u[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) u[r] = v[r] > 0.f ? v[r] : v[r] * e.y16_slope;
+    for (int r = 0; r < 4; ++r) u[r] = lrelu_max(v[r], e.y16_slope);
     const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
     const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
     const auto l01 = split_lo2(h01, u[0], u[1]);

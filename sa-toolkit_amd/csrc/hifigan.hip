@@ -34,10 +34,12 @@ static void phase_window(int k, int u, int pad, int* dmin, int* dmax) {
 // ---- output stage: leaky_relu(0.01) -> ReflectionPad1d((1,0)) -> Conv1d(C,1,7,pad=3) -> tanh ----
 // HBM-streaming kernel: each block produces 1024 output samples of one utterance from a
 // [C][1024+6] LDS tile.  Padded signal p[i] (i in [0,T]) = lrelu(x[i-1]) for i>=1, p[0] = lrelu(x[1]).
+static int g_convpost_quad = 1;
+void convpost_set_quad(int v) { g_convpost_quad = v != 0; }
 constexpr int POST_TILE = 1024;
 constexpr int POST_MAXC = 64;
 
-template <int C>
+template <int C, bool QUAD = false>
 __global__ void __launch_bounds__(256) convpost_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias,
@@ -93,6 +95,34 @@ __global__ void __launch_bounds__(256) convpost_kernel(const float* __restrict__
   }
   __syncthreads();
   const float bv = bias[0];
+  if constexpr (QUAD && C > 0 && W % 4 == 2) {
+    // four CONSECUTIVE outputs per lane: their ten columns of a channel lie inside three aligned 16-byte LDS reads (rows are W = 1030
+    // floats apart: even rows are aligned at column lt, odd rows two columns earlier), the weights come through the scalar unit; per
+    // output the products in the order (channel, tap) of the loop below — the same bits
+    const int lt = 4 * threadIdx.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int sh = (c & 1) * 2;                  // floats between the aligned window and column lt
+      const float4* rp = reinterpret_cast<const float4*>(lds + c * W + lt - sh);
+      float pv[12];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float4 f = rp[q];
+        pv[4 * q] = f.x; pv[4 * q + 1] = f.y; pv[4 * q + 2] = f.z; pv[4 * q + 3] = f.w;
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[o] = fmaf(w[c * 7 + j], pv[sh + o + j], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int t = t0 + lt + o;
+      if (t < To) y[(size_t)b * To + t] = tanhf(acc[o] + bv);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < POST_TILE / 256; ++k) {
     const int lt = threadIdx.x + k * 256;
@@ -389,7 +419,7 @@ extern "C" int sat_hifigan_convpost_f32(const float* x, const float* w, const fl
   const size_t lds = ((size_t)C * (POST_TILE + 6) + (size_t)C * 7) * sizeof(float);
   // C = 16 (the reference generator's last stage): batched tile loads; the accumulation order over (c, j) is
   // the same in both instantiations
-  auto kern = (C == 16 && (size_t)C * T * 4 < (1ull << 31)) ? convpost_kernel<16> : convpost_kernel<0>;
+  auto kern = (C == 16 && (size_t)C * T * 4 < (1ull << 31)) ? (g_convpost_quad ? convpost_kernel<16, true> : convpost_kernel<16>) : convpost_kernel<0>;
   if (lds > 64 * 1024) {
     SAT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }

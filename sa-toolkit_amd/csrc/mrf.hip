@@ -567,7 +567,7 @@ extern "C" int sat_resblock_mrf_f16x3(const sat_mrf_desc* d, void* stream) {
   SAT_REQUIRE(d->B > 0 && d->T > 0, "resblock_mrf: empty shape");
   SAT_REQUIRE(sat_resblock_mrf_supported(d->C, d->n_branches, d->ksize, &d->dilation[0][0]),
               "resblock_mrf: C = 16 with kernel sizes (3, 7, 11) or one of them, dilations (1, 3, 5) only");
-  SAT_REQUIRE(d->slope > 0.f && (!d->y_split || d->y_split_slope > 0.f), "resblock_mrf: slopes must be positive");
+  SAT_REQUIRE(d->slope > 0.f && d->slope <= 1.f && (!d->y_split || (d->y_split_slope > 0.f && d->y_split_slope <= 1.f)), "resblock_mrf: slopes must lie in (0, 1]");
   SAT_REQUIRE((long long)d->C * d->T * 4 < (1LL << 31), "resblock_mrf: slab too large for 31-bit offsets");
   SAT_REQUIRE_WORKSPACE(d->scratch_bytes >= sat_resblock_mrf_scratch_bytes(d->n_branches, d->ksize), "resblock_mrf: scratch too small");
   hipStream_t s = (hipStream_t)stream;

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) pair32s_kernel(const
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float v = __builtin_fmaf(acc[k], p.d1, b1[m][k]);
-          const float a = v > 0.f ? v : v * p.slope;
+          const float a = lrelu_max(v, p.slope);
           u[k] = inside ? a : 0.f;
         }
         const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) pair32s_kernel(const
           rv[3] = mix_add_halves<true>(hw[1], lw[1]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rv[k] = rv[k] > 0.f ? rv[k] : rv[k] * p.inv_slope;
+        for (int k = 0; k < 4; ++k) rv[k] = lrelu_undo_min(rv[k], p.inv_slope);
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) pair32s_kernel(const
         if (Y16) {
           float u[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) u[k] = v[k] > 0.f ? v[k] : v[k] * p.y_slope;
+          for (int k = 0; k < 4; ++k) u[k] = lrelu_max(v[k], p.y_slope);
           const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
           const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
           const auto l01 = split_lo2(h01, u[0], u[1]);
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(512, 1) pairw_kernel(const P32Args p) {
 #pragma unroll
                    for (int k = 0; k < 4; ++k) {
                      const float v = __builtin_fmaf(acc[m][k], descale, bias_m[k]);
-                     const float a = v > 0.f ? v : v * p.slope;
+                     const float a = lrelu_max(v, p.slope);
                      u[k] = inside ? a : 0.f;
                    }
                    const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(512, 1) pairw_kernel(const P32Args p) {
 #pragma unroll
                    for (int k = 0; k < 4; ++k) {
                      float r = rsum[k];
-                     r = r > 0.f ? r : r * p.inv_slope;
+                     r = lrelu_undo_min(r, p.inv_slope);
                      v[k] = __builtin_fmaf(acc[m][k], descale, bias_m[k]) + r;
                      if (YF && p.accum) v[k] = yv[m][k] + v[k];
                    }
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(512, 1) pairw_kernel(const P32Args p) {
                    if (Y16) {
                      float u[4];
 #pragma unroll
-                     for (int k = 0; k < 4; ++k) u[k] = v[k] > 0.f ? v[k] : v[k] * p.y_slope;
+                     for (int k = 0; k < 4; ++k) u[k] = lrelu_max(v[k], p.y_slope);
                      const auto h01 = __builtin_amdgcn_cvt_pkrtz(u[0], u[1]);
                      const auto h23 = __builtin_amdgcn_cvt_pkrtz(u[2], u[3]);
                      const auto l01 = split_lo2(h01, u[0], u[1]);

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256, 3) resblock_pair64_kernel(const ConvArgs 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float t = __builtin_fmaf(acc[m][0][4 * rg + k], p.w_descale1, p.bias1[32 * m + 8 * rg + 4 * lh + k]);
-          t = t > 0.f ? t : t * p.in_slope;
+          t = lrelu_max(t, p.in_slope);
           v[k] = inside ? t : 0.f;
         }
         const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);

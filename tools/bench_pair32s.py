@@ -9,7 +9,7 @@ from satools_amd import ops, packing, _lib
 B, dev = 32, "cuda"
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-T = 40000 * 32 // C
+T = 32000 * 32 // C      # the stage's length at batch 32 x 250 frames
 
 
 def timed(f, n=20):
@@ -32,16 +32,29 @@ b1, b2 = torch.randn(C, device=dev) * 0.1, torch.randn(C, device=dev) * 0.1
 xs = ops.act_split(x, 0.1)
 ys = ops.split_like(B, C, T, dev)
 acc = torch.randn(B, C, T, device=dev)
+def setopt(name, v):
+    _lib.check(_lib.lib().sat_conv_set_option(name, v), "set_option")
+
+
 for d in (1, 3, 5):
-    row = []
+    row, outs = [], []
     for opt in (0, 8, 4):
-        _lib.check(_lib.lib().sat_conv_set_option(b"pair32s", int(opt > 0)), "set_option")
-        _lib.check(_lib.lib().sat_conv_set_option(b"pair32w", int(opt > 0)), "set_option")
-        _lib.check(_lib.lib().sat_conv_set_option(b"pair64w", int(opt > 0)), "set_option")
-        _lib.check(_lib.lib().sat_conv_set_option(b"pair32s_waves", opt), "set_option")
+        setopt(b"pair32s", int(opt > 0))
+        setopt(b"pair32w", int(opt > 0))
+        setopt(b"pair64w", int(opt > 0))
+        setopt(b"pair32s_waves", opt)
         t_planes = timed(lambda: ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, y_split=ys, y_split_slope=0.1, planes_residual=True, no_y=True))
-        t_f32 = timed(lambda: ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, planes_residual=True, out=acc))
-        row.append((t_planes, t_f32))
+        y1 = ys.clone()
+        acc2 = acc.clone()
+        t_f32 = timed(lambda: ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, planes_residual=True, out=acc2))
+        acc3 = acc.clone()
+        ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, planes_residual=True, out=acc3, accum=True)
+        t_acc = timed(lambda: ops.resblock_pair(x, w1, b1, w2, b2, k, d, x_split=xs, planes_residual=True, out=acc2, accum=True))
+        row.append((t_planes, t_f32, t_acc))
+        outs.append((y1, acc3))
+    same = all(torch.equal(outs[1][i], outs[2][i]) for i in (0, 1))
     mb = 2 * B * C * T * 4 / 1e6
-    print(f"C {C} k {k} dilation {d}: planes -> planes: general {row[0][0]:6.1f}, 8 waves {row[1][0]:6.1f}, 2 x 4 waves {row[2][0]:6.1f} us ({mb / row[2][0]:.2f} TB/s)   "
-          f"planes -> f32: {row[0][1]:6.1f}, {row[1][1]:6.1f}, {row[2][1]:6.1f} us")
+    names = ("general", "8 waves", "2 x 4 waves")
+    print(f"C {C} k {k} dilation {d} ({mb:.0f} MB in + out); streaming forms bit-identical: {same}")
+    for nm, (a, b_, c) in zip(names, row):
+        print(f"    {nm:24s} planes -> planes {a:6.1f} us ({mb / a:.2f} TB/s)   planes -> f32 {b_:6.1f}   planes -> f32 accumulated {c:6.1f}")
