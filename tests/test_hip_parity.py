@@ -259,6 +259,39 @@ def test_convpost_matches_oracle():
     assert (y.cpu() - ref).abs().max() < 2e-6
 
 
+@pytest.mark.parametrize("T", [2, 5, 1021, 1024, 1027, 4099])
+def test_convpost_four_samples_per_lane_gives_the_bits_of_the_one_sample_form(T):
+    """the output stage's two forms (sat_conv_set_option("convpost_quad")): T + 1 outputs around the 1024-sample tile edges, a tile with
+    fewer than four outputs, the reflected first sample — bit for bit, and against torch"""
+    ops, _ = _ops()
+    x, w, b = _rand(3, 16, T, seed=T), _rand(1, 16, 7, seed=2, scale=0.1), _rand(1, seed=3, scale=0.1)
+    ref = torch.tanh(F.conv1d(F.pad(F.leaky_relu(x), (1, 0), mode="reflect"), w, b, padding=3))
+    ys = []
+    for quad in (0, 1):
+        with conv_option("convpost_quad", quad, 1):
+            ys.append(ops.convpost(x.to(DEV), w.reshape(16, 7).contiguous().to(DEV), b.to(DEV)).cpu())
+    assert ys[0].shape == ref.shape == (3, 1, T + 1)
+    assert torch.equal(ys[0], ys[1])
+    assert (ys[1] - ref).abs().max() < 2e-6
+
+
+def test_conv_pre_on_half_width_tiles_gives_the_same_bits():
+    """the 7-tap f32-input conv of the generator (conv_pre) on 64 x 128 tiles (sat_conv_set_option("half_tile7"), taken when the 64 x 256
+    tiles are at most one per CU) against the 64 x 256 form: a ragged last tile, frames that end inside the first half tile"""
+    ops, packing = _ops()
+    for B, T in ((2, 250), (3, 129), (1, 300)):
+        x = _rand(B, 80, T, seed=T).to(DEV)
+        w = packing.pack_conv_weight_f16x3((_rand(512, 80, 7, seed=5, scale=0.05)).to(DEV))
+        b = _rand(512, seed=6, scale=0.1).to(DEV)
+        ys = []
+        for v in (0, 1):
+            with conv_option("half_tile7", v, 1):
+                ys.append(ops.conv1d(x, w, 512, 7, bias=b, pad_left=3, pad_right=3, mode=1).cpu())
+        assert torch.equal(ys[0], ys[1]), (B, T)
+        ref = F.conv1d(x.cpu().double(), _rand(512, 80, 7, seed=5, scale=0.05).double(), b.cpu().double(), padding=3)
+        assert rms(ys[1].double().numpy() - ref.numpy()) < 1e-5 * rms(ref.numpy())
+
+
 # ---------------------------------------------------------------------------------------------
 # front end and bottleneck
 # ---------------------------------------------------------------------------------------------
