@@ -320,3 +320,30 @@ def test_f8r_entry_refuses_foreign_packings_and_short_sidecars():
     other = ops.planes_f8_sidecar(ops.act_split(x * 2, 0.1))
     assert not torch.equal(other, xs8) and torch.equal(ops.planes_f8_sidecar(xs), xs8)
     torch.cuda.synchronize()
+
+
+def test_split_f16_kernels_refuse_leaky_relu_slopes_outside_0_1():
+    """the split-f16 epilogues apply a leaky-relu as max(v, slope v) and undo one as min(r, r / slope) (csrc/common.h lrelu_max,
+    lrelu_undo_min: the bits of the select for 0 <= slope <= 1 only): other slopes are refused where the reference's own activations
+    (0.1, 0.01, none) never go; the exact-f32 kernels keep the select and take any slope"""
+    import torch.nn.functional as F
+    from satools_amd import _lib, ops, packing
+    B, C, T, k = 2, 32, 300, 3
+    x = torch.randn(B, C, T, device=DEV)
+    w = torch.randn(C, C, k, device=DEV) * 0.1
+    b = torch.randn(C, device=DEV) * 0.1
+    w3, w0 = packing.pack_conv_weight_f16x3(w), packing.pack_conv_weight(w)
+    for slope in (0.0, 0.1, 1.0):
+        y = ops.conv1d(x, w3, C, k, bias=b, pad_left=1, pad_right=1, in_lrelu=slope, mode=1)
+        ref = F.conv1d(F.leaky_relu(x, slope), w, b, padding=1)
+        assert (y - ref).abs().max() < 1e-4
+    for slope in (1.5, -0.1):
+        with pytest.raises(_lib.SatError, match=r"\[0, 1\]"):
+            ops.conv1d(x, w3, C, k, bias=b, pad_left=1, pad_right=1, in_lrelu=slope, mode=1)
+        with pytest.raises(_lib.SatError, match=r"\[0, 1\]"):
+            ops.act_split(x, slope)
+        y = ops.conv1d(x, w0, C, k, bias=b, pad_left=1, pad_right=1, in_lrelu=slope, mode=0)      # exact f32: any slope
+        assert (y - F.conv1d(F.leaky_relu(x, slope), w, b, padding=1)).abs().max() < 1e-4
+    with pytest.raises(_lib.SatError, match=r"\[0, 1\]"):
+        ops.conv1d(x, w3, C, k, bias=b, pad_left=1, pad_right=1, mode=1, y_split=ops.split_like(B, C, T, DEV), y_split_slope=2.0)
+    torch.cuda.synchronize()
