@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 7
+#define SAT_ABI_VERSION 8
 
 typedef enum {
   SAT_OK = 0,
@@ -206,6 +206,31 @@ uint32_t sat_convtranspose_zero_taps(int ksize, int stride, int padding);
 
 int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed, float* y,
                    void* stream);
+
+/* One TDNNF layer (ABI 8): TDNNFBatchNorm.forward of the reference, satools/satools/chain/nn.py:306-347 — the factorised linear layer
+ * (linearB: context_len frames x feat_dim -> bottleneck_dim, chain/nn.py:267-278; linearA: bottleneck_dim -> out_dim),
+ * + bypass_scale * x[t + identity_lidx] (chain/nn.py:233-247, 279-292), BatchNorm1d in eval mode (folded: bn_scale, bn_shift), ReLU
+ * (chain/nn.py:336-347) — as the two launches sat_conv1d_f32 would make,
+ * behind one descriptor (subsampling factor 1; the strided and the 1.5-frame layers stay on sat_conv1d_f32 / sat_tdnnf_unfold15_f32).
+ * Weights: packing of the conv view of the two Linear layers ([bottleneck][feat][context_len], [out][bottleneck][1]) for `mode`.
+ * T_q = T_in - (context_len - 1).  On split planes (SAT_CONV_F16X3 with x_split / z_split / y_split, channel counts multiples of 16)
+ * the bottleneck only exists as planes (z may be NULL); y (f32) is always written: it is the next layer's bypass. */
+typedef struct {
+  int32_t B, feat_dim, bottleneck_dim, out_dim, T_in, context_len;
+  int32_t mode;                    /* SAT_CONV_F32 or SAT_CONV_F16X3 */
+  float bypass_scale;              /* 0 = no bypass (else out_dim == feat_dim and x is needed) */
+  float wB_descale, wA_descale;    /* sat_conv1d_desc.w_descale of the two packings (0 = 1) */
+  const float* x;                  /* [B][feat_dim][T_in] or NULL (then x_split, no bypass) */
+  const void* x_split;             /* SAT_SPLIT_F16 planes of x, or NULL */
+  const void *wB_packed, *wA_packed;
+  const float *bB, *bA;            /* biases or NULL */
+  const float *bn_scale, *bn_shift;/* [out_dim] or NULL */
+  float* y;                        /* [B][out_dim][T_q] */
+  void* y_split;                   /* also planes of y, or NULL */
+  float* z;                        /* [B][bottleneck_dim][T_q] scratch, or NULL when z_split serves */
+  void* z_split;                   /* planes scratch of the bottleneck, or NULL */
+} sat_tdnnf_layer_desc;
+int sat_tdnnf_layer_f32(const sat_tdnnf_layer_desc* d, void* stream);
 /* n = 1..3 convolutions d[0..n-1] (x[j], w_packed[j], y[j] as for sat_conv1d_f32) that do not depend on each other's
  * results within the call — the three branches of a multi-receptive-field block (reference hifigan/archi.py:82-86: kernel
  * sizes 3 / 7 / 11 on the same stage) — or that depend on them only through y[j] accumulated in index order (d[j].accum on the

@@ -48,6 +48,17 @@ class ConvDesc(C.Structure):
     ]
 
 
+class TdnnfLayerDesc(C.Structure):
+    """mirror of sat_tdnnf_layer_desc"""
+    _fields_ = [
+        ("B", C.c_int32), ("feat_dim", C.c_int32), ("bottleneck_dim", C.c_int32), ("out_dim", C.c_int32), ("T_in", C.c_int32), ("context_len", C.c_int32),
+        ("mode", C.c_int32), ("bypass_scale", C.c_float), ("wB_descale", C.c_float), ("wA_descale", C.c_float),
+        ("x", C.c_void_p), ("x_split", C.c_void_p), ("wB_packed", C.c_void_p), ("wA_packed", C.c_void_p),
+        ("bB", C.c_void_p), ("bA", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
+        ("y", C.c_void_p), ("y_split", C.c_void_p), ("z", C.c_void_p), ("z_split", C.c_void_p),
+    ]
+
+
 class MrfDesc(C.Structure):
     """mirror of sat_mrf_desc"""
     _fields_ = [
@@ -100,6 +111,7 @@ _PROTOS = {
     "sat_upsample2_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sat_upsample2_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p]),
+    "sat_tdnnf_layer_f32": (C.c_int, [C.POINTER(TdnnfLayerDesc), C.c_void_p]),
     "sat_act_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "sat_hifigan_convpost_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]),
@@ -182,7 +194,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.sat_abi_version() != 7:       # 5: SAT_CONV_F16F8R; sat_conv1d_desc grew x_split8 / y_split8 / y_split_hi_only.  6: sat_pcm16_*.  7: VQ near-tie count, hifigan get_option / range probe
+        if l.sat_abi_version() != 8:       # 5: SAT_CONV_F16F8R; sat_conv1d_desc grew x_split8 / y_split8 / y_split_hi_only.  6: sat_pcm16_*.  7: VQ near-tie count, hifigan get_option / range probe.  8: sat_tdnnf_layer_f32
             raise SatError("libsatools_hip.so ABI version mismatch")
         # A/B switches of the conv dispatch for whole-program measurements (bench.py under different kernels):
         # SATOOLS_AMD_CONV_OPTIONS="pair32w=0,lean_balance=2" -> sat_conv_set_option(name, value) at load time

@@ -347,6 +347,17 @@ class _TdnnfBase(nn.Module):
             return y, ys
         planes_in = c.modeB == 1 and sub == 1 and xs is not None and x.shape[1] % 16 == 0
         need_z = c.codebook is not None or return_bottleneck
+        if sub == 1 and not need_z and c.modeA == c.modeB and c.modeB in (0, 1):
+            # the plain layer (no subsampling, no quantiser inside): ONE call across the C-ABI (sat_tdnnf_layer_f32) — linearB, linearA with
+            # bypass + BatchNorm + ReLU; on split planes the bottleneck exists only as planes
+            t_q = x.shape[2] - (ctx - 1)
+            planes = c.modeB == 1 and lay.bottleneck_dim % 16 == 0
+            zs = ops.split_like(B, lay.bottleneck_dim, t_q, x.device) if planes else None
+            ys = ops.split_like(B, lay.out_dim, t_q, x.device) if (c.modeA == 1 and lay.out_dim % 16 == 0) else None
+            y = ops.tdnnf_layer(x, c.wB, c.bB, c.wA, c.bA, lay.bottleneck_dim, lay.out_dim, ctx, bn_scale=c.scale, bn_shift=c.shift,
+                                bypass_scale=float(lay.bypass_scale) if lay.use_bypass else 0.0, mode=c.modeB,
+                                x_split=xs if planes_in else None, y_split=ys, z_split=zs)
+            return y, ys
         zs = None
         if planes_in and not need_z and lay.bottleneck_dim % 16 == 0:
             t_q = x.shape[2] - (ctx - 1)

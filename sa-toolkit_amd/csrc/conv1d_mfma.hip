@@ -1870,6 +1870,50 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
   return launch_ks<1, 4, 1, 4>(a, d->B, d->groups, s);                       //  32 rows x 512 positions
 }
 
+// One TDNNF layer per call (chain/nn.py:336-347 TDNNFBatchNorm.forward = TDNNF.forward 267-292 with its bypass -> BatchNorm1d -> ReLU): the
+// two launches sat_conv1d_f32 makes for linearB (context_len taps over frames, feat -> bottleneck) and linearA (1x1, bottleneck -> out,
+// bias, bypass from the layer input identity_lidx frames in, folded BatchNorm, ReLU) behind ONE descriptor — the host composes nothing
+// between them, and the bottleneck never has to exist as f32 when the layer runs on split planes.
+extern "C" int sat_tdnnf_layer_f32(const sat_tdnnf_layer_desc* d, void* stream) {
+  SAT_REQUIRE(d && d->wB_packed && d->wA_packed && d->y, "tdnnf_layer: null pointer");
+  SAT_REQUIRE(d->B > 0 && d->feat_dim > 0 && d->bottleneck_dim > 0 && d->out_dim > 0 && d->context_len >= 1 && d->T_in >= d->context_len,
+              "tdnnf_layer: unsupported shape");
+  SAT_REQUIRE(d->mode == SAT_CONV_F32 || d->mode == SAT_CONV_F16X3, "tdnnf_layer: mode must be SAT_CONV_F32 or SAT_CONV_F16X3");
+  SAT_REQUIRE(d->x || d->x_split, "tdnnf_layer: x or x_split");
+  const int T_q = d->T_in - (d->context_len - 1);
+  const bool planes = d->mode == SAT_CONV_F16X3 && d->z_split && d->bottleneck_dim % 16 == 0;
+  SAT_REQUIRE(planes || d->z, "tdnnf_layer: the bottleneck needs z (f32) or, on split planes, z_split");
+  SAT_REQUIRE(d->bypass_scale == 0.f || (d->x && d->out_dim == d->feat_dim), "tdnnf_layer: the bypass adds the f32 layer input (out_dim == feat_dim)");
+  sat_conv1d_desc b{};
+  b.B = d->B, b.C_in = d->feat_dim, b.T_in = d->T_in, b.C_out = d->bottleneck_dim, b.T_q = T_q;
+  b.ksize = d->context_len, b.dilation = 1, b.stride = 1, b.pad_left = 0, b.mode = d->mode, b.groups = 1, b.up = 1;
+  b.x_cstride = d->T_in, b.x_bstride = (int64_t)d->feat_dim * d->T_in;
+  b.y_cstride = T_q, b.y_bstride = (int64_t)d->bottleneck_dim * T_q;
+  b.res_tstride = 1;
+  b.bias = d->bB;
+  b.w_descale = d->wB_descale;
+  b.x_split = d->mode == SAT_CONV_F16X3 ? d->x_split : nullptr;
+  if (planes) b.y_split = d->z_split, b.y_split_slope = 1.0f, b.no_y = 1;
+  int st = sat_conv1d_f32(&b, d->x, d->wB_packed, planes ? (float*)d->z_split : d->z, stream);
+  if (st != SAT_OK) return st;
+  sat_conv1d_desc a{};
+  a.B = d->B, a.C_in = d->bottleneck_dim, a.T_in = T_q, a.C_out = d->out_dim, a.T_q = T_q;
+  a.ksize = 1, a.dilation = 1, a.stride = 1, a.pad_left = 0, a.mode = d->mode, a.groups = 1, a.up = 1;
+  a.x_cstride = T_q, a.x_bstride = (int64_t)d->bottleneck_dim * T_q;
+  a.y_cstride = T_q, a.y_bstride = (int64_t)d->out_dim * T_q;
+  a.bias = d->bA, a.ch_scale = d->bn_scale, a.ch_shift = d->bn_shift, a.relu = 1;
+  a.w_descale = d->wA_descale;
+  a.res_tstride = 1;
+  if (d->bypass_scale != 0.f) {
+    a.res = d->x, a.res_scale = d->bypass_scale;
+    a.res_toff = d->context_len == 2 ? 1 : d->context_len / 2;      // identity_lidx, chain/nn.py:233-247
+    a.res_cstride = d->T_in, a.res_bstride = (int64_t)d->feat_dim * d->T_in;
+  }
+  if (planes) a.x_split = d->z_split;
+  if (d->y_split && d->mode == SAT_CONV_F16X3) a.y_split = d->y_split, a.y_split_slope = 1.0f;
+  return sat_conv1d_f32(&a, planes ? (const float*)d->z_split : d->z, d->wA_packed, d->y, stream);
+}
+
 extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const* x, const void* const* w_packed, float* const* y,
                                     int n, void* stream) {
   SAT_REQUIRE(d && x && w_packed && y && n >= 1 && n <= 3, "conv1d_multi: 1..3 convolutions");

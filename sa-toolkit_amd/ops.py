@@ -152,6 +152,31 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
     return d, x, out, res      # (res: the possibly re-laid-out residual must outlive the launch)
 
 
+def tdnnf_layer(x, wB, bB, wA, bA, bottleneck_dim, out_dim, context_len, *, bn_scale=None, bn_shift=None, bypass_scale=0.0, mode=0,
+                x_split=None, y_split=None, z_split=None):
+    """One TDNNF layer in ONE C-ABI call (sat_tdnnf_layer_f32; chain/nn.py:267-347): linearB over `context_len` frames, linearA, the bypass
+    `bypass_scale * x[t + identity_lidx]`, folded BatchNorm, ReLU.  x [B, feat, T_in] f32 -> y [B, out_dim, T_in - context_len + 1];
+    on split planes (mode=CONV_F16X3 with `x_split` and a `z_split` scratch) the bottleneck exists only as planes and `y_split`
+    also receives the planes of y.  The two launches (and the bits) of the two conv1d calls it replaces."""
+    x = _f32c(x)
+    B, feat, t_in = x.shape
+    t_q = t_in - (int(context_len) - 1)
+    if t_q <= 0:
+        raise _lib.SatError("tdnnf_layer: input too short for this context")
+    y = torch.empty(B, out_dim, t_q, dtype=torch.float32, device=x.device)
+    planes = int(mode) == _lib.CONV_F16X3 and z_split is not None
+    z = None if planes else torch.empty(B, bottleneck_dim, t_q, dtype=torch.float32, device=x.device)
+    d = _lib.TdnnfLayerDesc()
+    d.B, d.feat_dim, d.bottleneck_dim, d.out_dim, d.T_in, d.context_len = B, feat, int(bottleneck_dim), int(out_dim), t_in, int(context_len)
+    d.mode, d.bypass_scale = int(mode), float(bypass_scale)
+    d.wB_descale, d.wA_descale = _descale(wB, mode), _descale(wA, mode)
+    d.x, d.x_split, d.wB_packed, d.wA_packed = ptr(x), ptr(x_split), ptr(wB), ptr(wA)
+    d.bB, d.bA, d.bn_scale, d.bn_shift = ptr(bB), ptr(bA), ptr(bn_scale), ptr(bn_shift)
+    d.y, d.y_split, d.z, d.z_split = ptr(y), ptr(y_split), ptr(z), ptr(z_split)
+    check(lib().sat_tdnnf_layer_f32(C.byref(d), stream()), "sat_tdnnf_layer_f32")
+    return y
+
+
 def convpost(x, w, bias):
     x = _f32c(x)
     B, c, t = x.shape

@@ -292,6 +292,50 @@ def test_conv_pre_on_half_width_tiles_gives_the_same_bits():
         assert rms(ys[1].double().numpy() - ref.numpy()) < 1e-5 * rms(ref.numpy())
 
 
+@pytest.mark.parametrize("ctx,feat,bott,out,T,bypass", [(3, 1024, 128, 1024, 252, 0.66), (3, 80, 128, 1024, 61, 0.0), (1, 256, 64, 256, 40, 0.66),
+                                                       (2, 64, 40, 64, 33, 0.66)])
+def test_tdnnf_layer_call_equals_its_two_launches(ctx, feat, bott, out, T, bypass):
+    """sat_tdnnf_layer_f32 (one C-ABI call per TDNNF layer, chain/nn.py:267-347) against the two sat_conv1d_f32 calls it composes — bit for
+    bit in exact-f32 mode and on split planes — and against torch in float64: linearB over `ctx` frames, linearA, bypass from
+    identity_lidx frames in (chain/nn.py:233-247), BatchNorm (eval, no affine), ReLU"""
+    ops, packing = _ops()
+    B = 3
+    x = _rand(B, feat, T, seed=T).relu()
+    wB, wA = _rand(bott, feat, ctx, seed=1, scale=1.0 / np.sqrt(feat * ctx)), _rand(out, bott, 1, seed=2, scale=1.0 / np.sqrt(bott))
+    bB, bA = _rand(bott, seed=3, scale=0.1), _rand(out, seed=4, scale=0.1)
+    mean, var = _rand(out, seed=5, scale=0.1), _rand(out, seed=6).abs() + 0.5
+    scale, shift = 1.0 / torch.sqrt(var + 1e-5), -mean / torch.sqrt(var + 1e-5)
+    lidx = 1 if ctx == 2 else ctx // 2
+    t_q = T - (ctx - 1)
+    xd = x.double()
+    ref = F.conv1d(F.conv1d(xd, wB.double(), bB.double()), wA.double(), bA.double())
+    if bypass:
+        ref = ref + bypass * xd[:, :, lidx:lidx + t_q]
+    ref = F.relu(ref * scale.double()[None, :, None] + shift.double()[None, :, None])
+    dev = lambda t: t.to(DEV)
+    for mode, pack in ((0, packing.pack_conv_weight), (1, packing.pack_conv_weight_f16x3)):
+        pB, pA = pack(dev(wB)), pack(dev(wA))
+        planes = mode == 1 and bott % 16 == 0
+        xs = ops.act_split(dev(x), 1.0) if (mode == 1 and feat % 16 == 0) else None
+        kw = dict(res=dev(x), res_scale=bypass, res_toff=lidx) if bypass else {}
+        # the two launches
+        zs = ops.split_like(B, bott, t_q, DEV) if planes else None
+        z = ops.conv1d(dev(x), pB, bott, ctx, bias=dev(bB), pad_left=0, pad_right=0, mode=mode, x_split=xs,
+                       **(dict(y_split=zs, y_split_slope=1.0, no_y=True) if planes else {}))
+        ys2 = ops.split_like(B, out, t_q, DEV) if mode == 1 and out % 16 == 0 else None
+        y2 = ops.conv1d(z, pA, out, 1, bias=dev(bA), ch_scale=dev(scale), ch_shift=dev(shift), relu=True, mode=mode, x_split=zs, y_split=ys2,
+                        y_split_slope=1.0, **kw)
+        # the one call
+        ys1 = ops.split_like(B, out, t_q, DEV) if ys2 is not None else None
+        y1 = ops.tdnnf_layer(dev(x), pB, dev(bB), pA, dev(bA), bott, out, ctx, bn_scale=dev(scale), bn_shift=dev(shift), bypass_scale=bypass, mode=mode,
+                             x_split=xs, y_split=ys1, z_split=ops.split_like(B, bott, t_q, DEV) if planes else None)
+        assert y1.shape == (B, out, t_q) and torch.equal(y1, y2), (mode, ctx)
+        if ys1 is not None:
+            assert torch.equal(ys1, ys2)
+        err = rms(y1.double().cpu().numpy() - ref.numpy()) / rms(ref.numpy())
+        assert err < (2e-6 if mode == 0 else 5e-6), (mode, err)
+
+
 # ---------------------------------------------------------------------------------------------
 # front end and bottleneck
 # ---------------------------------------------------------------------------------------------
