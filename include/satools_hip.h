@@ -214,18 +214,20 @@ int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packe
  * behind one descriptor (subsampling factor 1; the strided and the 1.5-frame layers stay on sat_conv1d_f32 / sat_tdnnf_unfold15_f32).
  * Weights: packing of the conv view of the two Linear layers ([bottleneck][feat][context_len], [out][bottleneck][1]) for `mode`.
  * T_q = T_in - (context_len - 1).  On split planes (SAT_CONV_F16X3 with x_split / z_split / y_split, channel counts multiples of 16)
- * the bottleneck only exists as planes (z may be NULL); y (f32) is always written: it is the next layer's bypass. */
+ * the bottleneck only exists as planes (z may be NULL).  Planes only: with x = NULL (and x_split) the bypass is rebuilt from the input
+ * planes (hi + lo: 22 significand bits of x), with y = NULL (and y_split) the f32 output is not stored — a chain of layers then moves
+ * one tensor per layer through HBM instead of two. */
 typedef struct {
   int32_t B, feat_dim, bottleneck_dim, out_dim, T_in, context_len;
   int32_t mode;                    /* SAT_CONV_F32 or SAT_CONV_F16X3 */
   float bypass_scale;              /* 0 = no bypass (else out_dim == feat_dim and x is needed) */
   float wB_descale, wA_descale;    /* sat_conv1d_desc.w_descale of the two packings (0 = 1) */
-  const float* x;                  /* [B][feat_dim][T_in] or NULL (then x_split, no bypass) */
+  const float* x;                  /* [B][feat_dim][T_in], or NULL (then x_split: input AND bypass come from the planes) */
   const void* x_split;             /* SAT_SPLIT_F16 planes of x, or NULL */
   const void *wB_packed, *wA_packed;
   const float *bB, *bA;            /* biases or NULL */
   const float *bn_scale, *bn_shift;/* [out_dim] or NULL */
-  float* y;                        /* [B][out_dim][T_q] */
+  float* y;                        /* [B][out_dim][T_q], or NULL (then y_split alone) */
   void* y_split;                   /* also planes of y, or NULL */
   float* z;                        /* [B][bottleneck_dim][T_q] scratch, or NULL when z_split serves */
   void* z_split;                   /* planes scratch of the bottleneck, or NULL */

@@ -323,11 +323,34 @@ class _TdnnfBase(nn.Module):
         self._cache_key = key
         _lib.cache_rebuild_end(device)
 
-    def _tdnnf_layer(self, lay, c, x, xs=None, return_bottleneck=False, want_aux=False, row_frames=None, tie=None):
+    #: inside the bottleneck stack the layers hand on split planes ONLY (no f32 store of a layer's output, the bypass rebuilt from the input
+    #: planes; sat_tdnnf_layer_f32 with x = y = NULL): SATOOLS_AMD_TDNNF_PLANES_ONLY=0 keeps the f32 tensors
+    tdnnf_planes_only = os.environ.get("SATOOLS_AMD_TDNNF_PLANES_ONLY", "1") != "0"
+
+    @staticmethod
+    def _takes_planes(lay, c, channels, need_z=False):
+        """does `_tdnnf_layer` read this layer's input from split planes alone (never the f32 tensor)?  A plain layer does (linearB and,
+        inside sat_tdnnf_layer_f32, the bypass); a subsampling layer only when it has no bypass (its strided bypass reads the f32 input)"""
+        sub = lay.subsampling_factor
+        if c.modeB != 1 or c.modeA != 1 or channels % 16 or sub == 1.5:
+            return False
+        if int(sub) == 1:
+            # (the layer with the quantiser inside / the bottleneck read-out multiplies the planes and has no bypass to take from f32)
+            return need_z or (c.codebook is None and lay.bottleneck_dim % 16 == 0 and lay.out_dim % 16 == 0)
+        return (not need_z and not lay.use_bypass and channels % 64 == 0 and lay.bottleneck_dim % 16 == 0 and c.codebook is None)
+
+    def _plain_on_planes(self, lay, c, channels):
+        """a layer `_tdnnf_layer` serves by sat_tdnnf_layer_f32 with planes in, planes out and the bottleneck as planes"""
+        return (int(lay.subsampling_factor) == 1 and lay.subsampling_factor != 1.5 and c.codebook is None and c.modeA == 1 and c.modeB == 1 and
+                channels % 16 == 0 and lay.bottleneck_dim % 16 == 0 and lay.out_dim % 16 == 0)
+
+    def _tdnnf_layer(self, lay, c, x, xs=None, return_bottleneck=False, want_aux=False, row_frames=None, tie=None, skip_f32=False, x_valid=True):
         """x [B, feat, T] -> [B, out, T'] (or the bottleneck [B, bott, T']).  In split-f16 mode the layers
         hand their activations on as split planes as well (`xs`, csrc/conv1d_mfma.hip): linearB then
         stages its 1024 x 3 input with 16-byte copies and linearA reads the bottleneck from planes; the
-        f32 tensor stays for the bypass connection.  Returns (y, planes of y or None)."""
+        f32 tensor stays for the bypass connection.  Returns (y, planes of y or None).
+        skip_f32: the f32 output is not stored (y is then an unwritten shape carrier: the successor takes the planes); x_valid = False:
+        `x` is such a carrier and the bypass is rebuilt from `xs` — both only where _plain_on_planes holds (_run_stack decides)."""
         ctx, sub = lay.context_len, int(lay.subsampling_factor)
         B = x.shape[0]
         if lay.subsampling_factor == 1.5:
@@ -356,8 +379,10 @@ class _TdnnfBase(nn.Module):
             ys = ops.split_like(B, lay.out_dim, t_q, x.device) if (c.modeA == 1 and lay.out_dim % 16 == 0) else None
             y = ops.tdnnf_layer(x, c.wB, c.bB, c.wA, c.bA, lay.bottleneck_dim, lay.out_dim, ctx, bn_scale=c.scale, bn_shift=c.shift,
                                 bypass_scale=float(lay.bypass_scale) if lay.use_bypass else 0.0, mode=c.modeB,
-                                x_split=xs if planes_in else None, y_split=ys, z_split=zs)
+                                x_split=xs if planes_in else None, y_split=ys, z_split=zs, no_y=skip_f32, bypass_from_planes=not x_valid)
             return y, ys
+        assert x_valid or (c.modeB == 1 and xs is not None), "an unwritten f32 input reached a layer that reads it"
+
         zs = None
         if planes_in and not need_z and lay.bottleneck_dim % 16 == 0:
             t_q = x.shape[2] - (ctx - 1)
@@ -431,10 +456,15 @@ class _TdnnfBase(nn.Module):
         """x [B, C, T] (already padded) through tdnn1, tdnnfs[:-2], and the bottleneck of tdnnfs[-2]"""
         self._prepare(x.device)
         layers = self._stack_layers()
-        xs = None
-        for lay, c in zip(layers[:-1], self._cache[:-1]):
-            x, xs = self._tdnnf_layer(lay, c, x, xs)
-        return self._tdnnf_layer(layers[-1], self._cache[-1], x, xs, return_bottleneck=True, want_aux=want_aux, tie=tie)
+        xs, valid = None, True
+        for i, (lay, c) in enumerate(zip(layers[:-1], self._cache[:-1])):
+            # a layer whose successor reads its input from planes alone writes no f32 output; its successor then rebuilds the bypass from planes
+            nxt, cn = layers[i + 1], self._cache[i + 1]
+            skip = (self.tdnnf_planes_only and self._plain_on_planes(lay, c, x.shape[1]) and (xs is not None or not lay.use_bypass) and
+                    self._takes_planes(nxt, cn, lay.out_dim, need_z=i + 2 == len(layers)))
+            x, xs = self._tdnnf_layer(lay, c, x, xs, skip_f32=skip, x_valid=valid)
+            valid = not skip
+        return self._tdnnf_layer(layers[-1], self._cache[-1], x, xs, return_bottleneck=True, want_aux=want_aux, tie=tie, x_valid=valid)
 
     # ---- exact VQ indices in the default arithmetic: near-ties counted on the device, their utterances decided again ----------
     def _precision_keys(self):

@@ -1805,12 +1805,18 @@ static int conv1d_prepare(const sat_conv1d_desc* d, const float* x, const void* 
   return SAT_OK;
 }
 
+static int conv1d_dispatch(const sat_conv1d_desc* d, ConvArgs& a, hipStream_t s);
+
 extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const void* w_packed,
                               float* y, void* stream) {
   ConvArgs a;
   int st = conv1d_prepare(d, x, w_packed, y, a);
   if (st != SAT_OK) return st;
-  hipStream_t s = (hipStream_t)stream;
+  return conv1d_dispatch(d, a, (hipStream_t)stream);
+}
+
+// the kernel choice for a prepared conv (sat_conv1d_f32; sat_tdnnf_layer_f32 enters here with the bypass planes' geometry set)
+static int conv1d_dispatch(const sat_conv1d_desc* d, ConvArgs& a, hipStream_t s) {
   if (d->mode == SAT_CONV_F16F8R) {
     SAT_REQUIRE(d->groups == 1 && convring_supports(a, d->B),
                 "conv1d(f16f8r): served by the LDS-DMA ring kernel only (C_out > 64, C_in %% 32 == 0, ksize >= 3, halo <= 64, bias, plain / "
@@ -1875,7 +1881,8 @@ extern "C" int sat_conv1d_f32(const sat_conv1d_desc* d, const float* x, const vo
 // bias, bypass from the layer input identity_lidx frames in, folded BatchNorm, ReLU) behind ONE descriptor — the host composes nothing
 // between them, and the bottleneck never has to exist as f32 when the layer runs on split planes.
 extern "C" int sat_tdnnf_layer_f32(const sat_tdnnf_layer_desc* d, void* stream) {
-  SAT_REQUIRE(d && d->wB_packed && d->wA_packed && d->y, "tdnnf_layer: null pointer");
+  SAT_REQUIRE(d && d->wB_packed && d->wA_packed, "tdnnf_layer: null pointer");
+  SAT_REQUIRE(d->y || (d->y_split && d->mode == SAT_CONV_F16X3), "tdnnf_layer: y, or (split planes) y_split alone");
   SAT_REQUIRE(d->B > 0 && d->feat_dim > 0 && d->bottleneck_dim > 0 && d->out_dim > 0 && d->context_len >= 1 && d->T_in >= d->context_len,
               "tdnnf_layer: unsupported shape");
   SAT_REQUIRE(d->mode == SAT_CONV_F32 || d->mode == SAT_CONV_F16X3, "tdnnf_layer: mode must be SAT_CONV_F32 or SAT_CONV_F16X3");
@@ -1883,7 +1890,10 @@ extern "C" int sat_tdnnf_layer_f32(const sat_tdnnf_layer_desc* d, void* stream) 
   const int T_q = d->T_in - (d->context_len - 1);
   const bool planes = d->mode == SAT_CONV_F16X3 && d->z_split && d->bottleneck_dim % 16 == 0;
   SAT_REQUIRE(planes || d->z, "tdnnf_layer: the bottleneck needs z (f32) or, on split planes, z_split");
-  SAT_REQUIRE(d->bypass_scale == 0.f || (d->x && d->out_dim == d->feat_dim), "tdnnf_layer: the bypass adds the f32 layer input (out_dim == feat_dim)");
+  const bool bypass_planes = d->bypass_scale != 0.f && !d->x;      // no f32 input: the bypass is rebuilt from the input planes (hi + lo)
+  SAT_REQUIRE(d->bypass_scale == 0.f || d->out_dim == d->feat_dim, "tdnnf_layer: the bypass adds the layer input (out_dim == feat_dim)");
+  SAT_REQUIRE(!bypass_planes || (d->x_split && d->mode == SAT_CONV_F16X3 && d->feat_dim % 16 == 0),
+              "tdnnf_layer: a bypass without the f32 input needs x_split (SAT_CONV_F16X3, feat_dim %% 16 == 0)");
   sat_conv1d_desc b{};
   b.B = d->B, b.C_in = d->feat_dim, b.T_in = d->T_in, b.C_out = d->bottleneck_dim, b.T_q = T_q;
   b.ksize = d->context_len, b.dilation = 1, b.stride = 1, b.pad_left = 0, b.mode = d->mode, b.groups = 1, b.up = 1;
@@ -1904,14 +1914,27 @@ extern "C" int sat_tdnnf_layer_f32(const sat_tdnnf_layer_desc* d, void* stream) 
   a.bias = d->bA, a.ch_scale = d->bn_scale, a.ch_shift = d->bn_shift, a.relu = 1;
   a.w_descale = d->wA_descale;
   a.res_tstride = 1;
-  if (d->bypass_scale != 0.f) {
+  const int lidx = d->context_len == 2 ? 1 : d->context_len / 2;      // identity_lidx, chain/nn.py:233-247
+  if (d->bypass_scale != 0.f && !bypass_planes) {
     a.res = d->x, a.res_scale = d->bypass_scale;
-    a.res_toff = d->context_len == 2 ? 1 : d->context_len / 2;      // identity_lidx, chain/nn.py:233-247
+    a.res_toff = lidx;
     a.res_cstride = d->T_in, a.res_bstride = (int64_t)d->feat_dim * d->T_in;
+  } else if (bypass_planes) {
+    a.res_split = d->x_split, a.res_split_slope = 1.0f, a.res_scale = d->bypass_scale;
   }
   if (planes) a.x_split = d->z_split;
   if (d->y_split && d->mode == SAT_CONV_F16X3) a.y_split = d->y_split, a.y_split_slope = 1.0f;
-  return sat_conv1d_f32(&a, planes ? (const float*)d->z_split : d->z, d->wA_packed, d->y, stream);
+  if (!d->y) a.no_y = 1;
+  ConvArgs args;
+  st = conv1d_prepare(&a, planes ? (const float*)d->z_split : d->z, d->wA_packed, d->y, args);
+  if (st != SAT_OK) return st;
+  if (bypass_planes) {
+    // the bypass planes are the layer INPUT: rows of T_in positions, output column 0 <-> position identity_lidx (the common epilogues
+    // of the 1x1 GEMM kernels take both; conv_common.h res16_T / res16_toff)
+    SAT_REQUIRE((long long)d->feat_dim * d->T_in * 4 < (1LL << 31), "tdnnf_layer: input slab too large for 31-bit offsets");
+    args.res16_T = d->T_in, args.res16_toff = lidx;
+  }
+  return conv1d_dispatch(&a, args, (hipStream_t)stream);
 }
 
 extern "C" int sat_conv1d_multi_f32(const sat_conv1d_desc* d, const float* const* x, const void* const* w_packed, float* const* y,

@@ -86,6 +86,7 @@ struct ConvArgs {
   int no_y;
   const void* res16;     // residual as SAT_SPLIT_F16 planes of lrelu(r, res16_slope) (inverted on the fly), or null
   float res16_inv;       // 1 / slope
+  int res16_T, res16_toff;   // row length of the residual planes (0 = T_q) and the position of output column 0 in them (the TDNNF bypass: the layer input, identity_lidx frames in)
   int f8;                // planes kernels: cross terms hi*lo + lo*hi on the block-scaled e4m3 MFMA
   int poly_planes;       // up > 1, planes only: the LDS-transposed polyphase epilogue
   int up_grouped;        // up = 4, rows (16-channel group, phase, channel): conv_ring16.hip's upsampler form
@@ -138,8 +139,9 @@ __device__ __forceinline__ void epilogue_prefetch_res(const ConvArgs& p, float (
   const int r_rb = (int)p.r_cs * 4;
   if (p.res16) {
     // residual from the split planes: per 4 consecutive rows the 8-byte hi and lo words of this column (raw)
+    const int rT = p.res16_T > 0 ? p.res16_T : p.T_q, rO = p.res16_toff;
     const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.res16 + (long long)b * p.rows_g * p.T_q * 4), 0, (unsigned)(p.rows_g * p.T_q * 4), 0x00020000);
+        (void*)((const char*)p.res16 + (long long)b * p.rows_g * rT * 4), 0, (unsigned)(p.rows_g * rT * 4), 0x00020000);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -149,10 +151,10 @@ __device__ __forceinline__ void epilogue_prefetch_res(const ConvArgs& p, float (
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int chunk = ((co_w + m * 32) >> 4) + (rg >> 1);
-          const unsigned off = (qok && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (rg & 1)) * p.T_q + q) * 16 + 8 * lh) : 0x80000000u;
+          const unsigned off = (qok && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (rg & 1)) * rT + q + rO) * 16 + 8 * lh) : 0x80000000u;
           const uint4 hv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 0, 0));   // narrowed to 8 bytes (the b64 builtin of this hipcc loads one dword)
           const unsigned hv[2] = {hv4.x, hv4.y};
-          const uint4 lv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * p.T_q * 16, 0));
+          const uint4 lv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * rT * 16, 0));
           const unsigned lv[2] = {lv4.x, lv4.y};
           rpre[m][n][4 * rg + 0] = __builtin_bit_cast(float, hv[0]);
           rpre[m][n][4 * rg + 1] = __builtin_bit_cast(float, hv[1]);
@@ -218,9 +220,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
     const __amdgpu_buffer_rsrc_t shs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.ch_shift ? p.ch_shift + chb : p.y), 0, p.ch_shift ? chn : 0u, 0x00020000);
     const int y_rb = (int)p.y_cs * 4, r_rb = (int)p.r_cs * 4;  // bytes per row
+    const int rT = p.res16_T > 0 ? p.res16_T : p.T_q, rO = p.res16_toff;
     const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.res16 ? (char*)p.res16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
-        p.res16 ? (unsigned)(p.rows_g * p.T_q * 4) : 0u, 0x00020000);
+        (void*)(p.res16 ? (char*)p.res16 + (long long)b * p.rows_g * rT * 4 : (char*)p.y), 0,
+        p.res16 ? (unsigned)(p.rows_g * rT * 4) : 0u, 0x00020000);
     const bool has_res = p.res != nullptr || p.res16 != nullptr;
     const __amdgpu_buffer_rsrc_t y16rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.y16 ? (char*)p.y16 + (long long)b * p.rows_g * p.T_q * 4 : (char*)p.y), 0,
@@ -256,10 +259,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
               for (int k = 0; k < 4; ++k) raw[4 * rg + k] = rpre[m][n][4 * rg + k];
             } else {
               const int chunk = ((co_w + m * 32) >> 4) + (rg >> 1);
-              const unsigned off = (qok && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (rg & 1)) * p.T_q + q) * 16 + 8 * lh) : OOB;
+              const unsigned off = (qok && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (rg & 1)) * rT + q + rO) * 16 + 8 * lh) : OOB;
               const uint4 hv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 0, 0));   // narrowed to 8 bytes (the b64 builtin of this hipcc loads one dword)
           const unsigned hv[2] = {hv4.x, hv4.y};
-              const uint4 lv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * p.T_q * 16, 0));
+              const uint4 lv4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r16rs, off, 2 * rT * 16, 0));
           const unsigned lv[2] = {lv4.x, lv4.y};
               raw[4 * rg + 0] = __builtin_bit_cast(float, hv[0]);
               raw[4 * rg + 1] = __builtin_bit_cast(float, hv[1]);
@@ -472,17 +475,18 @@ template <int NT>
 __device__ __forceinline__ void epilogue16_load_res_row(const ConvArgs& p, f32x4 (&out)[NT], int b, int co_r, int q_w, int li, int lg) {
   const unsigned OOB = 0x80000000u;
   if (p.res16) {
+    const int rT = p.res16_T > 0 ? p.res16_T : p.T_q, rO = p.res16_toff;
     const __amdgpu_buffer_rsrc_t r16rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.res16 + (long long)b * p.rows_g * p.T_q * 4), 0, (unsigned)(p.rows_g * p.T_q * 4), 0x00020000);
+        (void*)((const char*)p.res16 + (long long)b * p.rows_g * rT * 4), 0, (unsigned)(p.rows_g * rT * 4), 0x00020000);
     const int chunk = co_r >> 4;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int q = q_w + n * 16 + li;
-      const unsigned off = (q < p.T_q && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (lg >> 1)) * p.T_q + q) * 16 + 8 * (lg & 1)) : OOB;
+      const unsigned off = (q < p.T_q && chunk * 16 < p.rows_g) ? (unsigned)(((chunk * 4 + (lg >> 1)) * rT + q + rO) * 16 + 8 * (lg & 1)) : OOB;
       // exactly the 8 bytes of this lane's four channels, as two dwords (the b64 load builtin of this hipcc loads one dword, and
       // a 16-byte load at an 8-byte offset would reach past the last unit of the plane image)
       const unsigned h0 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 0, 0), h1 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 4, 0);
-      const unsigned l0 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 2 * p.T_q * 16, 0), l1 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 2 * p.T_q * 16 + 4, 0);
+      const unsigned l0 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 2 * rT * 16, 0), l1 = __builtin_amdgcn_raw_buffer_load_b32(r16rs, off, 2 * rT * 16 + 4, 0);
       out[n] = f32x4{__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1), __builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1)};
     }
     return;

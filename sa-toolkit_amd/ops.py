@@ -153,12 +153,20 @@ def _conv1d_desc(x, w_packed, c_out, ksize, *, bias=None, dilation=1, stride=1, 
 
 
 def tdnnf_layer(x, wB, bB, wA, bA, bottleneck_dim, out_dim, context_len, *, bn_scale=None, bn_shift=None, bypass_scale=0.0, mode=0,
-                x_split=None, y_split=None, z_split=None):
+                x_split=None, y_split=None, z_split=None, no_y=False, bypass_from_planes=False):
     """One TDNNF layer in ONE C-ABI call (sat_tdnnf_layer_f32; chain/nn.py:267-347): linearB over `context_len` frames, linearA, the bypass
     `bypass_scale * x[t + identity_lidx]`, folded BatchNorm, ReLU.  x [B, feat, T_in] f32 -> y [B, out_dim, T_in - context_len + 1];
     on split planes (mode=CONV_F16X3 with `x_split` and a `z_split` scratch) the bottleneck exists only as planes and `y_split`
-    also receives the planes of y.  The two launches (and the bits) of the two conv1d calls it replaces."""
-    x = _f32c(x)
+    also receives the planes of y.  The two launches (and the bits) of the two conv1d calls it replaces.
+    On split planes: `no_y` — y is not stored (the returned tensor is an UNINITIALISED shape carrier for a successor that takes `y_split`);
+    `bypass_from_planes` — `x` only gives the shape (it may be such a carrier) and the bypass is rebuilt from `x_split` (hi + lo: 22
+    significand bits of the input)."""
+    on_planes = int(mode) == _lib.CONV_F16X3 and z_split is not None
+    no_y = bool(no_y) and on_planes and y_split is not None
+    x_unused = bool(bypass_from_planes) and on_planes and x_split is not None
+    if bypass_from_planes and not x_unused:
+        raise _lib.SatError("tdnnf_layer: bypass_from_planes needs mode=CONV_F16X3 with x_split and z_split")
+    x = x if x_unused else _f32c(x)
     B, feat, t_in = x.shape
     t_q = t_in - (int(context_len) - 1)
     if t_q <= 0:
@@ -170,9 +178,9 @@ def tdnnf_layer(x, wB, bB, wA, bA, bottleneck_dim, out_dim, context_len, *, bn_s
     d.B, d.feat_dim, d.bottleneck_dim, d.out_dim, d.T_in, d.context_len = B, feat, int(bottleneck_dim), int(out_dim), t_in, int(context_len)
     d.mode, d.bypass_scale = int(mode), float(bypass_scale)
     d.wB_descale, d.wA_descale = _descale(wB, mode), _descale(wA, mode)
-    d.x, d.x_split, d.wB_packed, d.wA_packed = ptr(x), ptr(x_split), ptr(wB), ptr(wA)
+    d.x, d.x_split, d.wB_packed, d.wA_packed = (None if x_unused else ptr(x)), ptr(x_split), ptr(wB), ptr(wA)
     d.bB, d.bA, d.bn_scale, d.bn_shift = ptr(bB), ptr(bA), ptr(bn_scale), ptr(bn_shift)
-    d.y, d.y_split, d.z, d.z_split = ptr(y), ptr(y_split), ptr(z), ptr(z_split)
+    d.y, d.y_split, d.z, d.z_split = (None if no_y else ptr(y)), ptr(y_split), ptr(z), ptr(z_split)
     check(lib().sat_tdnnf_layer_f32(C.byref(d), stream()), "sat_tdnnf_layer_f32")
     return y
 

@@ -21,6 +21,11 @@ def _rand(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
+def _lib_err():
+    from satools_amd import _lib
+    return _lib.SatError
+
+
 class conv_option:
     """sat_conv_set_option(name, value) for the duration of a with-block (restored to `default` afterwards)"""
 
@@ -334,6 +339,21 @@ def test_tdnnf_layer_call_equals_its_two_launches(ctx, feat, bott, out, T, bypas
             assert torch.equal(ys1, ys2)
         err = rms(y1.double().cpu().numpy() - ref.numpy()) / rms(ref.numpy())
         assert err < (2e-6 if mode == 0 else 5e-6), (mode, err)
+        if planes and xs is not None and ys1 is not None:
+            # planes only: no f32 output, the bypass rebuilt from the input planes (22 significand bits of x); `x` is a shape carrier
+            ys3 = ops.split_like(B, out, t_q, DEV)
+            carrier = torch.full((B, feat, T), float("nan"), device=DEV)
+            y3 = ops.tdnnf_layer(carrier, pB, dev(bB), pA, dev(bA), bott, out, ctx, bn_scale=dev(scale), bn_shift=dev(shift), bypass_scale=bypass,
+                                 mode=mode, x_split=xs, y_split=ys3, z_split=ops.split_like(B, bott, t_q, DEV), no_y=True, bypass_from_planes=True)
+            assert y3.shape == (B, out, t_q)
+            got = ops.unsplit(ys3).double().cpu().numpy()
+            assert np.isfinite(got).all() and rms(got - ref.numpy()) / rms(ref.numpy()) < 5e-6
+            if not bypass:
+                assert torch.equal(ys3, ys1)
+    if feat % 16 == 0:
+        with pytest.raises(_lib_err()):
+            ops.tdnnf_layer(dev(x), packing.pack_conv_weight(dev(wB)), dev(bB), packing.pack_conv_weight(dev(wA)), dev(bA), bott, out, ctx,
+                            bypass_scale=bypass, mode=0, bypass_from_planes=True)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -408,6 +428,38 @@ def test_extract_bn_matches_oracle_and_golden(model, gold, fbank_tag_state, prec
         _check_extract_bn(model, gold, fbank_tag_state)
     finally:
         model.bn_extractor.precision = type(model.bn_extractor).precision
+
+
+def test_bottleneck_stack_on_planes_only_against_the_f32_hand_over(model):
+    """inside the bottleneck stack a plain layer hands on split planes only (no f32 store, the bypass rebuilt from the input planes:
+    sat_tdnnf_layer_f32 with x = y = NULL, `tdnnf_planes_only`) — against the stack whose layers also write and read the f32 tensors:
+    features within the split-f16 error (1e-5 relative), the same VQ indices, and the stack of the exact-f32 setting untouched"""
+    from satools_amd import synthetic
+    ext = model.bn_extractor
+    wav = synthetic.harm_batch([3, 4, 5], 80000).to(DEV)
+    keep, sig = ext.tdnnf_planes_only, ext.vq_tie_sigmas
+    ext.vq_tie_sigmas = 0.0
+    try:
+        res = {}
+        for v in (False, True):
+            ext.tdnnf_planes_only = v
+            bn, (z, idx, _) = ext.extract_bn(wav.clone(), want_aux=True)
+            res[v] = (bn.clone(), z.clone(), idx.clone())
+        ext.precision = "f32"
+        e32 = {}
+        for v in (False, True):
+            ext.tdnnf_planes_only = v
+            e32[v] = ext.extract_bn(wav.clone()).clone()
+    finally:
+        ext.tdnnf_planes_only, ext.vq_tie_sigmas = keep, sig
+        ext.precision = type(ext).precision
+    assert torch.isfinite(res[True][1]).all()
+    err = rms((res[True][1] - res[False][1]).cpu().numpy()) / rms(res[False][1].cpu().numpy())
+    print(f"pre-quantiser features, planes only vs f32 hand-over: {err:.2e} relative RMS; indices equal: {bool(torch.equal(res[True][2], res[False][2]))}")
+    assert 0 < err < 1e-5
+    assert torch.equal(res[True][2], res[False][2])
+    assert (res[True][0] - res[False][0]).abs().max() < 1e-5          # x + (q - x): the same codes, the last bit of the sum follows x
+    assert torch.equal(e32[True], e32[False])
 
 
 def _check_extract_bn(model, gold, fbank_tag_state):
